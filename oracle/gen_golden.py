@@ -1,0 +1,350 @@
+"""
+oracle/gen_golden.py -- TEST INFRASTRUCTURE.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own Python (third-party modules that are absent here are stubbed in
+sys.modules, in memory), runs its functions on CPU with fixed seeds and stores inputs + outputs
+as small .npz fixtures under tests/golden/.  The reference source never travels; the fixtures are
+data.  Re-run:  python oracle/gen_golden.py
+
+Fixtures:
+  g1_rays      get_camera_rays / get_rays / get_rays_from_uv / get_samples / get_samples_all
+  g2_zsample   Renderer z-sampling (depth-guided) with and without perturbation
+  g3_composite sdf2alpha + compositing 7-tuple + gradients
+  g4_decoders  Decoders torch-MLP path: outputs + parameter / input gradients
+  g5_losses    sdf_losses (incl. empty-mask NaN) ; mapping/tracking loss come through g8/g9
+  g6_zerodepth zero-depth branch + sample_pdf (un-normalised pdf quirk)
+  g7_render    render_batch_ray fwd+bwd through reference Renderer+Decoders with the oracle's CPU
+               hash grid plugged in as scene_rep (pins everything AROUND the encoder)
+  g8_tracking  Tracker.optimize_tracking, one full iteration (dummy self)
+  g9_mapping   Mapper.optimize_mapping, two full iterations incl. Adam (dummy self)
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+import unislam_oracle as O  # noqa: E402
+
+for m in ["pytorch3d", "pytorch3d.transforms", "tinycudann", "colorama", "cv2", "skimage", "skimage.metrics",
+          "open3d", "trimesh", "torchmetrics", "pytorch_msssim", "torchmetrics.image", "torchmetrics.image.lpip"]:
+    sys.modules[m] = MagicMock()
+# pytorch3d is absent: the pose helper is build-owned (parity unpinned for it); give the reference our restatement
+sys.modules["pytorch3d.transforms"].quaternion_to_matrix = O.quaternion_to_matrix
+sys.path.insert(0, REF)
+import warnings  # noqa: E402
+warnings.simplefilter("ignore")
+from src import common as RC  # noqa: E402
+from src.utils.Renderer import Renderer as RefRenderer  # noqa: E402
+from src.networks.decoders import Decoders as RefDecoders  # noqa: E402
+from src.Mapper import Mapper as RefMapper  # noqa: E402
+from src.Tracker import Tracker as RefTracker  # noqa: E402
+import src.Tracker as RT  # noqa: E402
+import src.Mapper as RM  # noqa: E402
+
+RC.quaternion_to_matrix = O.quaternion_to_matrix
+DEV = "cpu"
+
+
+def npz(name, **kw):
+    os.makedirs(OUT, exist_ok=True)
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in kw.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"{name}: {sum(a.nbytes for a in arrs.values())/1024:.1f} KiB raw, keys={list(arrs)}")
+
+
+def rand_c2w(g, n):
+    q = torch.randn(n, 4, generator=g); q = q / q.norm(dim=-1, keepdim=True)
+    c = torch.eye(4).repeat(n, 1, 1)
+    c[:, :3, :3] = O.quaternion_to_matrix(q); c[:, :3, 3] = torch.randn(n, 3, generator=g) * 0.3
+    return c
+
+
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])      # Replica room0 (configs/Replica/room0.yaml:3)
+
+
+def make_cfg(n_strat, n_imp, perturb, tcnn_network=False):
+    return {"rendering": {"perturb": perturb, "n_stratified": n_strat, "n_importance": n_imp},
+            "scale": 1, "grid_mode": "hash_grid", "grid": {"tcnn_network": tcnn_network}}
+
+
+def make_renderer(cfg, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5):
+    u = types.SimpleNamespace(bound=BOUND, device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy)
+    return RefRenderer(cfg, u)
+
+
+def small_grid(seed, log2T=10, res=64, amp=0.5):
+    enc = O.HashGridOracle(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
+                               "log2_hashmap_size": log2T, "base_resolution": 16,
+                               "per_level_scale": O.per_level_scale(res)})
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        enc.params.copy_((torch.rand(enc.params.shape, generator=g) * 2 - 1) * amp)
+    return enc
+
+
+def g1():
+    g = torch.Generator().manual_seed(1)
+    H, W, fx, fy, cx, cy = 12, 16, 11.0, 12.0, 7.5, 5.5
+    cam = RC.get_camera_rays(H, W, fx, fy, cx, cy)
+    c2w = rand_c2w(g, 3)
+    ro, rd = RC.get_rays(H, W, fx, fy, cx, cy, c2w[0], DEV)
+    depths = torch.rand(3, H, W, generator=g) * 3; colors = torch.rand(3, H, W, 3, generator=g)
+    # get_samples (tracking): crop 2..H-2, 3..W-3; b=1 is what the tracker uses, b=3 also exercised
+    torch.manual_seed(11)
+    s1 = RC.get_samples(2, H - 2, 3, W - 3, 7, H, W, fx, fy, cx, cy, c2w[:1], depths[:1], colors[:1], DEV)
+    torch.manual_seed(11)
+    idx1 = torch.randint((H - 4) * (W - 6), (7 * 1,))
+    torch.manual_seed(12)
+    s3 = RC.get_samples(0, H, 0, W, 5, H, W, fx, fy, cx, cy, c2w, depths, colors, DEV)
+    torch.manual_seed(12)
+    idx3 = torch.randint(H * W, (5 * 3,))
+    # get_samples_all (mapping): pools of P pixels
+    P = 40
+    pool_idx = torch.stack([torch.randperm(H * W, generator=g)[:P] for _ in range(3)])
+    pd = torch.gather(depths.reshape(3, -1), 1, pool_idx)
+    pc = torch.gather(colors.reshape(3, -1, 3), 1, pool_idx.unsqueeze(-1).expand(-1, -1, 3))
+    pr = cam.reshape(-1, 3)[pool_idx]
+    torch.manual_seed(13)
+    sa = RC.get_samples_all(0, H, 0, W, 6, H, W, fx, fy, cx, cy, c2w, pd, pc, DEV, pr)
+    torch.manual_seed(13)
+    idxa = torch.randint(P, (6 * 3,)).reshape(3, -1)
+    npz("g1_rays", intr=np.array([H, W, fx, fy, cx, cy]), cam=cam, c2w=c2w, rays_o=ro, rays_d=rd, depths=depths,
+        colors=colors, s1_idx=idx1, s1_o=s1[0], s1_d=s1[1], s1_depth=s1[2], s1_color=s1[3],
+        s3_idx=idx3, s3_o=s3[0], s3_d=s3[1], s3_depth=s3[2], s3_color=s3[3],
+        pool_d=pd, pool_c=pc, pool_r=pr, sa_idx=idxa, sa_o=sa[0], sa_d=sa[1], sa_depth=sa[2], sa_color=sa[3])
+
+
+class _ConstDecoders:
+    """stand-in decoders so that render_batch_ray returns z_vals without any model in the loop"""
+    beta = 10
+
+    def __call__(self, pts, scene_rep):
+        return torch.zeros(*pts.shape[:-1], 4)
+
+
+def g2():
+    g = torch.Generator().manual_seed(2)
+    R = 32
+    gt = torch.rand(R, generator=g) * 3 + 0.3
+    ro = torch.zeros(R, 3); rd = torch.randn(R, 3, generator=g)
+    out = {"gt_depth": gt, "truncation": np.float64(0.06)}
+    for (ns, ni) in [(32, 8), (48, 8)]:
+        for perturb in (False, True):
+            r = make_renderer(make_cfg(ns, ni, perturb))
+            torch.manual_seed(21)
+            z = r.render_batch_ray(None, _ConstDecoders(), rd, ro, DEV, 0.06, gt_depth=gt)[5]
+            key = f"z_{ns}_{ni}_{int(perturb)}"
+            out[key] = z
+            if perturb:
+                torch.manual_seed(21)
+                out[f"trand_{ns}_{ni}"] = torch.rand(R, ns + ni)
+    npz("g2_zsample", **out)
+
+
+class _FixedRawDecoders:
+    """decoders stub that returns a fixed raw[R,S,4] leaf: drives the reference's compositing lines in isolation"""
+
+    def __init__(self, raw, beta):
+        self.raw, self.beta = raw, beta
+
+    def __call__(self, pts, scene_rep):
+        return self.raw
+
+
+def g3():
+    g = torch.Generator().manual_seed(3)
+    R, S = 24, 40
+    out = {"truncation": np.float64(0.06)}
+    for tag, beta0 in [("b10", 10.0), ("b73", 7.3)]:
+        raw = torch.randn(R, S, 4, generator=g) * 0.5
+        raw[..., :3] = torch.sigmoid(raw[..., :3])
+        raw[..., 3] = torch.tanh(raw[..., 3] + torch.linspace(1.5, -1.5, S))       # sdf crossing zero along the ray
+        raw.requires_grad_(True)
+        beta = torch.nn.Parameter(torch.tensor([beta0]))
+        gt = torch.rand(R, generator=g) * 3 + 0.3
+        ro = torch.zeros(R, 3); rd = torch.randn(R, 3, generator=g)
+        r = make_renderer(make_cfg(32, 8, False))
+        term, unc, depth, rgb, sdf, z, dunc = r.render_batch_ray(None, _FixedRawDecoders(raw, beta), rd, ro, DEV, 0.06, gt_depth=gt)
+        outs = dict(term=term, unc=unc, depth=depth, rgb=rgb, dunc=dunc)
+        probes = {k: torch.randn(v.shape, generator=g) for k, v in outs.items()}
+        sum((probes[k] * v).sum() for k, v in outs.items()).backward()
+        out.update({f"{tag}_raw": raw, f"{tag}_gt": gt, f"{tag}_beta": beta, f"{tag}_z": z, f"{tag}_draw": raw.grad,
+                    f"{tag}_dbeta": beta.grad, f"{tag}_sdf": sdf})
+        out.update({f"{tag}_{k}": v for k, v in outs.items()})
+        out.update({f"{tag}_probe_{k}": v for k, v in probes.items()})
+    npz("g3_composite", **out)
+
+
+def g4():
+    g = torch.Generator().manual_seed(4)
+    cfg = make_cfg(32, 8, False)
+    dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    N = 96
+    feat_s = (torch.randn(N, 32, generator=g) * 0.7).requires_grad_(True)
+    feat_c = (torch.randn(N, 32, generator=g) * 0.7).requires_grad_(True)
+    sr = ([lambda p: feat_s], [lambda p: feat_c])
+    p = torch.rand(N, 3, generator=g)
+    sdf = dec.get_raw_sdf(p, sr); rgb = dec.get_raw_rgb(p, sr)
+    ps, pc = torch.randn(N, generator=g), torch.randn(N, 3, generator=g)
+    ((sdf * ps).sum() + (rgb * pc).sum()).backward()
+    sd = {k.replace(".", "__"): v for k, v in dec.state_dict().items()}
+    gd = {"grad__" + k.replace(".", "__"): v.grad for k, v in dec.named_parameters() if v.grad is not None}
+    npz("g4_decoders", feat_s=feat_s, feat_c=feat_c, sdf=sdf, rgb=rgb, probe_s=ps, probe_c=pc,
+        dfeat_s=feat_s.grad, dfeat_c=feat_c.grad, **sd, **gd)
+
+
+def g5():
+    g = torch.Generator().manual_seed(5)
+    R, S, tr = 20, 40, 0.06
+    gt = torch.rand(R, generator=g) * 3 + 0.3
+    z = O.sample_z_with_depth(gt[:, None], tr, 32, 8, True, torch.rand(R, S, generator=g))
+    sdf = torch.tanh(torch.randn(R, S, generator=g)).requires_grad_(True)
+    me = types.SimpleNamespace(truncation=tr, w_sdf_fs=5, w_sdf_center=200, w_sdf_tail=10)
+    l_m = RefMapper.sdf_losses(me, sdf, z, gt)
+    l_m.backward()
+    te = types.SimpleNamespace(truncation=tr, w_sdf_fs=10, w_sdf_center=200, w_sdf_tail=50)
+    l_t = RefTracker.sdf_losses(te, sdf.detach(), z, gt)
+    # empty-mask case: every sample far in front -> center/tail empty -> NaN
+    z_far = torch.zeros(R, S) + 0.01
+    l_nan = RefMapper.sdf_losses(me, sdf.detach(), z_far, gt)
+    npz("g5_losses", gt=gt, z=z, sdf=sdf, truncation=np.float64(tr), loss_map=l_m, dsdf=sdf.grad, loss_trk=l_t,
+        z_far=z_far, loss_nan=l_nan)
+
+
+def g6():
+    g = torch.Generator().manual_seed(6)
+    # sample_pdf on its own
+    B, M, K = 9, 30, 8
+    zz = torch.sort(torch.rand(B, M + 2, generator=g) * 4, -1)[0]
+    mid = 0.5 * (zz[:, 1:] + zz[:, :-1])                           # M+1 bin positions for M weights (Renderer.py:127-128)
+    w = torch.rand(B, M, generator=g) * 0.2
+    w[0] = 0                                                      # all-zero pdf row
+    w[1] *= 20                                                    # cdf >> 1 (pdf is not normalised)
+    u = torch.rand(B, K, generator=g)
+    torch.manual_seed(61)
+    s = RC.sample_pdf(mid, w, K, det=False, device=DEV)
+    torch.manual_seed(61)
+    u61 = torch.rand(B, K)
+    # zero-depth branch through the reference renderer with the oracle grid + reference torch decoders
+    cfg = make_cfg(32, 8, True)
+    r = make_renderer(cfg)
+    dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    enc_s, enc_c = small_grid(601), small_grid(602)
+    R = 12
+    ro = torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05
+    rd = torch.randn(R, 3, generator=g); rd = rd / rd.norm(dim=-1, keepdim=True)
+    gt = torch.rand(R, generator=g) * 2 + 0.4
+    gt[::3] = 0.0                                                  # every 3rd ray has no depth
+    torch.manual_seed(62)
+    ret = r.render_batch_ray(([enc_s], [enc_c]), dec, rd, ro, DEV, 0.06, gt_depth=gt)
+    sd = {"dec__" + k.replace(".", "__"): v for k, v in dec.state_dict().items()}
+    npz("g6_zerodepth", pdf_mid=mid, pdf_w=w, pdf_u=u61, pdf_samples=s,
+        rays_o=ro, rays_d=rd, gt_depth=gt, grid_s=enc_s.params, grid_c=enc_c.params, seed=62,
+        z_vals=ret[5], depth=ret[2], rgb=ret[3], **sd)
+
+
+def g7():
+    g = torch.Generator().manual_seed(7)
+    cfg = make_cfg(32, 8, True)
+    r = make_renderer(cfg)
+    dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    enc_s, enc_c = small_grid(701), small_grid(702)
+    R = 16
+    ro = (torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05).requires_grad_(True)
+    rd = torch.randn(R, 3, generator=g); rd = (rd / rd.norm(dim=-1, keepdim=True)).requires_grad_(True)
+    gt = torch.rand(R, generator=g) * 2 + 0.4
+    torch.manual_seed(71)
+    ret = r.render_batch_ray(([enc_s], [enc_c]), dec, rd, ro, DEV, 0.06, gt_depth=gt)
+    term, unc, depth, rgb, sdf, z, dunc = ret
+    probes = {k: torch.randn(v.shape, generator=g) for k, v in
+              dict(term=term, unc=unc, depth=depth, rgb=rgb, sdf=sdf, dunc=dunc).items()}
+    L = sum((probes[k] * v).sum() for k, v in dict(term=term, unc=unc, depth=depth, rgb=rgb, sdf=sdf, dunc=dunc).items())
+    L.backward()
+    sd = {"dec__" + k.replace(".", "__"): v for k, v in dec.state_dict().items()}
+    gd = {"gdec__" + k.replace(".", "__"): v.grad for k, v in dec.named_parameters()}
+    pr = {"probe_" + k: v for k, v in probes.items()}
+    npz("g7_render", rays_o=ro, rays_d=rd, gt_depth=gt, grid_s=enc_s.params, grid_c=enc_c.params, seed=71,
+        term=term, unc=unc, depth=depth, rgb=rgb, sdf=sdf, z_vals=z, dunc=dunc,
+        g_grid_s=enc_s.params.grad, g_grid_c=enc_c.params.grad, g_rays_o=ro.grad, g_rays_d=rd.grad, **sd, **gd, **pr)
+
+
+def g8():
+    """Tracker.optimize_tracking (Tracker.py:149-244) with a dummy self; one iteration, both mask modes."""
+    g = torch.Generator().manual_seed(8)
+    H, W, fx, fy, cx, cy = 20, 24, 14.0, 14.0, 11.5, 9.5
+    cfg = make_cfg(32, 8, True)
+    renderer = make_renderer(cfg, H, W, fx, fy, cx, cy)
+    dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    enc_s, enc_c = small_grid(801, amp=0.3), small_grid(802, amp=0.3)
+    gt_depth = (torch.rand(1, H, W, generator=g) * 1.5 + 0.5)
+    gt_depth[0, 5, 5:9] = 0.0
+    gt_color = torch.rand(1, H, W, 3, generator=g)
+    pose0 = torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]])
+    out = dict(intr=np.array([H, W, fx, fy, cx, cy]), gt_depth=gt_depth, gt_color=gt_color, pose=pose0,
+               grid_s=enc_s.params, grid_c=enc_c.params, edge=np.array([2, 3]), n=48,
+               **{"dec__" + k.replace(".", "__"): v for k, v in dec.state_dict().items()})
+    for mode in ("original", "no_mask"):
+        pose = torch.nn.Parameter(pose0.clone())
+        opt = torch.optim.SGD([pose], lr=0.0)
+        me = types.SimpleNamespace(cfg=cfg, hash_grids_xyz=[enc_s], c_hash_grids_xyz=[enc_c], device=DEV,
+                                   H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, ignore_edge_H=2, ignore_edge_W=3,
+                                   bound=BOUND, renderer=renderer, decoders=dec, truncation=0.06, t_mask_mode=mode,
+                                   w_color=5, w_depth=1, w_sdf_fs=10, w_sdf_center=200, w_sdf_tail=50)
+        me.sdf_losses = lambda *a, _me=me: RefTracker.sdf_losses(_me, *a)
+        enc_s.params.grad = None; enc_c.params.grad = None
+        torch.manual_seed(81)
+        loss, unc = RefTracker.optimize_tracking(me, pose, gt_color, gt_depth, 48, opt)
+        out[f"{mode}_loss"] = np.float32(loss); out[f"{mode}_unc"] = unc.detach(); out[f"{mode}_gpose"] = pose.grad.clone()
+        out[f"{mode}_ggrid_s"] = enc_s.params.grad.clone()
+    out["seed"] = 81
+    npz("g8_tracking", **out)
+
+
+def g9():
+    """Mapper.optimize_mapping (Mapper.py:276-459) with a dummy self: first frame, 2 iterations incl. Adam."""
+    g = torch.Generator().manual_seed(9)
+    H, W, fx, fy, cx, cy = 20, 24, 14.0, 14.0, 11.5, 9.5
+    cfg = make_cfg(32, 8, True)
+    cfg["mapping"] = {"lr": {"decoders_lr": 0.001, "hash_grids_lr": 0.05, "c_hash_grids_lr": 0.05}}
+    renderer = make_renderer(cfg, H, W, fx, fy, cx, cy)
+    dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    enc_s, enc_c = small_grid(901, amp=0.3), small_grid(902, amp=0.3)
+    gt_depth = (torch.rand(H, W, generator=g) * 1.5 + 0.5)
+    gt_depth[5, 5:9] = 0.0
+    gt_color = torch.rand(H, W, 3, generator=g)
+    c2w = O.cam_pose_to_matrix(torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]]))[0]
+    rays_d = RC.get_camera_rays(H, W, fx, fy, cx, cy)
+    out = dict(intr=np.array([H, W, fx, fy, cx, cy]), gt_depth=gt_depth, gt_color=gt_color, c2w=c2w,
+               grid_s0=enc_s.params.detach().clone(), grid_c0=enc_c.params.detach().clone(), pixels=40, iters=2,
+               **{"dec0__" + k.replace(".", "__"): v.clone() for k, v in dec.state_dict().items()})
+    me = types.SimpleNamespace(cfg=cfg, hash_grids_xyz=[enc_s], c_hash_grids_xyz=[enc_c], device=DEV,
+                               H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, bound=BOUND, renderer=renderer, decoders=dec,
+                               truncation=0.06, m_mask_mode="original", w_color=5, w_depth=0.1, w_sdf_fs=5,
+                               w_sdf_center=200, w_sdf_tail=10, keyframe_selection_method="global",
+                               keyframe_dict=[], keyframe_list=[], mapping_pixels=40, joint_opt=False,
+                               no_vis_on_first_frame=True, tracking_back=torch.zeros(1).int(),
+                               mapping_window_size=20)
+    me.sdf_losses = lambda *a: RefMapper.sdf_losses(me, *a)
+    me.create_optimizer = lambda c, f: RefMapper.create_optimizer(me, c, f)
+    torch.manual_seed(91)
+    RefMapper.optimize_mapping(me, 2, 5.0, 0, gt_color, gt_depth, c2w, [], [], c2w, rays_d)
+    out.update(seed=91, lr_factor=5.0, grid_s1=enc_s.params.detach(), grid_c1=enc_c.params.detach(),
+               **{"dec1__" + k.replace(".", "__"): v for k, v in dec.state_dict().items()})
+    npz("g9_mapping", **out)
+
+
+if __name__ == "__main__":
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+        fn()
