@@ -1,0 +1,192 @@
+/*
+ * unislam_hip.h -- C ABI of libunislam_hip.so: the MI355X (gfx950) implementation of Uni-SLAM's
+ * per-iteration volumetric-rendering hot path.
+ *
+ * The reference (dfki-av/Uni-SLAM) is pure Python and has no FFI of its own for this path; its native
+ * compute comes from tiny-cuda-nn (tcnn.Encoding / tcnn.Network torch modules) and ATen ops.  Each entry
+ * point below replaces the reference call site(s) it cites (paths relative to the reference tree).  The
+ * Python host side (package uni-slam_amd/, importable as `unislam_amd`) binds these through ctypes and
+ * mirrors the reference's module/function API; INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative US_ERR_* for argument errors, or a positive hipError_t;
+ *     no C++ exception crosses the boundary; us_last_error() gives a thread-local message.
+ *   - all pointers are DEVICE pointers (tensor.data_ptr()) unless the name ends in _host; fp32, row-major,
+ *     contiguous.  The caller (PyTorch) owns every buffer incl. workspaces and keeps them alive until the
+ *     stream work completes; the library never allocates or frees device memory and holds no mutable state.
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); launches are asynchronous and
+ *     never synchronise, so every call can be captured into a hipGraph.
+ *   - N = number of points = rays * samples; C = n_levels * n_features (32 for Uni-SLAM).
+ */
+#ifndef UNISLAM_HIP_H
+#define UNISLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define US_MAX_LEVELS 32
+#define US_ABI_VERSION 1
+
+enum {
+    US_OK = 0,
+    US_ERR_NULL = -1,       /* required pointer is NULL */
+    US_ERR_SHAPE = -2,      /* size / shape outside what the kernels support */
+    US_ERR_CONFIG = -3,     /* unsupported descriptor (features per level, width, ...) */
+    US_ERR_WORKSPACE = -4   /* workspace too small */
+};
+
+const char* us_last_error(void);
+int us_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-resolution hash grid  (replaces tcnn.Encoding "HashGrid": construction src/UNISLAM.py:242-253,
+ * call src/networks/decoders.py:103, backward via autograd at src/Mapper.py:444 / src/Tracker.py:241)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct us_grid_desc {
+    uint32_t n_levels;            /* L  (<= US_MAX_LEVELS) */
+    uint32_t n_features;          /* F  per level: 1, 2 or 4 */
+    uint32_t log2_hashmap_size;
+    uint32_t base_resolution;
+    float    per_level_scale;
+    float    scale[US_MAX_LEVELS];        /* exp2f(l*log2f(pls))*base - 1 */
+    uint32_t resolution[US_MAX_LEVELS];   /* ceilf(scale)+1 */
+    uint32_t offset[US_MAX_LEVELS + 1];   /* level start, in table ENTRIES (F floats each) */
+    uint32_t n_params;                    /* F * offset[L] : length of the flat fp32 `params` vector */
+} us_grid_desc;
+
+/* host only: fills scale/resolution/offset/n_params exactly as tcnn's GridEncoding constructor does */
+int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_features,
+                      uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale);
+
+/* flags for the three grid entry points: US_GRID_CLAMP01 folds decoders.py:101's torch.clamp(p, 0, 1) into the
+ * position load (and zeroes dy_dx where the clamp is active, like torch.clamp's backward) */
+#define US_GRID_CLAMP01 1
+
+/* out[N][C] = encode(x[N][3]);  dy_dx[N][C][3] optional (NULL when positions need no gradient) */
+int us_hashgrid_fwd(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n,
+                    float* out, float* dy_dx, int flags, void* stream);
+
+/* 8 corner indices per (point, level): idx[N][L][8] uint32 (entry index inside the level) -- parity/debug */
+int us_hashgrid_indices(const us_grid_desc* desc_host, const float* x, int64_t n, uint32_t* idx, int flags,
+                        void* stream);
+
+/* grad_params[n_params] += scatter(dL_dy[N][C]).  Caller zeroes grad_params when it wants a fresh gradient.
+ * mode 0: direct global float atomics (tcnn's kernel_grid_backward shape);
+ * mode 1: LDS-privatised table slices (one workgroup accumulates a slice of one level over all points
+ *         in LDS, then flushes it with contiguous atomics);  mode -1: pick by shape. */
+int us_hashgrid_bwd_params(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
+                           float* grad_params, int mode, int flags, void* stream);
+
+/* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
+int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,
+                          float* dL_dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused tiny MLP on MFMA  (replaces tcnn.Network "FullyFusedMLP" src/networks/decoders.py:50-70,123,148
+ * and the nn.Linear stacks src/networks/decoders.py:74-84,125-128,150-153)
+ * ---------------------------------------------------------------------------------------------- */
+enum { US_ACT_NONE = 0, US_ACT_TANH = 1, US_ACT_SIGMOID = 2 };
+enum { US_PREC_F32 = 0, US_PREC_BF16 = 1 };   /* MFMA operand type; accumulation is always fp32 */
+
+typedef struct us_mlp_desc {
+    uint32_t n_in;        /* 32 */
+    uint32_t width;       /* 16, 32 or 64 hidden neurons */
+    uint32_t n_hidden;    /* number of hidden layers: 1 or 2  (n_hidden+1 matrices) */
+    uint32_t n_out;       /* 1..16 real outputs (rows n_out..15 of the last matrix are padding) */
+    uint32_t out_act;     /* US_ACT_* */
+    uint32_t has_bias;    /* 0: tcnn layout (weights only)   1: biases appended after the weights */
+    uint32_t precision;   /* US_PREC_* */
+} us_mlp_desc;
+/* params (flat fp32): W0[width][n_in], (n_hidden-1) x W[width][width], Wlast[16][width]   (row-major [out][in]),
+ * then if has_bias: b0[width], (n_hidden-1) x b[width], blast[16]. */
+size_t us_mlp_n_params(const us_mlp_desc* d);
+
+/* out[i*out_stride + o] = act(MLP(in[i][:]))[o], o < n_out   (out_stride lets two decoders write one raw[N][4]) */
+int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n,
+               float* out, int64_t out_stride, void* stream);
+
+/* dL_din[N][n_in] (nullable) and grad_params += (nullable), from dL_dout[i*dout_stride + o].
+ * `out` is the forward result (same layout as in us_mlp_fwd) used for the activation derivative. */
+int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out, int64_t out_stride,
+               const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray sampling / points  (replaces src/utils/Renderer.py:81-101,132-137 and src/common.py:152-166 gather+rotate)
+ * ---------------------------------------------------------------------------------------------- */
+/* depth-guided z sampling for rays with gt_depth > 0 (Renderer.py:86-101):
+ *   z_free = (c_free*gt)*t_uni[j];  z_surf = (gt - surf_off) + surf_span*t_surf[k];  merge-sort;  optional jitter
+ *   (Renderer.py:42-57) with t_rand[R][S] (NULL: no perturbation).  S = n_strat + n_imp <= 256.          */
+int us_sample_z(const float* gt_depth, int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf, int n_imp,
+                float c_free, float surf_off, float surf_span, const float* t_rand, float* z_vals, void* stream);
+/* c_free = 1.2f, surf_off = (float)(1.5*truncation), surf_span = (float)(3*truncation): the python scalars the
+ * reference multiplies into fp32 tensors */
+
+/* pts[R][S][3] = ((o + d*z) - bound_lo) / (bound_hi - bound_lo)   (Renderer.py:132-137); bound_host = {lo[3], hi[3]} */
+int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, const float* bound_host,
+                  int64_t n_rays, int n_samples, float* pts, void* stream);
+/* adjoint of us_ray_points wrt rays_o / rays_d (tracking: pose gradient, Tracker.py:170-174) */
+int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
+                      int n_samples, float* dL_do, float* dL_dd, void* stream);
+
+/* bounding-box pre-filter (Mapper.py:396-402, Tracker.py:177-184): far = min_dim max((lo-o)/d, (hi-o)/d);
+ * valid[i] = far >= gt_depth[i] (&& gt_depth[i] > 0 when require_depth); far_out[R] optional (Renderer.py:108-113) */
+int us_bbox_filter(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
+                   int64_t n_rays, int require_depth, uint8_t* valid, float* far_out, void* stream);
+
+/* mapping ray assembly: gather-then-rotate (common.py:152-166 rotates all P pool pixels first; same result):
+ * idx[b][n] int64 into per-frame pools depths[b][P], colors[b][P][3], dirs[b][P][3]; c2ws[b][4][4]            */
+int us_gather_rays(const float* c2ws, const float* pool_depth, const float* pool_color, const float* pool_dirs,
+                   const int64_t* idx, int b, int64_t pool_size, int64_t n_per_frame,
+                   float* rays_o, float* rays_d, float* depth, float* color, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SDF -> alpha compositing  (replaces src/utils/Renderer.py:140-158)
+ * ---------------------------------------------------------------------------------------------- */
+/* raw[R][S][4] = (r,g,b,sdf); beta: device scalar.  Outputs per ray; weights[R][S] optional (NULL). */
+int us_composite_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
+                     float* term, float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* weights,
+                     void* stream);
+/* upstream per-ray grads (any may be NULL = zero) + direct grad on the returned sdf[R][S] (nullable);
+ * d_raw[R][S][4] written, d_beta[1] accumulated (+=). */
+int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
+                     const float* g_term, const float* g_unc, const float* g_depth, const float* g_rgb,
+                     const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Uncertainty-gated losses  (replaces src/Mapper.py:141-175,411-440 and src/Tracker.py:113-147,206-238)
+ * Two phases so that data-dependent mask COUNTS can be all-reduced across ranks before gradients are scaled.
+ * ---------------------------------------------------------------------------------------------- */
+enum { US_LOSS_MAP_ORIGINAL = 0, US_LOSS_MAP_NOMASK = 1, US_LOSS_TRK_ORIGINAL = 2, US_LOSS_TRK_NOMASK = 3 };
+enum { US_LS_FS = 0, US_LS_CENTER = 1, US_LS_TAIL = 2, US_LS_COLOR = 3, US_LS_DEPTH = 4, US_LS_N = 5 };
+/* stats[10]: sums[5] then counts[5] (fp32; overwritten).  sdf[(r*S+s)*sdf_stride] (stride 4 reads raw[R][S][4]'s
+ * 4th channel in place); valid[R] (nullable) drops rays the bbox pre-filter rejected without compacting the
+ * batch (no host sync); median: device scalar (10x-median depth-error gate, tracking only; NULL for mapping).
+ * partials: workspace of us_loss_partials_size(n_rays) floats for a fixed-order (deterministic) reduction.   */
+size_t us_loss_partials_size(int64_t n_rays);
+int us_loss_stats(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* valid, const float* z_vals,
+                  const float* gt_depth, const float* gt_color,
+                  const float* depth, const float* rgb, const float* pixel_unc, const float* median,
+                  int64_t n_rays, int n_samples, double truncation, float* partials, float* stats, void* stream);
+/* gradients of  loss = sum_k w[k] * sums[k] / counts[k]  wrt sdf[R][S], depth[R], rgb[R][3], using the (possibly
+ * globally reduced) counts in stats[5..9];  loss_out[1] (nullable) receives the scalar from stats.            */
+int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* valid, const float* z_vals,
+                 const float* gt_depth, const float* gt_color,
+                 const float* depth, const float* rgb, const float* pixel_unc, const float* median,
+                 int64_t n_rays, int n_samples, double truncation, const float* w_host5, const float* stats,
+                 float* g_sdf, float* g_depth, float* g_rgb, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser  (replaces torch.optim.Adam at src/Mapper.py:364,445 / src/Tracker.py:328,242)
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.optim.Adam semantics (amsgrad off, weight_decay 0); step = 1-based step count after increment */
+int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                 double eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNISLAM_HIP_H */

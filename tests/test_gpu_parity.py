@@ -1,0 +1,506 @@
+"""
+GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI
+(libunislam_hip.so via unislam_amd), against the CPU oracle and the committed golden fixtures.
+Tolerances: hash indices and z_vals bit-exact; fp32 values within the rtol written at each check
+(north_star: 1e-3 relative on rendered RGB/depth; the fp32 kernels are held much tighter).
+"""
+import numpy as np
+import pytest
+import torch
+
+import unislam_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+PLS816 = O.per_level_scale(816)
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+
+
+@pytest.fixture(scope="module")
+def us():
+    import unislam_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return unislam_amd
+
+
+def enc_cfg(log2T, res=816, L=16, F=2):
+    return {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": log2T,
+            "base_resolution": 16, "per_level_scale": O.per_level_scale(res)}
+
+
+def close(a, b, rtol, atol):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------------------------------------- hash grid
+@pytest.mark.parametrize("log2T,n", [(16, 4099), (19, 1000), (10, 1), (12, 64)])
+def test_hashgrid_indices_bit_exact_and_features(us, log2T, n):
+    rng = np.random.default_rng(log2T + n)
+    x = rng.random((n, 3), dtype=np.float32)
+    x[0] = 0.0
+    if n > 2:
+        x[1] = 1.0; x[2] = [1.0, 0.0, 0.5]
+    enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+    d = O.make_grid_desc(16, 2, log2T, 16, PLS816)
+    assert enc.desc.n_params == d.n_params
+    p = (rng.random(d.n_params, dtype=np.float32) * 2 - 1)
+    with torch.no_grad():
+        enc.params.copy_(T(p))
+    xg = T(x).to(DEV)
+    idx = us.grid_indices(enc.desc, xg).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(idx, O.hashgrid_indices(d, x))                       # bit-exact indices
+    out = enc(xg).detach().cpu().numpy()
+    ref, _ = O.hashgrid_fwd(d, p, x)
+    np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-7)                  # same fmaf chain
+
+
+def test_hashgrid_clamp_and_out_of_range(us):
+    rng = np.random.default_rng(3)
+    x = (rng.random((500, 3), dtype=np.float32) * 1.6 - 0.3)                    # some coordinates outside [0,1]
+    enc = us.HashGridEncoding(3, enc_cfg(14)).to(DEV)
+    d = O.make_grid_desc(16, 2, 14, 16, PLS816)
+    p = rng.standard_normal(d.n_params).astype(np.float32)
+    with torch.no_grad():
+        enc.params.copy_(T(p))
+    xg = T(x).to(DEV).requires_grad_(True)
+    out = enc(xg, clamp=True)
+    xc = np.clip(x, 0, 1)
+    ref, dydx = O.hashgrid_fwd(d, p, xc, True)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(us.grid_indices(enc.desc, xg.detach(), clamp=True).cpu().numpy().astype(np.uint32),
+                          O.hashgrid_indices(d, xc))
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(T(dy).to(DEV))
+    gx = O.hashgrid_bwd_input(dy, dydx) * ((x >= 0) & (x <= 1))                 # torch.clamp backward mask
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), gx, rtol=2e-4, atol=2e-3)
+    # without the clamp flag the raw coordinates are hashed as they are (tcnn behaviour)
+    assert np.array_equal(us.grid_indices(enc.desc, xg.detach()).cpu().numpy().astype(np.uint32), O.hashgrid_indices(d, x))
+
+
+@pytest.mark.parametrize("mode", [0, 1, -1])
+@pytest.mark.parametrize("log2T,n", [(16, 20000), (19, 3000)])
+def test_hashgrid_backward(us, mode, log2T, n):
+    rng = np.random.default_rng(7 + log2T)
+    x = rng.random((n, 3), dtype=np.float32)
+    enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+    enc.bwd_mode = mode
+    d = O.make_grid_desc(16, 2, log2T, 16, PLS816)
+    p = rng.standard_normal(d.n_params).astype(np.float32) * 0.1
+    with torch.no_grad():
+        enc.params.copy_(T(p))
+    xg = T(x).to(DEV).requires_grad_(True)
+    dy = rng.standard_normal((n, 32)).astype(np.float32)
+    dy[::7] = 0.0                                                              # rows the kernels may skip
+    enc(xg).backward(T(dy).to(DEV))
+    gp = O.hashgrid_bwd_params(d, x, dy)
+    scale = np.abs(gp).max()
+    np.testing.assert_allclose(enc.params.grad.cpu().numpy(), gp, rtol=1e-4, atol=1e-5 * scale)
+    _, dydx = O.hashgrid_fwd(d, p, x, True)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), O.hashgrid_bwd_input(dy, dydx), rtol=2e-4, atol=1e-3)
+
+
+def test_hashgrid_empty_and_features_1_4(us):
+    enc = us.HashGridEncoding(3, enc_cfg(12)).to(DEV)
+    assert enc(torch.empty(0, 3, device=DEV)).shape == (0, 32)
+    rng = np.random.default_rng(5)
+    x = rng.random((333, 3), dtype=np.float32)
+    for F in (1, 4):
+        e = us.HashGridEncoding(3, enc_cfg(11, res=300, L=8, F=F)).to(DEV)
+        d = O.make_grid_desc(8, F, 11, 16, O.per_level_scale(300))
+        p = rng.standard_normal(d.n_params).astype(np.float32)
+        with torch.no_grad():
+            e.params.copy_(T(p))
+        xg = T(x).to(DEV)
+        out = e(xg)
+        ref, _ = O.hashgrid_fwd(d, p, x)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+        dy = rng.standard_normal(ref.shape).astype(np.float32)
+        out.backward(T(dy).to(DEV))
+        gp = O.hashgrid_bwd_params(d, x, dy)
+        np.testing.assert_allclose(e.params.grad.cpu().numpy(), gp, rtol=1e-4, atol=1e-5 * np.abs(gp).max())
+
+
+def test_hashgrid_full_size_properties(us):
+    """BASELINE cfg2 size (4096 rays x 64 samples, room0 tables): size-independent properties."""
+    n = 4096 * 64
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.rand((n, 3), device=DEV, generator=g)
+    for log2T in (16, 19):
+        enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+        with torch.no_grad():
+            enc.params.fill_(0.25)
+            assert torch.allclose(enc(x), torch.full((n, 32), 0.25, device=DEV), rtol=1e-6)     # partition of unity
+            p1 = torch.randn(enc.params.shape, device=DEV, generator=g); p2 = torch.randn(enc.params.shape, device=DEV, generator=g)
+            enc.params.copy_(p1); o1 = enc(x)
+            enc.params.copy_(p2); o2 = enc(x)
+            enc.params.copy_(p1 + 2 * p2); o12 = enc(x)
+            assert torch.allclose(o12, o1 + 2 * o2, rtol=1e-4, atol=1e-4)                       # linear in the table
+        # adjoint identity <dy, fwd(q)> == <bwd(dy), q>, for both backward strategies, and mode 0 == mode 1
+        dy = torch.randn((n, 32), device=DEV, generator=g)
+        grads = []
+        for mode in (0, 1):
+            enc.bwd_mode = mode
+            enc.params.grad = None
+            out = enc(x)
+            out.backward(dy)
+            lhs = (dy.double() * out.detach().double()).sum()
+            rhs = (enc.params.grad.double() * enc.params.detach().double()).sum()
+            assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
+            grads.append(enc.params.grad.clone())
+        assert torch.allclose(grads[0], grads[1], rtol=1e-3, atol=1e-3 * grads[0].abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- MLP
+@pytest.mark.parametrize("width,n_hidden,n_out,act,bias,n", [
+    (16, 1, 1, "tanh", False, 1000),        # reference tcnn path, SDF   (decoders.py:50-59)
+    (16, 1, 3, "sigmoid", False, 257),      # reference tcnn path, colour
+    (16, 2, 1, "tanh", True, 4096),         # reference torch path       (decoders.py:74-84)
+    (16, 2, 3, "sigmoid", True, 63),
+    (32, 2, 3, "sigmoid", True, 5000),      # BASELINE "2x32"
+    (32, 1, 1, "tanh", True, 130),
+    (64, 2, 3, "none", True, 700),
+    (64, 1, 1, "tanh", False, 33),
+])
+def test_mlp_forward_backward(us, width, n_hidden, n_out, act, bias, n):
+    g = torch.Generator().manual_seed(width * 10 + n_hidden)
+    desc = us.make_mlp_desc(32, width, n_hidden, n_out, act, bias)
+    n_p = us.network.mlp_n_params(desc)
+    shapes = [(width, 32)] + [(width, width)] * (n_hidden - 1) + [(16, width)]
+    assert n_p == sum(a * b for a, b in shapes) + (n_hidden * width + 16 if bias else 0)
+    params = (torch.rand(n_p, generator=g) * 2 - 1) * 0.4
+    x = torch.randn(n, 32, generator=g)
+    dy = torch.randn(n, n_out, generator=g)
+    # fp32 torch reference of the same flat layout
+    pr = params.clone().requires_grad_(True); xr = x.clone().requires_grad_(True)
+    ws, o = [], 0
+    for (a, b) in shapes:
+        ws.append(pr[o:o + a * b].view(a, b)); o += a * b
+    bs = None
+    if bias:
+        bs = []
+        for (a, _) in shapes:
+            bs.append(pr[o:o + a]); o += a
+    ws[-1] = ws[-1][:n_out]
+    if bs:
+        bs[-1] = bs[-1][:n_out]
+    yr = O.mlp_forward(xr, ws, bs, act)
+    (yr * dy).sum().backward()
+    pg = params.to(DEV).requires_grad_(True); xg = x.to(DEV).requires_grad_(True)
+    y = us.fused_mlp(xg, pg, desc)
+    close(y, yr, 2e-5, 2e-6)
+    (y * dy.to(DEV)).sum().backward()
+    close(xg.grad, xr.grad, 1e-4, 1e-5)
+    gref = pr.grad.clone()
+    scale = gref.abs().max().item()
+    close(pg.grad, gref, 1e-4, 1e-5 * scale)
+
+
+def test_mlp_rejects_unsupported(us):
+    with pytest.raises(us.UniSlamHipError):
+        us.fused_mlp(torch.zeros(4, 32, device=DEV), torch.zeros(10000, device=DEV), us.make_mlp_desc(32, 48, 1, 1, "tanh", False))
+    with pytest.raises(us.UniSlamHipError):
+        us.fused_mlp(torch.zeros(4, 32), torch.zeros(768), us.make_mlp_desc(32, 16, 1, 1, "tanh", False))   # CPU tensor
+
+
+# ---------------------------------------------------------------------------------------------- sampler / compositing / losses
+@pytest.mark.parametrize("ns,ni", [(32, 8), (48, 8)])
+def test_sample_z_bit_exact(us, golden, ns, ni):
+    g = golden("g2_zsample")
+    gt = T(g["gt_depth"]).to(DEV)
+    tu, ts = torch.linspace(0., 1., ns).to(DEV), torch.linspace(0., 1., ni).to(DEV)
+    z0 = us.sample_z(gt, float(g["truncation"]), tu, ts)
+    assert np.array_equal(z0.cpu().numpy(), g[f"z_{ns}_{ni}_0"])
+    z1 = us.sample_z(gt, float(g["truncation"]), tu, ts, T(g[f"trand_{ns}_{ni}"]).to(DEV))
+    assert np.array_equal(z1.cpu().numpy(), g[f"z_{ns}_{ni}_1"])
+
+
+def test_sample_z_bench_shapes(us):
+    # 64 = 48+16 and 96 = 80+16 samples (BASELINE cfg2/cfg3), ragged ray count
+    for ns, ni, R in [(48, 16, 4099), (80, 16, 1001)]:
+        gt = torch.rand(R) * 3 + 0.3
+        tr = torch.rand(R, ns + ni)
+        ref = O.sample_z_with_depth(gt[:, None], 0.06, ns, ni, True, tr)
+        z = us.sample_z(gt.to(DEV), 0.06, torch.linspace(0., 1., ns).to(DEV), torch.linspace(0., 1., ni).to(DEV), tr.to(DEV))
+        assert np.array_equal(z.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("tag", ["b10", "b73"])
+def test_composite_golden(us, golden, tag):
+    from unislam_amd.renderer import _CompositeFn
+    g = golden("g3_composite")
+    raw = T(g[f"{tag}_raw"]).to(DEV).requires_grad_(True)
+    beta = T(g[f"{tag}_beta"]).to(DEV).requires_grad_(True)
+    z = T(g[f"{tag}_z"]).to(DEV)
+    term, unc, depth, rgb, dunc = _CompositeFn.apply(raw, z, beta)
+    outs = dict(term=term, unc=unc, depth=depth, rgb=rgb, dunc=dunc)
+    for k, v in outs.items():
+        close(v, g[f"{tag}_{k}"], 2e-5, 2e-6)
+    sum((T(g[f"{tag}_probe_{k}"]).to(DEV) * v).sum() for k, v in outs.items()).backward()
+    close(raw.grad, g[f"{tag}_draw"], 2e-4, 2e-5)
+    close(beta.grad, g[f"{tag}_dbeta"], 2e-4, 2e-4)
+
+
+def test_composite_96_samples_vs_oracle(us):
+    from unislam_amd.renderer import _CompositeFn
+    g = torch.Generator().manual_seed(11)
+    R, S = 301, 96
+    raw = torch.rand(R, S, 4, generator=g)
+    raw[..., 3] = torch.tanh(torch.randn(R, S, generator=g) + torch.linspace(2, -2, S))
+    z = torch.sort(torch.rand(R, S, generator=g) * 4, -1)[0]
+    rr = raw.clone().requires_grad_(True); br = torch.tensor([10.0], requires_grad=True)
+    ref = O.composite(rr, z, br)
+    probes = [torch.randn(v.shape, generator=g) for v in (ref[0], ref[1], ref[2], ref[3], ref[6])]
+    sum((p * v).sum() for p, v in zip(probes, (ref[0], ref[1], ref[2], ref[3], ref[6]))).backward()
+    rg = raw.to(DEV).requires_grad_(True); bg = torch.tensor([10.0], device=DEV, requires_grad=True)
+    out = _CompositeFn.apply(rg, z.to(DEV), bg)
+    for a, b in zip(out, (ref[0], ref[1], ref[2], ref[3], ref[6])):
+        close(a, b, 2e-5, 2e-6)
+    sum((p.to(DEV) * v).sum() for p, v in zip(probes, out)).backward()
+    close(rg.grad, rr.grad, 3e-4, 3e-5)
+    close(bg.grad, br.grad, 3e-4, 3e-3)
+
+
+def test_sdf_losses_golden(us, golden):
+    g = golden("g5_losses")
+    sdf = T(g["sdf"]).to(DEV).requires_grad_(True)
+    z, gt, tr = T(g["z"]).to(DEV), T(g["gt"]).to(DEV), float(g["truncation"])
+    l = us.sdf_losses(sdf, z, gt, tr, 5, 200, 10)
+    close(l, g["loss_map"], 1e-5, 1e-6)
+    l.backward()
+    close(sdf.grad, g["dsdf"], 1e-4, 1e-7)
+    close(us.sdf_losses(sdf.detach(), z, gt, tr, 10, 200, 50), g["loss_trk"], 1e-5, 1e-6)
+    ln = us.sdf_losses(sdf.detach(), T(g["z_far"]).to(DEV), gt, tr, 5, 200, 10)
+    assert torch.isnan(ln) and np.isnan(g["loss_nan"])                           # empty selection -> NaN like torch.mean([])
+
+
+@pytest.mark.parametrize("kind,mode", [("mapping", "original"), ("mapping", "no_mask"), ("tracking", "original"), ("tracking", "no_mask")])
+def test_full_loss_vs_oracle(us, kind, mode):
+    g = torch.Generator().manual_seed(13)
+    R, S, tr = 200, 40, 0.06
+    gt = torch.rand(R, generator=g) * 2 + 0.4
+    if kind == "mapping":
+        gt[::9] = 0.0
+    z = O.sample_z_with_depth(gt.clamp(min=0.3)[:, None], tr, 32, 8, True, torch.rand(R, S, generator=g))
+    sdf = torch.tanh(torch.randn(R, S, generator=g))
+    depth = gt + torch.randn(R, generator=g) * 0.05; depth[3] += 30.0
+    rgb = torch.rand(R, 3, generator=g); gc = torch.rand(R, 3, generator=g)
+    unc = torch.rand(R, generator=g) * 0.01; unc[::5] = 0.5
+    w = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+    leaves = [t.clone().requires_grad_(True) for t in (sdf, depth, rgb)]
+    ret = (None, unc, leaves[1], leaves[2], leaves[0], z, None)
+    lr = (O.mapping_loss if kind == "mapping" else O.tracking_loss)(ret, gt, gc, tr, w, mode)
+    lr.backward()
+    gl = [t.to(DEV).requires_grad_(True) for t in (sdf, depth, rgb)]
+    l = us.fused_loss(kind, mode, gl[0], z.to(DEV), gl[1], gl[2], unc.to(DEV), gt.to(DEV), gc.to(DEV), tr, w)
+    close(l, lr, 2e-5, 1e-6)
+    l.backward()
+    for a, b in zip(gl, leaves):
+        close(a.grad, b.grad, 2e-4, 1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- rays
+def test_gather_rays_golden(us, golden):
+    g = golden("g1_rays")
+    H, W, fx, fy, cx, cy = g["intr"]
+    dev = lambda k: T(g[k]).to(DEV)
+    sa = us.common.get_samples_all(0, int(H), 0, int(W), 6, int(H), int(W), fx, fy, cx, cy, dev("c2w"), dev("pool_d"),
+                                   dev("pool_c"), DEV, dev("pool_r"), indices=dev("sa_idx"))
+    for a, k in zip(sa, ("sa_o", "sa_d", "sa_depth", "sa_color")):
+        close(a, g[k], 1e-6, 1e-6)
+    ro, rd = us.common.get_rays(int(H), int(W), fx, fy, cx, cy, dev("c2w")[0], DEV)
+    close(ro, g["rays_o"], 1e-6, 1e-6); close(rd, g["rays_d"], 1e-6, 1e-6)
+    # bbox filter against the reference expression (Mapper.py:396-402)
+    o, d = T(g["sa_o"]), T(g["sa_d"])
+    far = O.bbox_far(o, d, BOUND)
+    gt = far * torch.tensor([0.5, 1.5] * (o.shape[0] // 2))
+    m = us.common.bbox_filter(o.to(DEV), d.to(DEV), gt.to(DEV), BOUND)
+    assert torch.equal(m.cpu(), far >= gt)
+    close(us.common.bbox_far(o.to(DEV), d.to(DEV), BOUND), far, 1e-6, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- end to end
+def _grid(us, params, log2T=10, res=64):
+    enc = us.HashGridEncoding(3, enc_cfg(log2T, res)).to(DEV)
+    with torch.no_grad():
+        enc.params.copy_(T(params))
+    return enc
+
+
+def _cfg(n_strat=32, n_imp=8, perturb=True, tcnn=False):
+    return {"rendering": {"perturb": perturb, "n_stratified": n_strat, "n_importance": n_imp}, "scale": 1,
+            "grid_mode": "hash_grid", "grid": {"tcnn_network": tcnn}, "model": {"c_dim": 32, "truncation": 0.06}}
+
+
+def _renderer(us, cfg, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5):
+    import types
+    return us.Renderer(cfg, types.SimpleNamespace(bound=BOUND, device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy))
+
+
+def _decoders(us, g, prefix, cfg):
+    dec = us.Decoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    sd = {k[len(prefix):].replace("__", "."): T(v) for k, v in g.items() if k.startswith(prefix)}
+    dec.load_state_dict(sd)                       # reference state_dict keys load unchanged
+    return dec.to(DEV)
+
+
+def test_g7_render_batch_ray_fwd_bwd(us, golden):
+    g = golden("g7_render")
+    cfg = _cfg()
+    dec = _decoders(us, g, "dec__", cfg)
+    es, ec = _grid(us, g["grid_s"]), _grid(us, g["grid_c"])
+    ro = T(g["rays_o"]).to(DEV).requires_grad_(True); rd = T(g["rays_d"]).to(DEV).requires_grad_(True)
+    torch.manual_seed(int(g["seed"]))
+    t_rand = torch.rand(ro.shape[0], 40)            # the reference's CPU draw for this seed
+    r = _renderer(us, cfg)
+    term, unc, depth, rgb, sdf, z, dunc = r.render_batch_ray(([es], [ec]), dec, rd, ro, DEV, 0.06, gt_depth=T(g["gt_depth"]).to(DEV),
+                                                            t_rand=t_rand.to(DEV))
+    assert np.array_equal(z.cpu().numpy(), g["z_vals"])                              # bit-exact samples
+    outs = dict(term=term, unc=unc, depth=depth, rgb=rgb, sdf=sdf, dunc=dunc)
+    for k, v in outs.items():
+        close(v, g[k], 1e-3, 1e-5)                  # north_star tolerance: 1e-3 relative on rendered RGB / depth
+        close(v, g[k], 5e-5, 5e-6)                  # what the fp32 path actually holds
+    sum((T(g["probe_" + k]).to(DEV) * v).sum() for k, v in outs.items()).backward()
+    close(es.params.grad, g["g_grid_s"], 2e-4, 2e-6); close(ec.params.grad, g["g_grid_c"], 2e-4, 2e-6)
+    close(ro.grad, g["g_rays_o"], 2e-3, 2e-3); close(rd.grad, g["g_rays_d"], 2e-3, 2e-3)
+    for n, p_ in dec.named_parameters():
+        ref = g["gdec__" + n.replace(".", "__")]
+        close(p_.grad, ref, 2e-4, 1e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_g6_zero_depth_branch(us, golden):
+    g = golden("g6_zerodepth")
+    cfg = _cfg()
+    dec = _decoders(us, g, "dec__", cfg)
+    es, ec = _grid(us, g["grid_s"]), _grid(us, g["grid_c"])
+    r = _renderer(us, cfg)
+    # replay the reference's CPU random stream: jitter [R1,S], coarse jitter [R0,32], pdf uniforms [R0,8]
+    gt = T(g["gt_depth"])
+    R1, R0 = int((gt > 0).sum()), int((gt <= 0).sum())
+    torch.manual_seed(int(g["seed"]))
+    tr1, tr0, u0 = torch.rand(R1, 40), torch.rand(R0, 32), torch.rand(R0, 8)
+    draws = [tr0.to(DEV), u0.to(DEV)]
+    real_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: draws.pop(0)           # the two draws inside the zero-depth branch, in order
+        ret = r.render_batch_ray(([es], [ec]), dec, T(g["rays_d"]).to(DEV), T(g["rays_o"]).to(DEV), DEV, 0.06,
+                                 gt_depth=gt.to(DEV), t_rand=tr1.to(DEV))
+    finally:
+        torch.rand = real_rand
+    close(ret[5], g["z_vals"], 1e-4, 1e-5); close(ret[2], g["depth"], 1e-3, 1e-4); close(ret[3], g["rgb"], 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["original", "no_mask"])
+def test_g8_tracking_iteration(us, golden, mode):
+    g = golden("g8_tracking")
+    H, W, fx, fy, cx, cy = g["intr"]; H, W = int(H), int(W)
+    eh, ew = int(g["edge"][0]), int(g["edge"][1])
+    cfg = _cfg()
+    dec = _decoders(us, g, "dec__", cfg)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    es, ec = _grid(us, g["grid_s"]), _grid(us, g["grid_c"])
+    r = _renderer(us, cfg, H, W, fx, fy, cx, cy)
+    pose = T(g["pose"]).to(DEV).clone().requires_grad_(True)
+    # the reference's CPU random stream: randint for the pixels, then rand for the jitter
+    torch.manual_seed(int(g["seed"]))
+    idx = torch.randint((H - 2 * eh) * (W - 2 * ew), (int(g["n"]),))
+    c2w = us.common.cam_pose_to_matrix(pose)
+    i, j = torch.meshgrid(torch.linspace(ew, W - ew - 1, W - 2 * ew), torch.linspace(eh, H - eh - 1, H - 2 * eh), indexing="ij")
+    i, j = i.t().reshape(-1)[idx].to(DEV)[None], j.t().reshape(-1)[idx].to(DEV)[None]
+    gd_img, gc_img = T(g["gt_depth"])[:, eh:H - eh, ew:W - ew].reshape(1, -1), T(g["gt_color"])[:, eh:H - eh, ew:W - ew].reshape(1, -1, 3)
+    gd, gc = gd_img[0, idx].to(DEV), gc_img[0, idx].to(DEV)
+    ro, rd = us.common.get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, DEV)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    inside = us.common.bbox_filter(ro, rd, gd, BOUND, require_depth=True)          # Tracker.py:177-184
+    ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+    t_rand = torch.rand(ro.shape[0], 40).to(DEV)
+    ret = r.render_batch_ray(([es], [ec]), dec, rd, ro, DEV, 0.06, gt_depth=gd, t_rand=t_rand)
+    loss = us.tracking_loss(ret, gd, gc, 0.06, dict(fs=10, center=200, tail=50, color=5, depth=1), mode)
+    loss.backward()
+    close(loss, g[f"{mode}_loss"], 1e-4, 1e-5); close(ret[1], g[f"{mode}_unc"], 1e-4, 1e-6)
+    close(pose.grad, g[f"{mode}_gpose"], 5e-3, 5e-3)
+    close(es.params.grad, g[f"{mode}_ggrid_s"], 5e-4, 1e-5)
+
+
+def test_g9_mapping_two_iterations(us, golden):
+    g = golden("g9_mapping")
+    H, W, fx, fy, cx, cy = g["intr"]; H, W = int(H), int(W)
+    cfg = _cfg()
+    dec = _decoders(us, g, "dec0__", cfg)
+    es, ec = _grid(us, g["grid_s0"]), _grid(us, g["grid_c0"])
+    r = _renderer(us, cfg, H, W, fx, fy, cx, cy)
+    gt_depth, gt_color, c2w = T(g["gt_depth"]), T(g["gt_color"]), T(g["c2w"])
+    cam = O.get_camera_rays(H, W, fx, fy, cx, cy)
+    torch.manual_seed(int(g["seed"]))
+    idx = torch.randperm(H * W)[:int(H * W * 0.1)]
+    pool_c, pool_d, pool_r = (gt_color.reshape(-1, 3)[idx][None].to(DEV), gt_depth.reshape(-1)[idx][None].to(DEV),
+                              cam.reshape(-1, 3)[idx][None].to(DEV))
+    f = float(g["lr_factor"])
+    opt = torch.optim.Adam([{"params": list(dec.parameters()), "lr": 0.001 * f},
+                            {"params": [es.params], "lr": 0.05 * f}, {"params": [ec.params], "lr": 0.05 * f}])
+    w = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+    P = pool_d.shape[1]
+    for _ in range(int(g["iters"])):
+        indices = torch.randint(P, (int(g["pixels"]),)).reshape(1, -1)            # CPU stream of the reference
+        ro, rd, gd, gc = us.common.get_samples_all(0, H, 0, W, int(g["pixels"]), H, W, fx, fy, cx, cy, c2w[None].to(DEV),
+                                                   pool_d, pool_c, DEV, pool_r, indices=indices.to(DEV))
+        inside = us.common.bbox_filter(ro, rd, gd, BOUND)
+        ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+        n_depth = int((gd > 0).sum())
+        t_rand = torch.rand(n_depth, 40)
+        n_zero = ro.shape[0] - n_depth
+        draws = [torch.rand(n_zero, 32).to(DEV), torch.rand(n_zero, 8).to(DEV)] if n_zero else []
+        real_rand = torch.rand
+        try:
+            if draws:
+                torch.rand = lambda *a, **k: draws.pop(0)
+            ret = r.render_batch_ray(([es], [ec]), dec, rd, ro, DEV, 0.06, gt_depth=gd, t_rand=t_rand.to(DEV))
+        finally:
+            torch.rand = real_rand
+        loss = us.mapping_loss(ret, gd, gc, 0.06, w, "original")
+        opt.zero_grad(); loss.backward(); opt.step()
+    close(es.params, g["grid_s1"], 1e-3, 2e-5); close(ec.params, g["grid_c1"], 1e-3, 2e-5)
+    for n, v in dec.state_dict().items():
+        close(v, g["dec1__" + n.replace(".", "__")], 1e-3, 2e-5)
+
+
+def test_tcnn_layout_decoders_vs_oracle(us):
+    """tcnn_network=True (Replica configs): FusedMLP flat params, no bias, 32->16->out, vs the fp32 oracle."""
+    torch.manual_seed(5)
+    cfg = _cfg(tcnn=True)
+    dec = us.Decoders(cfg, c_dim=32, truncation=0.06).to(DEV)
+    assert set(dec.state_dict().keys()) == {"beta", "sdf_decoder.params", "color_decoder.params"}
+    assert dec.sdf_decoder.params.numel() == 768 and dec.color_decoder.params.numel() == 768
+    od = O.DecodersOracle(tcnn_network=True)
+    with torch.no_grad():
+        od.sdf_params.copy_(dec.sdf_decoder.params.cpu()); od.color_params.copy_(dec.color_decoder.params.cpu())
+    rng = np.random.default_rng(0)
+    pg = rng.standard_normal(O.make_grid_desc(16, 2, 10, 16, O.per_level_scale(64)).n_params).astype(np.float32) * 0.5
+    es, ec = _grid(us, pg), _grid(us, pg[::-1].copy())
+    os_, oc_ = O.HashGridOracle(3, enc_cfg(10, 64)), O.HashGridOracle(3, enc_cfg(10, 64))
+    with torch.no_grad():
+        os_.params.copy_(T(pg)); oc_.params.copy_(T(pg[::-1].copy()))
+    p = torch.rand(7, 9, 3)
+    raw = dec(p.to(DEV), ([es], [ec]))
+    ref = od(p, ([os_], [oc_]))
+    close(raw, ref, 1e-4, 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+def test_adam_matches_torch(us):
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pt = p0.clone().to(DEV).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=0.05)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g).to(DEV) * (0.1 if step != 3 else 0.0)
+        pt.grad = gr.clone(); opt.step()
+        L.check(L.lib().us_adam_step(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), n, 0.05, 0.9, 0.999, 1e-8, step, L.stream()), "adam")
+    close(p, pt.detach(), 2e-5, 2e-6)

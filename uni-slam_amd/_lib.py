@@ -1,0 +1,123 @@
+"""
+ctypes binding of libunislam_hip.so (C ABI: include/unislam_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not on a HIP device, the calls raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunislam_hip.so")
+US_MAX_LEVELS = 32
+US_GRID_CLAMP01 = 1
+
+c_f = ctypes.c_void_p          # device pointers travel as void*
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_flt = ctypes.c_float
+c_dbl = ctypes.c_double
+
+
+class GridDesc(ctypes.Structure):
+    """us_grid_desc"""
+    _fields_ = [
+        ("n_levels", c_u32), ("n_features", c_u32), ("log2_hashmap_size", c_u32), ("base_resolution", c_u32),
+        ("per_level_scale", c_flt), ("scale", c_flt * US_MAX_LEVELS), ("resolution", c_u32 * US_MAX_LEVELS),
+        ("offset", c_u32 * (US_MAX_LEVELS + 1)), ("n_params", c_u32),
+    ]
+
+
+class MlpDesc(ctypes.Structure):
+    """us_mlp_desc"""
+    _fields_ = [("n_in", c_u32), ("width", c_u32), ("n_hidden", c_u32), ("n_out", c_u32), ("out_act", c_u32),
+                ("has_bias", c_u32), ("precision", c_u32)]
+
+
+_GP = ctypes.POINTER(GridDesc)
+_MP = ctypes.POINTER(MlpDesc)
+_HF = ctypes.POINTER(c_flt)     # host float array
+
+# name -> (restype, argtypes): exactly the declarations of include/unislam_hip.h
+SIGNATURES = {
+    "us_last_error": (ctypes.c_char_p, []),
+    "us_abi_version": (c_int, []),
+    "us_grid_desc_init": (c_int, [_GP, c_u32, c_u32, c_u32, c_u32, c_flt]),
+    "us_hashgrid_fwd": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_f, c_int, c_f]),
+    "us_hashgrid_indices": (c_int, [_GP, c_f, c_i64, c_f, c_int, c_f]),
+    "us_hashgrid_bwd_params": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_int, c_f]),
+    "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
+    "us_mlp_n_params": (ctypes.c_size_t, [_MP]),
+    "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_f]),
+    "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f]),
+    "us_sample_z": (c_int, [c_f, c_i64, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt, c_f, c_f, c_f]),
+    "us_ray_points": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f]),
+    "us_ray_points_bwd": (c_int, [c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),
+    "us_bbox_filter": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),
+    "us_gather_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_int, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f]),
+    "us_composite_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_composite_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_loss_partials_size": (ctypes.c_size_t, [c_i64]),
+    "us_loss_stats": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, c_f, c_f, c_f]),
+    "us_loss_grad": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, _HF, c_f,
+                             c_f, c_f, c_f, c_f, c_f]),
+    "us_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_f]),
+}
+
+_lib = None
+
+
+class UniSlamHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libunislam_hip.so (built by __graft_entry__.build() / make -C uni-slam_amd/csrc).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UniSlamHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  unislam_amd has no CPU or PyTorch fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().us_last_error()
+        raise UniSlamHipError(f"{what}: rc={rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device pointer of a contiguous fp32/int64/uint8 HIP tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise UniSlamHipError("unislam_amd kernels run on the GPU only: got a tensor on " + str(t.device))
+    if not t.is_contiguous():
+        raise UniSlamHipError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    """contiguous fp32 view/copy on the same device"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_floats(vals):
+    arr = (c_flt * len(vals))(*[float(v) for v in vals])
+    return arr

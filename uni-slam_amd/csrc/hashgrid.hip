@@ -1,0 +1,425 @@
+// hashgrid.hip -- multi-resolution hash-grid encoding for gfx950 (MI355X).
+//
+// Replaces tcnn.Encoding("HashGrid") as used by Uni-SLAM (reference src/UNISLAM.py:242-253 construction,
+// src/networks/decoders.py:101-103 call, autograd backward at src/Mapper.py:444 / src/Tracker.py:241).
+// The arithmetic follows the published tiny-cuda-nn algorithm (grid.h of the pinned commit 2ec562e8):
+// grid_scale / grid_resolution / pos_fract / grid_index with the coherent prime hash; indices are bit-exact
+// with oracle/hashgrid_ref.c, features use the same fmaf chain (corner order c = 0..7, bit d of c = +1 in dim d).
+//
+// Layout in HBM: `params` is ONE flat fp32 vector, level after level, entry-major ([entry][F]); a level's slab
+// starts at offset[l]*F floats.  Outputs are [N][L*F] row-major (what the torch module returns).
+//
+// Kernels
+//   k_fwd        one thread per (point, level); blockIdx.y = level, so the level's scale/resolution/offset are
+//                wave-uniform kernel arguments living in SGPRs (no LDS staging needed for them) and all blocks in
+//                flight work on the same level slab (<= 4 MiB for log2T = 19), which is what one XCD L2 holds.
+//                8 independent 8-byte gathers per thread are issued before the first is consumed.
+//   k_bwd_atomic tcnn-shaped scatter: 8*F global float atomics per (point, level).
+//   k_bwd_sliced the fast path: a 1024-thread workgroup owns a SLICE (<= 32768 floats = 128 KiB of LDS) of one
+//                level's table and a partition of the points; it re-derives the 8 corner indices of every point in
+//                its partition (VALU is cheap, memory-side float atomics are not: ~20 G requests/s chip-wide),
+//                accumulates hits in LDS with ds_add_f32 and finally flushes the slice with contiguous global
+//                atomics (256 B per wave instruction = the full atomic rate).  No point sorting, no host sync.
+//   k_bwd_input  dL/dx from the dy_dx the forward stored (tcnn kernel_grid_backward_input).
+#include "us_common.h"
+#include <math.h>
+#include <string.h>
+
+struct LevelTable {                 // passed by value: ~400 B of kernel arguments
+    float    scale[US_MAX_LEVELS];
+    uint32_t res[US_MAX_LEVELS];
+    uint32_t off[US_MAX_LEVELS + 1];
+};
+
+static LevelTable make_table(const us_grid_desc* d) {
+    LevelTable t;
+    for (int l = 0; l < US_MAX_LEVELS; ++l) { t.scale[l] = d->scale[l]; t.res[l] = d->resolution[l]; }
+    for (int l = 0; l <= US_MAX_LEVELS; ++l) t.off[l] = d->offset[l];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: descriptor (tcnn GridEncodingTemplated constructor arithmetic, fp32 like the original)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int us_grid_desc_init(us_grid_desc* d, uint32_t n_levels, uint32_t n_features, uint32_t log2_hashmap_size,
+                                 uint32_t base_resolution, float per_level_scale) {
+    US_REQUIRE(d, US_ERR_NULL, "us_grid_desc_init: desc is NULL");
+    US_REQUIRE(n_levels >= 1 && n_levels <= US_MAX_LEVELS, US_ERR_CONFIG, "us_grid_desc_init: n_levels %u not in 1..%d", n_levels, US_MAX_LEVELS);
+    US_REQUIRE(n_features == 1 || n_features == 2 || n_features == 4, US_ERR_CONFIG, "us_grid_desc_init: n_features_per_level %u not in {1,2,4}", n_features);
+    US_REQUIRE(log2_hashmap_size >= 3 && log2_hashmap_size <= 28, US_ERR_CONFIG, "us_grid_desc_init: log2_hashmap_size %u out of range", log2_hashmap_size);
+    US_REQUIRE(base_resolution >= 1 && per_level_scale >= 1.0f, US_ERR_CONFIG, "us_grid_desc_init: bad base_resolution / per_level_scale");
+    memset(d, 0, sizeof(*d));
+    d->n_levels = n_levels; d->n_features = n_features; d->log2_hashmap_size = log2_hashmap_size;
+    d->base_resolution = base_resolution; d->per_level_scale = per_level_scale;
+    const float log2_pls = log2f(per_level_scale);
+    uint64_t offset = 0;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        const float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        const uint32_t max_params = 0xFFFFFFFFu / 2u;
+        uint32_t n = (powf((float)res, 3.0f) > (float)max_params) ? max_params : res * res * res;
+        n = ((n + 7u) / 8u) * 8u;
+        const uint32_t cap = 1u << log2_hashmap_size;
+        if (n > cap) n = cap;
+        d->scale[l] = scale; d->resolution[l] = res; d->offset[l] = (uint32_t)offset;
+        offset += n;
+    }
+    US_REQUIRE(offset * n_features < 0xFFFFFFFFull, US_ERR_CONFIG, "us_grid_desc_init: table too large");
+    d->offset[n_levels] = (uint32_t)offset;
+    d->n_params = (uint32_t)(offset * n_features);
+    return US_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct LevelGeom {          // wave-uniform
+    float scale; uint32_t res; uint32_t hs; bool hashed; uint32_t res2;
+};
+
+__device__ __forceinline__ LevelGeom level_geom(const LevelTable& t, uint32_t level) {
+    LevelGeom g;
+    g.scale = t.scale[level]; g.res = t.res[level]; g.hs = t.off[level + 1] - t.off[level];
+    // tcnn grid_index: dims are accumulated while stride <= hashmap_size; the hash replaces the sum when the
+    // final stride exceeds hashmap_size.  For a Hash grid that is exactly "res^3 (uint32) > hashmap_size", also
+    // when the loop stopped early (res or res^2 already > hashmap_size).
+    uint32_t stride = 1; bool early = false;
+    for (int dim = 0; dim < 3; ++dim) { if (stride <= g.hs) stride *= g.res; else early = true; }
+    g.hashed = early || (g.hs < stride);
+    g.res2 = g.res * g.res;
+    return g;
+}
+
+__device__ __forceinline__ void pos_fract(float x, float scale, float& pos, uint32_t& cell) {
+    const float p = fmaf(scale, x, 0.5f);
+    const float f = floorf(p);
+    cell = (uint32_t)(int)f;
+    pos = p - f;
+}
+
+// entry index of vertex (gx,gy,gz) inside the level
+__device__ __forceinline__ uint32_t grid_index(const LevelGeom& g, uint32_t gx, uint32_t gy, uint32_t gz) {
+    if (g.hashed) {
+        const uint32_t h = gx ^ (gy * 2654435761u) ^ (gz * 805459861u);
+        return h & (g.hs - 1u);                 // hashed levels always hold exactly 2^log2T entries
+    }
+    uint32_t idx = gx + gy * g.res + gz * g.res2;
+    if (idx >= g.hs) idx %= g.hs;               // wrap-around of the +1 vertex at x == 1 (rare)
+    return idx;
+}
+
+// decoders.py:101 clamps positions to [0,1] before the encoder; US_GRID_CLAMP01 folds that clamp into the load
+__device__ __forceinline__ float load_x(const float* __restrict__ x, int64_t i, int k, int clamp) {
+    const float v = x[i * 3 + k];
+    return clamp ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+}
+
+// weights in tcnn's multiplication order: w = ((1*a0)*a1)*a2
+__device__ __forceinline__ float corner_weight(int c, const float pos[3]) {
+    float w = (c & 1) ? pos[0] : 1.0f - pos[0];
+    w *= (c & 2) ? pos[1] : 1.0f - pos[1];
+    w *= (c & 4) ? pos[2] : 1.0f - pos[2];
+    return w;
+}
+
+template <int F> struct Feat;
+template <> struct Feat<1> { typedef float  T; };
+template <> struct Feat<2> { typedef float2 T; };
+template <> struct Feat<4> { typedef float4 T; };
+
+template <int F> __device__ __forceinline__ void feat_to_array(const typename Feat<F>::T& v, float* a);
+template <> __device__ __forceinline__ void feat_to_array<1>(const float& v, float* a) { a[0] = v; }
+template <> __device__ __forceinline__ void feat_to_array<2>(const float2& v, float* a) { a[0] = v.x; a[1] = v.y; }
+template <> __device__ __forceinline__ void feat_to_array<4>(const float4& v, float* a) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int F, bool DYDX>
+__global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
+                                             const float* __restrict__ x, int64_t n, float* __restrict__ out,
+                                             float* __restrict__ dy_dx, int clamp) {
+    const uint32_t level = blockIdx.y;
+    const LevelGeom g = level_geom(tab, level);
+    const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
+    const uint32_t C = n_levels * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pos[3]; uint32_t cell[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+        typename Feat<F>::T v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)           // 8 independent gathers in flight
+            v[c] = grid[grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1))];
+        float res[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) res[f] = 0.0f;
+        float va[8][F];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            feat_to_array<F>(v[c], va[c]);
+            const float w = corner_weight(c, pos);
+#pragma unroll
+            for (int f = 0; f < F; ++f) res[f] = fmaf(w, va[c][f], res[f]);
+        }
+        float* o = out + i * C + level * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = res[f];
+        if (DYDX) {
+            // tcnn: for grad_dim, idx over the two other dims (lower dim = bit 0 of idx), weight = scale*a*b,
+            // grads += weight * (right - left)
+            float* d = dy_dx + (i * C + level * F) * 3;
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float acc[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const int d0 = gd == 0 ? 1 : 0, d1 = gd == 2 ? 1 : 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w = g.scale;
+                    w *= (q & 1) ? pos[d0] : 1.0f - pos[d0];
+                    w *= (q & 2) ? pos[d1] : 1.0f - pos[d1];
+                    const int cl = ((q & 1) << d0) | (((q >> 1) & 1) << d1);
+                    const int cr = cl | (1 << gd);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) acc[f] += w * (va[cr][f] - va[cl][f]);
+                }
+                const float xin = x[i * 3 + gd];
+                const bool pass = !clamp || (xin >= 0.0f && xin <= 1.0f);
+#pragma unroll
+                for (int f = 0; f < F; ++f) d[f * 3 + gd] = pass ? acc[f] : 0.0f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_indices(LevelTable tab, uint32_t n_levels, const float* __restrict__ x,
+                                                 int64_t n, uint32_t* __restrict__ idx, int clamp) {
+    const uint32_t level = blockIdx.y;
+    const LevelGeom g = level_geom(tab, level);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pos[3]; uint32_t cell[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            idx[(i * n_levels + level) * 8 + c] =
+                grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward wrt table: direct global atomics (levels selected by `level_mask`)
+// ---------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void k_bwd_atomic(LevelTable tab, uint32_t n_levels, uint32_t level_mask,
+                                                    const float* __restrict__ x, const float* __restrict__ dL_dy,
+                                                    int64_t n, float* __restrict__ grad, int clamp) {
+    const uint32_t level = blockIdx.y;
+    if (!((level_mask >> level) & 1u)) return;
+    const LevelGeom g = level_geom(tab, level);
+    float* gl = grad + (size_t)tab.off[level] * F;
+    const uint32_t C = n_levels * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float dy[F]; bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { dy[f] = dL_dy[i * C + level * F + f]; any |= (dy[f] != 0.0f); }
+        if (!any) continue;                    // adding zeros changes nothing
+        float pos[3]; uint32_t cell[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t e = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1));
+            const float w = corner_weight(c, pos);
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(gl + (size_t)e * F + f, w * dy[f]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward wrt table: LDS-privatised slices
+// ---------------------------------------------------------------------------------------------------------------
+#define US_SLICE_FLOATS 32768            // 128 KiB of the 160 KiB LDS
+#define US_SLICE_THREADS 1024
+
+struct SliceMap {                        // prefix sum of slices per level (only levels in the mask have slices)
+    uint32_t first[US_MAX_LEVELS + 1];
+};
+
+template <int F>
+__global__ __launch_bounds__(US_SLICE_THREADS) void k_bwd_sliced(LevelTable tab, SliceMap smap, uint32_t n_levels,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ dL_dy, int64_t n,
+                                                                 float* __restrict__ grad, int clamp) {
+    __shared__ float acc[US_SLICE_FLOATS];
+    constexpr uint32_t SLICE_ENTRIES = US_SLICE_FLOATS / F;
+    // which (level, slice) is blockIdx.y ?   (wave-uniform scalar search over <= 32 levels)
+    uint32_t level = 0;
+    while (level + 1 < n_levels && smap.first[level + 1] <= blockIdx.y) ++level;
+    const uint32_t slice = blockIdx.y - smap.first[level];
+    const LevelGeom g = level_geom(tab, level);
+    const uint32_t lo = slice * SLICE_ENTRIES;
+    const uint32_t cnt = min(SLICE_ENTRIES, g.hs - lo);
+    for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) acc[k] = 0.0f;
+    __syncthreads();
+
+    const uint32_t C = n_levels * F;
+    // contiguous partition of the points for this blockIdx.x
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(n, i0 + per);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += US_SLICE_THREADS) {
+        float dy[F]; bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { dy[f] = dL_dy[i * C + level * F + f]; any |= (dy[f] != 0.0f); }
+        if (!any) continue;
+        float pos[3]; uint32_t cell[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t e = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1)) - lo;
+            if (e < cnt) {                     // unsigned compare also rejects e < lo
+                const float w = corner_weight(c, pos);
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[e * F + f], w * dy[f]);     // ds_add_f32
+            }
+        }
+    }
+    __syncthreads();
+    float* gl = grad + ((size_t)tab.off[level] + lo) * F;
+    for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) {
+        const float v = acc[k];
+        if (v != 0.0f) atomicAdd(gl + k, v);   // contiguous lanes -> 64-B atomic requests, full atomic rate
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward wrt positions
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwd_input(const float* __restrict__ dL_dy, const float* __restrict__ dy_dx,
+                                                   int64_t n, uint32_t C, float* __restrict__ dL_dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (uint32_t k = 0; k < C; ++k) {
+            const float gk = dL_dy[i * C + k];
+            const float* d = dy_dx + (i * C + k) * 3;
+            r0 += gk * d[0]; r1 += gk * d[1]; r2 += gk * d[2];
+        }
+        dL_dx[i * 3 + 0] = r0; dL_dx[i * 3 + 1] = r1; dL_dx[i * 3 + 2] = r2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+static int check_desc(const char* fn, const us_grid_desc* d) {
+    US_REQUIRE(d, US_ERR_NULL, "%s: desc is NULL", fn);
+    US_REQUIRE(d->n_levels >= 1 && d->n_levels <= US_MAX_LEVELS, US_ERR_CONFIG, "%s: n_levels %u", fn, d->n_levels);
+    US_REQUIRE(d->n_features == 1 || d->n_features == 2 || d->n_features == 4, US_ERR_CONFIG, "%s: n_features %u", fn, d->n_features);
+    US_REQUIRE(d->n_params == d->offset[d->n_levels] * d->n_features, US_ERR_CONFIG, "%s: descriptor not initialised by us_grid_desc_init", fn);
+    return US_OK;
+}
+
+static unsigned point_blocks(int64_t n, int threads, int cap) {
+    int64_t b = us_cdiv(n, threads);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out,
+                               float* dy_dx, int flags, void* stream) {
+    const int clamp = flags & US_GRID_CLAMP01;
+    int rc = check_desc("us_hashgrid_fwd", d); if (rc) return rc;
+    US_REQUIRE(params && x && out, US_ERR_NULL, "us_hashgrid_fwd: NULL pointer");
+    US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_hashgrid_fwd: n < 0");
+    if (n == 0) return US_OK;
+    const LevelTable t = make_table(d);
+    dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_FWD(F)                                                                                         \
+    if (dy_dx) hipLaunchKernelGGL((k_fwd<F, true>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp); \
+    else hipLaunchKernelGGL((k_fwd<F, false>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp);
+    switch (d->n_features) { case 1: LAUNCH_FWD(1) break; case 2: LAUNCH_FWD(2) break; default: LAUNCH_FWD(4) break; }
+#undef LAUNCH_FWD
+    US_CHECK_LAUNCH("us_hashgrid_fwd");
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_indices(const us_grid_desc* d, const float* x, int64_t n, uint32_t* idx, int flags, void* stream) {
+    const int clamp = flags & US_GRID_CLAMP01;
+    int rc = check_desc("us_hashgrid_indices", d); if (rc) return rc;
+    US_REQUIRE(x && idx, US_ERR_NULL, "us_hashgrid_indices: NULL pointer");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    const LevelTable t = make_table(d);
+    dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
+    hipLaunchKernelGGL(k_indices, grid, block, 0, (hipStream_t)stream, t, d->n_levels, x, n, idx, clamp);
+    US_CHECK_LAUNCH("us_hashgrid_indices");
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n,
+                                      float* grad_params, int mode, int flags, void* stream) {
+    const int clamp = flags & US_GRID_CLAMP01;
+    int rc = check_desc("us_hashgrid_bwd_params", d); if (rc) return rc;
+    US_REQUIRE(x && dL_dy && grad_params, US_ERR_NULL, "us_hashgrid_bwd_params: NULL pointer");
+    US_REQUIRE(mode >= -1 && mode <= 1, US_ERR_CONFIG, "us_hashgrid_bwd_params: mode %d", mode);
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    const LevelTable t = make_table(d);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t F = d->n_features, L = d->n_levels;
+    const uint32_t slice_entries = US_SLICE_FLOATS / F;
+    // per level: slices pay when the level receives many more updates (8 per point) than it has entries
+    uint32_t sliced_mask = 0;
+    for (uint32_t l = 0; l < L; ++l) {
+        const uint64_t hs = d->offset[l + 1] - d->offset[l];
+        bool sliced = mode == 1 || (mode == -1 && (uint64_t)n * 8ull >= hs);
+        if (sliced) sliced_mask |= 1u << l;
+    }
+    const uint32_t all = L == 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
+    const uint32_t atomic_mask = all & ~sliced_mask;
+    if (atomic_mask) {
+        dim3 grid(point_blocks(n, 256, 1 << 20), L), block(256);
+        switch (F) {
+            case 1: hipLaunchKernelGGL((k_bwd_atomic<1>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
+            case 2: hipLaunchKernelGGL((k_bwd_atomic<2>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
+            default: hipLaunchKernelGGL((k_bwd_atomic<4>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
+        }
+        US_CHECK_LAUNCH("us_hashgrid_bwd_params(atomic)");
+    }
+    if (sliced_mask) {
+        SliceMap sm; uint32_t total = 0;
+        for (uint32_t l = 0; l < L; ++l) {
+            sm.first[l] = total;
+            if ((sliced_mask >> l) & 1u) total += (uint32_t)us_cdiv(d->offset[l + 1] - d->offset[l], slice_entries);
+        }
+        for (uint32_t l = L; l <= US_MAX_LEVELS; ++l) sm.first[l] = total;
+        // levels outside the mask get zero slices: first[l+1] == first[l], the in-kernel search skips them.
+        // point partitions: enough workgroups to fill 256 CUs a few times, but >= 8192 points each so that the
+        // slice flush (<= 128 KiB of atomics per workgroup) stays small next to the accumulation work
+        int64_t parts = us_cdiv(1024, total);
+        const int64_t max_parts = us_cdiv(n, 8192);
+        if (parts > max_parts) parts = max_parts;
+        if (parts < 1) parts = 1;
+        dim3 grid((unsigned)parts, total), block(US_SLICE_THREADS);
+        switch (F) {
+            case 1: hipLaunchKernelGGL((k_bwd_sliced<1>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
+            case 2: hipLaunchKernelGGL((k_bwd_sliced<2>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
+            default: hipLaunchKernelGGL((k_bwd_sliced<4>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
+        }
+        US_CHECK_LAUNCH("us_hashgrid_bwd_params(sliced)");
+    }
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t C, float* dL_dx,
+                                     void* stream) {
+    US_REQUIRE(dL_dy && dy_dx && dL_dx, US_ERR_NULL, "us_hashgrid_bwd_input: NULL pointer");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    hipLaunchKernelGGL(k_bwd_input, dim3(point_blocks(n, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, dL_dy, dy_dx, n, C, dL_dx);
+    US_CHECK_LAUNCH("us_hashgrid_bwd_input");
+    return US_OK;
+}

@@ -1,0 +1,457 @@
+// mlp.hip -- fully fused tiny MLP (forward and backward) on the gfx950 matrix cores.
+//
+// Replaces tcnn.Network("FullyFusedMLP") (reference src/networks/decoders.py:50-70, calls :123,:148) and the
+// nn.Linear stacks of the torch path (src/networks/decoders.py:74-84, :125-128, :150-153).
+//
+// Orientation.  Everything is computed TRANSPOSED: H_l^T[neuron][point] = W_l[neuron][k] * H_{l-1}^T[k][point].
+// With v_mfma_f32_16x16x4_f32 (A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D[row=4*(lane>>4)+reg][col=lane&15])
+// a 16-neuron x 16-point accumulator tile has the point on the lane and 4 neurons in its 4 registers, which is
+// exactly the B-operand shape of the next layer's MFMAs when K-step s takes register (s&3) of tile (s>>2):
+//     k(s, g) = 16*(s>>2) + 4*g + (s&3),  g = lane>>4
+// so activations never leave the register file between layers (no LDS, no cross-lane moves); only the weight
+// operand is read from LDS (one ds_read_b128 feeds 4 K-steps x 4 point tiles = 16 MFMAs).  The input features
+// use the same k(s,g) map, so a lane loads two float4 per point straight from the row-major [N][32] tensor.
+// f32-input MFMA is bit-for-bit a k-ordered fmaf chain, so this path matches an fp32 reference to rounding;
+// the work is ~30 kFLOP/point, <1% of the fp32 matrix peak at the target ray rate, so exact fp32 is affordable.
+//
+// Backward (one launch): recompute the hidden activations, then per layer
+//     dW_l  += dH_l  * H_{l-1}^T      reduction over POINTS -> both operands are transposed through a per-wave LDS
+//                                     scratch ([neuron][64 points], 272-byte rows), accumulated in MFMA registers
+//                                     across the whole grid-stride loop and flushed once with float atomics;
+//     dH_{l-1} = W_l^T * dH_l (.) relu'   same chained form as the forward, with W^T also resident in LDS.
+#include "us_common.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define MLP_WAVES 4
+#define MLP_THREADS (MLP_WAVES * 64)
+
+__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int NIN, int WIDTH, int NHID>
+struct MlpCfg {
+    static constexpr int N_IN = NIN, W = WIDTH, NH = NHID;
+    static constexpr int NQ = (WIDTH == 64) ? 2 : 4;  // 16-point tiles per wave iteration (register budget)
+    static constexpr int PTS = 16 * NQ;               // points per wave iteration
+    static constexpr int SCR_STRIDE = PTS + 4;        // scratch row: PTS points + 4 pad floats (16-byte aligned rows)
+    static constexpr int MT = WIDTH / 16;          // 16-row tiles of a hidden layer
+    static constexpr int KB_IN = NIN / 16;         // 16-wide K blocks of the input layer
+    static constexpr int KB_H = WIDTH / 16;
+    static constexpr int S_IN = NIN + 4;           // LDS row strides (floats)
+    static constexpr int S_W = WIDTH + 4;
+    static constexpr int S_O = 16 + 4;
+    // flat parameter offsets (floats)
+    static constexpr int P_W0 = 0;
+    static constexpr int P_WH = WIDTH * NIN;
+    static constexpr int P_WL = P_WH + (NHID - 1) * WIDTH * WIDTH;
+    static constexpr int N_W = P_WL + 16 * WIDTH;
+    static constexpr int P_B0 = N_W;
+    static constexpr int P_BH = P_B0 + WIDTH;
+    static constexpr int P_BL = P_BH + (NHID - 1) * WIDTH;
+    static constexpr int N_B = NHID * WIDTH + 16;
+    // LDS offsets (floats): forward weights, biases, then transposed weights (backward only)
+    static constexpr int L_W0 = 0;
+    static constexpr int L_WH = L_W0 + WIDTH * S_IN;
+    static constexpr int L_WL = L_WH + (NHID - 1) * WIDTH * S_W;
+    static constexpr int L_B = L_WL + 16 * S_W;
+    static constexpr int L_FWD_END = L_B + N_B;
+    static constexpr int L_W0T = ((L_FWD_END + 3) / 4) * 4;
+    static constexpr int L_WHT = L_W0T + NIN * S_W;
+    static constexpr int L_WLT = L_WHT + (NHID - 1) * WIDTH * S_W;
+    static constexpr int L_BWD_END = L_WLT + WIDTH * S_O;
+    static constexpr int SCR_ROWS_A = (NIN > WIDTH ? NIN : WIDTH);
+    static constexpr int SCR_ROWS_B = (WIDTH > 16 ? WIDTH : 16);
+    static constexpr int L_SCR = ((L_BWD_END + 3) / 4) * 4;
+    static constexpr int SCR_PER_WAVE = (SCR_ROWS_A + SCR_ROWS_B) * SCR_STRIDE;
+    static_assert(L_SCR + MLP_WAVES * SCR_PER_WAVE <= 40960, "MLP backward exceeds 160 KiB of LDS");
+    static constexpr int L_TOTAL_BWD = L_SCR + MLP_WAVES * SCR_PER_WAVE;
+};
+
+// out[q][m] = W(rows 16m..16m+15) * in + bias      (KB 16-wide K blocks; W in LDS with row stride SW)
+template <int NQ, int KB, int MT, int SW>
+__device__ __forceinline__ void dense(const float* w, const float* bias, const v4f (&in)[NQ][KB],
+                                      v4f (&out)[NQ][MT], int row, int g) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        v4f b0 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b0 = *reinterpret_cast<const v4f*>(bias + 16 * m + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) out[q][m] = b0;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const v4f a = *reinterpret_cast<const v4f*>(w + (16 * m + row) * SW + 16 * b + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) out[q][m] = mfma4(a[c], in[q][b][c], out[q][m]);
+        }
+    }
+}
+
+template <int NQ, int MT>
+__device__ __forceinline__ void relu_(v4f (&h)[NQ][MT]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[q][m][r] = fmaxf(h[q][m][r], 0.0f);
+}
+
+// dh *= (h > 0)
+template <int NQ, int MT>
+__device__ __forceinline__ void relu_bwd_(v4f (&dh)[NQ][MT], const v4f (&h)[NQ][MT]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh[q][m][r] = h[q][m][r] > 0.0f ? dh[q][m][r] : 0.0f;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == US_ACT_TANH) return tanhf(v);
+    if (act == US_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == US_ACT_TANH) return 1.0f - y * y;
+    if (act == US_ACT_SIGMOID) return y * (1.0f - y);
+    return 1.0f;
+}
+
+// cooperative load of the flat parameter vector into the LDS images
+template <typename C, bool BWD>
+__device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ params, bool has_bias) {
+    constexpr int NIN = C::N_IN, WIDTH = C::W, NHID = C::NH;
+    for (int i = threadIdx.x; i < WIDTH * NIN; i += MLP_THREADS) {
+        const int r = i / NIN, c = i % NIN; const float v = params[C::P_W0 + i];
+        lds[C::L_W0 + r * C::S_IN + c] = v;
+        if (BWD) lds[C::L_W0T + c * C::S_W + r] = v;
+    }
+    if (NHID == 2)
+        for (int i = threadIdx.x; i < WIDTH * WIDTH; i += MLP_THREADS) {
+            const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WH + i];
+            lds[C::L_WH + r * C::S_W + c] = v;
+            if (BWD) lds[C::L_WHT + c * C::S_W + r] = v;
+        }
+    for (int i = threadIdx.x; i < 16 * WIDTH; i += MLP_THREADS) {
+        const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WL + i];
+        lds[C::L_WL + r * C::S_W + c] = v;
+        if (BWD) lds[C::L_WLT + c * C::S_O + r] = v;
+    }
+    for (int i = threadIdx.x; i < C::N_B; i += MLP_THREADS) lds[C::L_B + i] = has_bias ? params[C::P_B0 + i] : 0.0f;
+}
+
+// input features of 64 points as B operands: xb[q][b][c] = in[p(q)][16b + 4g + c]
+template <int NQ, int NIN>
+__device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_t base, int64_t n, int row, int g,
+                                            v4f (&xb)[NQ][NIN / 16]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int64_t p = base + 16 * q + row;
+#pragma unroll
+        for (int b = 0; b < NIN / 16; ++b) {
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (p < n) v = *reinterpret_cast<const v4f*>(in + p * NIN + 16 * b + 4 * g);
+            xb[q][b] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------------------
+template <int NIN, int WIDTH, int NHID>
+__global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict__ params, int has_bias, int n_out,
+                                                         int act, const float* __restrict__ in, int64_t n,
+                                                         float* __restrict__ out, int64_t out_stride) {
+    typedef MlpCfg<NIN, WIDTH, NHID> C;
+    constexpr int NQ = C::NQ, PTS = C::PTS;
+    __shared__ __attribute__((aligned(16))) float lds[C::L_FWD_END];
+    load_weights<C, false>(lds, params, has_bias != 0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
+    const float* bias = lds + C::L_B;
+    const int64_t n_chunks = (n + PTS - 1) / PTS;
+    for (int64_t chunk = (int64_t)blockIdx.x * MLP_WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * MLP_WAVES) {
+        const int64_t base = chunk * PTS;
+        v4f xb[NQ][C::KB_IN];
+        load_inputs<NQ, NIN>(in, base, n, row, g, xb);
+        v4f h0[NQ][C::MT];
+        dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
+        relu_<NQ, C::MT>(h0);
+        v4f y[NQ][1];
+        if (NHID == 2) {
+            v4f h1[NQ][C::MT];
+            dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WH, bias + WIDTH, h0, h1, row, g);
+            relu_<NQ, C::MT>(h1);
+            dense<NQ, C::KB_H, 1, C::S_W>(lds + C::L_WL, bias + NHID * WIDTH, h1, y, row, g);
+        } else {
+            dense<NQ, C::KB_H, 1, C::S_W>(lds + C::L_WL, bias + NHID * WIDTH, h0, y, row, g);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t p = base + 16 * q + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * g + r;
+                if (p < n && o < n_out) out[p * out_stride + o] = act_fwd(y[q][0][r], act);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward
+// -------------------------------------------------------------------------------------------------------------
+template <int NQ, int MT>
+__device__ __forceinline__ void scratch_store(float* buf, const v4f (&t)[NQ][MT], int row, int g) {
+    constexpr int SCR_STRIDE = 16 * NQ + 4;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[(16 * m + 4 * g + r) * SCR_STRIDE + 16 * q + row] = t[q][m][r];
+}
+
+// acc[mo][mi] += D(rows out) * H(rows in)^T over the 64 points held in the two scratch images
+template <int NQ, int MO, int MI>
+__device__ __forceinline__ void wgrad(const float* bufD, const float* bufH, v4f (&acc)[MO][MI], int row, int g) {
+    constexpr int SCR_STRIDE = 16 * NQ + 4;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        v4f a[MO], b[MI];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) a[mo] = *reinterpret_cast<const v4f*>(bufD + (16 * mo + row) * SCR_STRIDE + 16 * qq + 4 * g);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) b[mi] = *reinterpret_cast<const v4f*>(bufH + (16 * mi + row) * SCR_STRIDE + 16 * qq + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mo][mi] = mfma4(a[mo][c], b[mi][c], acc[mo][mi]);
+    }
+}
+
+template <int NQ, int MT>
+__device__ __forceinline__ void bias_acc(v4f (&db)[MT], const v4f (&dh)[NQ][MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) db[m] += dh[q][m];
+}
+
+// flush a weight-gradient accumulator: tile (mo, mi) holds dW[16mo + 4g + r][16mi + row]
+template <int MO, int MI>
+__device__ __forceinline__ void flush_wgrad(float* gw, int K, const v4f (&acc)[MO][MI], int row, int g) {
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[mo][mi][r];
+                if (v != 0.0f) atomicAdd(gw + (16 * mo + 4 * g + r) * K + 16 * mi + row, v);
+            }
+}
+
+template <int MT>
+__device__ __forceinline__ void flush_bgrad(float* gb, v4f (&db)[MT], int row, int g) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = db[m][r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (row == 0 && v != 0.0f) atomicAdd(gb + 16 * m + 4 * g + r, v);
+        }
+}
+
+template <int NIN, int WIDTH, int NHID>
+__global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict__ params, int has_bias, int n_out,
+                                                         int act, const float* __restrict__ in,
+                                                         const float* __restrict__ out, int64_t out_stride,
+                                                         const float* __restrict__ dL_dout, int64_t dout_stride,
+                                                         int64_t n, float* __restrict__ dL_din,
+                                                         float* __restrict__ grad_params) {
+    typedef MlpCfg<NIN, WIDTH, NHID> C;
+    constexpr int NQ = C::NQ, PTS = C::PTS;
+    __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
+    load_weights<C, true>(lds, params, has_bias != 0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
+    const float* bias = lds + C::L_B;
+    float* bufA = lds + C::L_SCR + wave * C::SCR_PER_WAVE;         // H_{l-1}^T image  [neuron][PTS points]
+    float* bufB = bufA + C::SCR_ROWS_A * C::SCR_STRIDE;            // dH_l^T image
+
+    v4f gW0[C::MT][C::KB_IN], gWH[C::MT][C::MT], gWL[1][C::MT];
+    v4f gB0[C::MT], gBH[C::MT], gBL[1];
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < C::MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < C::KB_IN; ++b) gW0[a][b] = zero;
+#pragma unroll
+        for (int b = 0; b < C::MT; ++b) gWH[a][b] = zero;
+        gWL[0][a] = zero; gB0[a] = zero; gBH[a] = zero;
+    }
+    gBL[0] = zero;
+
+    const int64_t n_chunks = (n + PTS - 1) / PTS;
+    const int64_t n_groups = (n_chunks + MLP_WAVES - 1) / MLP_WAVES;
+    // uniform trip count for the whole workgroup (there are __syncthreads inside); idle waves run on zeros
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t base = (grp * MLP_WAVES + wave) * PTS;
+        v4f xb[NQ][C::KB_IN];
+        load_inputs<NQ, NIN>(in, base, n, row, g, xb);
+        v4f h0[NQ][C::MT], h1[NQ][C::MT];
+        dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
+        relu_<NQ, C::MT>(h0);
+        if (NHID == 2) {
+            dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WH, bias + WIDTH, h0, h1, row, g);
+            relu_<NQ, C::MT>(h1);
+        }
+        // dL/d(pre-activation of the output layer), rows >= n_out and points >= n are zero
+        v4f dO[NQ][1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t p = base + 16 * q + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * g + r;
+                float d = 0.0f;
+                if (p < n && o < n_out) d = dL_dout[p * dout_stride + o] * act_bwd(out[p * out_stride + o], act);
+                dO[q][0][r] = d;
+            }
+        }
+        // ---- output layer:  dWL += dO * Hlast^T ;  dHlast = WL^T dO (.) relu'
+        v4f (&hl)[NQ][C::MT] = (NHID == 2) ? h1 : h0;
+        __syncthreads();                                   // previous iteration's scratch reads are done
+        scratch_store<NQ, C::MT>(bufA, hl, row, g);
+        scratch_store<NQ, 1>(bufB, dO, row, g);
+        __syncthreads();
+        if (grad_params) { wgrad<NQ, 1, C::MT>(bufB, bufA, gWL, row, g); bias_acc<NQ, 1>(gBL, dO); }
+        v4f dh[NQ][C::MT];
+        dense<NQ, 1, C::MT, C::S_O>(lds + C::L_WLT, nullptr, dO, dh, row, g);
+        relu_bwd_<NQ, C::MT>(dh, hl);
+        if (NHID == 2) {
+            // ---- hidden layer: dWH += dH1 * H0^T ; dH0 = WH^T dH1 (.) relu'
+            __syncthreads();
+            scratch_store<NQ, C::MT>(bufA, h0, row, g);
+            scratch_store<NQ, C::MT>(bufB, dh, row, g);
+            __syncthreads();
+            if (grad_params) { wgrad<NQ, C::MT, C::MT>(bufB, bufA, gWH, row, g); bias_acc<NQ, C::MT>(gBH, dh); }
+            v4f dh0[NQ][C::MT];
+            dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WHT, nullptr, dh, dh0, row, g);
+            relu_bwd_<NQ, C::MT>(dh0, h0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) dh[q][m] = dh0[q][m];
+        }
+        // ---- input layer: dW0 += dH0 * X^T ; dX = W0^T dH0
+        if (grad_params) {
+            __syncthreads();
+            scratch_store<NQ, C::KB_IN>(bufA, xb, row, g);  // xb tile b, register c is feature 16b + 4g + c: same map
+            scratch_store<NQ, C::MT>(bufB, dh, row, g);
+            __syncthreads();
+            wgrad<NQ, C::MT, C::KB_IN>(bufB, bufA, gW0, row, g);
+            bias_acc<NQ, C::MT>(gB0, dh);
+        }
+        if (dL_din) {
+            v4f dx[NQ][C::KB_IN];
+            dense<NQ, C::KB_H, C::KB_IN, C::S_W>(lds + C::L_W0T, nullptr, dh, dx, row, g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t p = base + 16 * q + row;
+                if (p < n) {
+#pragma unroll
+                    for (int b = 0; b < C::KB_IN; ++b)
+                        *reinterpret_cast<v4f*>(dL_din + p * NIN + 16 * b + 4 * g) = dx[q][b];
+                }
+            }
+        }
+    }
+    if (grad_params) {
+        flush_wgrad<C::MT, C::KB_IN>(grad_params + C::P_W0, NIN, gW0, row, g);
+        if (NHID == 2) flush_wgrad<C::MT, C::MT>(grad_params + C::P_WH, WIDTH, gWH, row, g);
+        flush_wgrad<1, C::MT>(grad_params + C::P_WL, WIDTH, gWL, row, g);
+        if (has_bias) {
+            flush_bgrad<C::MT>(grad_params + C::P_B0, gB0, row, g);
+            if (NHID == 2) flush_bgrad<C::MT>(grad_params + C::P_BH, gBH, row, g);
+            flush_bgrad<1>(grad_params + C::P_BL, gBL, row, g);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------------------
+static int check_mlp(const char* fn, const us_mlp_desc* d) {
+    US_REQUIRE(d, US_ERR_NULL, "%s: desc is NULL", fn);
+    US_REQUIRE(d->n_in == 32, US_ERR_CONFIG, "%s: n_in %u (only 32 = 16 levels x 2 features is built)", fn, d->n_in);
+    US_REQUIRE(d->width == 16 || d->width == 32 || d->width == 64, US_ERR_CONFIG, "%s: width %u not in {16,32,64}", fn, d->width);
+    US_REQUIRE(d->n_hidden == 1 || d->n_hidden == 2, US_ERR_CONFIG, "%s: n_hidden %u not in {1,2}", fn, d->n_hidden);
+    US_REQUIRE(d->n_out >= 1 && d->n_out <= 16, US_ERR_CONFIG, "%s: n_out %u not in 1..16", fn, d->n_out);
+    US_REQUIRE(d->out_act <= US_ACT_SIGMOID, US_ERR_CONFIG, "%s: out_act %u", fn, d->out_act);
+    US_REQUIRE(d->precision == US_PREC_F32, US_ERR_CONFIG, "%s: precision %u (only US_PREC_F32 is built in this version)", fn, d->precision);
+    return US_OK;
+}
+
+extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
+    if (!d) return 0;
+    size_t nw = (size_t)d->width * d->n_in + (size_t)(d->n_hidden - 1) * d->width * d->width + 16u * d->width;
+    if (d->has_bias) nw += (size_t)d->n_hidden * d->width + 16u;
+    return nw;
+}
+
+#define MLP_DISPATCH(KERNEL, ...)                                                                                  \
+    do {                                                                                                           \
+        const int key = (int)d->width * 10 + (int)d->n_hidden;                                                     \
+        switch (key) {                                                                                             \
+            case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1>), grid, block, 0, s, __VA_ARGS__); break;              \
+            case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2>), grid, block, 0, s, __VA_ARGS__); break;              \
+            case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1>), grid, block, 0, s, __VA_ARGS__); break;              \
+            case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2>), grid, block, 0, s, __VA_ARGS__); break;              \
+            case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1>), grid, block, 0, s, __VA_ARGS__); break;              \
+            default:  hipLaunchKernelGGL((KERNEL<32, 64, 2>), grid, block, 0, s, __VA_ARGS__); break;              \
+        }                                                                                                          \
+    } while (0)
+
+extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
+                          int64_t out_stride, void* stream) {
+    int rc = check_mlp("us_mlp_fwd", d); if (rc) return rc;
+    US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
+    US_REQUIRE(out_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_fwd: out_stride %lld < n_out", (long long)out_stride);
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int pts = d->width == 64 ? 32 : 64;
+    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 2048) nb = 2048;
+    dim3 grid((unsigned)nb), block(MLP_THREADS);
+    MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride);
+    US_CHECK_LAUNCH("us_mlp_fwd");
+    return US_OK;
+}
+
+extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out,
+                          int64_t out_stride, const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din,
+                          float* grad_params, void* stream) {
+    int rc = check_mlp("us_mlp_bwd", d); if (rc) return rc;
+    US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
+    US_REQUIRE(out_stride >= (int64_t)d->n_out && dout_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_bwd: stride < n_out");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    if (!dL_din && !grad_params) return US_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int pts = d->width == 64 ? 32 : 64;
+    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 512) nb = 512;
+    dim3 grid((unsigned)nb), block(MLP_THREADS);
+    MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
+                 dout_stride, n, dL_din, grad_params);
+    US_CHECK_LAUNCH("us_mlp_bwd");
+    return US_OK;
+}

@@ -1,0 +1,610 @@
+// render.hip -- ray sampling, point generation, SDF->alpha compositing, masked losses and Adam for gfx950.
+//
+// Replaces the ATen op chains of reference src/utils/Renderer.py:81-101,132-158, src/common.py:152-166,
+// src/Mapper.py:141-175,411-445 and src/Tracker.py:113-147,206-242.  Each per-ray quantity is produced by ONE
+// 64-lane wavefront (lane = sample, DPP-lowered shuffles for the transmittance product scan and the five
+// reductions), so a ray's samples never round-trip through HBM between the ~30 torch kernels they replace.
+// The file is compiled with -ffp-contract=off: the reference evaluates these expressions as separate fp32 ops,
+// and z_vals is required to match it bit for bit.
+#include "us_common.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0a: depth-guided z sampling (Renderer.py:86-101) + jitter (Renderer.py:42-57)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_z(const float* __restrict__ gt_depth, int64_t n_rays,
+                                                  const float* __restrict__ t_uni, int n_strat,
+                                                  const float* __restrict__ t_surf, int n_imp, float c_free,
+                                                  float surf_off, float surf_span, const float* __restrict__ t_rand,
+                                                  float* __restrict__ z_vals, int rays_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
+    const int S = n_strat + n_imp;
+    const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
+    const int64_t ray = (int64_t)blockIdx.x * rays_per_block + rl;
+    const bool active = rl < rays_per_block && ray < n_rays;
+    float v = 0.0f;
+    if (active) {
+        const float gt = gt_depth[ray];
+        const float fg = c_free * gt, sb = gt - surf_off;
+        int rank;
+        if (j < n_strat) {
+            v = fg * t_uni[j];
+            rank = j;
+            for (int k = 0; k < n_imp; ++k) rank += ((sb + surf_span * t_surf[k]) < v) ? 1 : 0;
+        } else {
+            const int k = j - n_strat;
+            v = sb + surf_span * t_surf[k];
+            rank = k;
+            for (int i = 0; i < n_strat; ++i) rank += ((fg * t_uni[i]) <= v) ? 1 : 0;
+        }
+        zs[rl * S + rank] = v;        // the two ranks form a permutation of 0..S-1 (ties: free samples first)
+    }
+    __syncthreads();
+    if (active) {
+        const float* z = zs + rl * S;
+        float out = z[j];
+        if (t_rand) {
+            const float lower = j > 0 ? 0.5f * (z[j] + z[j - 1]) : z[0];
+            const float upper = j < S - 1 ? 0.5f * (z[j + 1] + z[j]) : z[S - 1];
+            out = lower + (upper - lower) * t_rand[ray * S + j];
+        }
+        z_vals[ray * S + j] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0b: points along rays, normalised to the unit cube (Renderer.py:132-137) and its adjoint
+// ---------------------------------------------------------------------------------------------------------------
+struct Bound3 { float lo[3]; float span[3]; };
+
+__global__ __launch_bounds__(256) void k_ray_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const float* __restrict__ z_vals, Bound3 bd, int64_t n_pts, int S,
+                                                    float* __restrict__ pts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pts; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = i / S;
+        const float z = z_vals[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p = rays_o[ray * 3 + k] + rays_d[ray * 3 + k] * z;
+            pts[i * 3 + k] = (p - bd.lo[k]) / bd.span[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ray_points_bwd(const float* __restrict__ dpts, const float* __restrict__ z_vals,
+                                                        Bound3 bd, int64_t n_rays, int S, float* __restrict__ d_o,
+                                                        float* __restrict__ d_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;                        // wave-uniform
+    float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+    for (int s = lane; s < S; s += 64) {
+        const float z = z_vals[ray * S + s];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gk = dpts[(ray * S + s) * 3 + k] / bd.span[k];
+            so[k] += gk; sd[k] += gk * z;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { so[k] = wave_sum(so[k]); sd[k] = wave_sum(sd[k]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { if (d_o) d_o[ray * 3 + k] = so[k]; if (d_d) d_d[ray * 3 + k] = sd[k]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0c: mapping ray assembly, gather first then rotate (common.py:152-166 rotates the whole pool first)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rays(const float* __restrict__ c2ws, const float* __restrict__ pool_depth,
+                                                     const float* __restrict__ pool_color,
+                                                     const float* __restrict__ pool_dirs, const int64_t* __restrict__ idx,
+                                                     int64_t P, int64_t n_per, int64_t total, float* __restrict__ rays_o,
+                                                     float* __restrict__ rays_d, float* __restrict__ depth,
+                                                     float* __restrict__ color) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / n_per;
+        const int64_t src = f * P + idx[i];
+        const float* M = c2ws + f * 16;
+        const float d0 = pool_dirs[src * 3 + 0], d1 = pool_dirs[src * 3 + 1], d2 = pool_dirs[src * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rays_d[i * 3 + k] = (d0 * M[k * 4 + 0] + d1 * M[k * 4 + 1]) + d2 * M[k * 4 + 2];
+            rays_o[i * 3 + k] = M[k * 4 + 3];
+            color[i * 3 + k] = pool_color[src * 3 + k];
+        }
+        depth[i] = pool_depth[src];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0d: bounding-box pre-filter (Mapper.py:396-402 / Tracker.py:177-184): valid = far_bb >= gt_depth [&& gt_depth > 0]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bbox_filter(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ gt_depth, Bound3 bd, int64_t n_rays,
+                                                     int require_depth, uint8_t* __restrict__ valid, float* __restrict__ far_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += (int64_t)gridDim.x * blockDim.x) {
+        float far = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float o = rays_o[i * 3 + k], d = rays_d[i * 3 + k];
+            const float t0 = (bd.lo[k] - o) / d, t1 = (bd.span[k] - o) / d;     // bd.span carries the UPPER bound here
+            far = fminf(far, fmaxf(t0, t1));
+        }
+        const float gt = gt_depth ? gt_depth[i] : 0.0f;
+        if (valid) valid[i] = (far >= gt) && (!require_depth || gt > 0.0f) ? 1 : 0;
+        if (far_out) far_out[i] = far;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: compositing.  One wavefront per ray; lane l owns samples l*EPL .. l*EPL+EPL-1 (EPL = ceil(S/64) <= 2).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sdf_to_alpha(float sdf, float beta, float& sig, float& e) {
+    // Renderer.py:154-158: 1 - exp(-beta * sigmoid(-sdf * beta))
+    const float u = -sdf * beta;
+    sig = 1.0f / (1.0f + expf(-u));
+    e = expf(-beta * sig);
+    return 1.0f - e;
+}
+
+// exclusive product scan over the 64 lanes
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc *= t;
+    }
+    const float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+// exclusive suffix sum: result(l) = sum_{k>l} v(k)
+__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(inc, o, 64);
+        if (lane + o < 64) inc += t;
+    }
+    const float ex = __shfl_down(inc, 1, 64);
+    return lane == 63 ? 0.0f : ex;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                       const float* __restrict__ beta_p, int64_t n_rays, int S,
+                                                       float* __restrict__ term, float* __restrict__ unc,
+                                                       float* __restrict__ depth, float* __restrict__ rgb,
+                                                       float* __restrict__ dunc, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float beta = beta_p[0];
+    float a[EPL], z[EPL], c[EPL][3], tl[EPL];
+    float tprod = 1.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int s = lane * EPL + e;
+        a[e] = 0.0f; z[e] = 0.0f; c[e][0] = c[e][1] = c[e][2] = 0.0f; tl[e] = 1.0f;
+        if (s < S) {
+            const float4 r = *reinterpret_cast<const float4*>(raw + (ray * S + s) * 4);
+            float sig, ex;
+            a[e] = sdf_to_alpha(r.w, beta, sig, ex);
+            z[e] = z_vals[ray * S + s];
+            c[e][0] = r.x; c[e][1] = r.y; c[e][2] = r.z;
+            tl[e] = (1.0f - a[e]) + 1e-10f;
+        }
+        tprod *= tl[e];
+    }
+    float T = wave_excl_prod(tprod, lane);
+    float w[EPL], s_w = 0.f, s_z = 0.f, s_c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        w[e] = a[e] * T;
+        T *= tl[e];
+        s_w += w[e]; s_z += w[e] * z[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_c[k] += w[e] * c[e][k];
+    }
+    s_w = wave_sum(s_w); s_z = wave_sum(s_z);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_c[k] = wave_sum(s_c[k]);
+    float s_v = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const float dz = s_z - z[e]; s_v += w[e] * (dz * dz); }
+    s_v = wave_sum(s_v);
+    if (weights) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { const int s = lane * EPL + e; if (s < S) weights[ray * S + s] = w[e]; }
+    }
+    if (lane == 0) {
+        term[ray] = s_w;
+        unc[ray] = (1.0f - s_w) * (1.0f - s_w);
+        depth[ray] = s_z;
+        rgb[ray * 3 + 0] = s_c[0]; rgb[ray * 3 + 1] = s_c[1]; rgb[ray * 3 + 2] = s_c[2];
+        dunc[ray] = sqrtf(s_v);
+    }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                       const float* __restrict__ beta_p, int64_t n_rays, int S,
+                                                       const float* __restrict__ g_term, const float* __restrict__ g_unc,
+                                                       const float* __restrict__ g_depth, const float* __restrict__ g_rgb,
+                                                       const float* __restrict__ g_dunc, const float* __restrict__ g_sdf,
+                                                       float* __restrict__ d_raw, float* __restrict__ d_beta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float beta = beta_p[0];
+    float a[EPL], z[EPL], c[EPL][3], tl[EPL], sg[EPL], ex[EPL], sdf[EPL];
+    float tprod = 1.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int s = lane * EPL + e;
+        a[e] = 0.f; z[e] = 0.f; c[e][0] = c[e][1] = c[e][2] = 0.f; tl[e] = 1.0f; sg[e] = 0.f; ex[e] = 0.f; sdf[e] = 0.f;
+        if (s < S) {
+            const float4 r = *reinterpret_cast<const float4*>(raw + (ray * S + s) * 4);
+            sdf[e] = r.w;
+            a[e] = sdf_to_alpha(r.w, beta, sg[e], ex[e]);
+            z[e] = z_vals[ray * S + s];
+            c[e][0] = r.x; c[e][1] = r.y; c[e][2] = r.z;
+            tl[e] = (1.0f - a[e]) + 1e-10f;
+        }
+        tprod *= tl[e];
+    }
+    float T0 = wave_excl_prod(tprod, lane);
+    float T[EPL], w[EPL], s_w = 0.f, s_z = 0.f;
+    {
+        float Tr = T0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { T[e] = Tr; w[e] = a[e] * Tr; Tr *= tl[e]; s_w += w[e]; s_z += w[e] * z[e]; }
+    }
+    s_w = wave_sum(s_w); s_z = wave_sum(s_z);
+    const float gt_ = g_term ? g_term[ray] : 0.f, gu = g_unc ? g_unc[ray] : 0.f;
+    const float gdu = g_dunc ? g_dunc[ray] : 0.f;
+    float gd = g_depth ? g_depth[ray] : 0.f;
+    float gc[3] = {0.f, 0.f, 0.f};
+    if (g_rgb) { gc[0] = g_rgb[ray * 3]; gc[1] = g_rgb[ray * 3 + 1]; gc[2] = g_rgb[ray * 3 + 2]; }
+    float kv = 0.f;                                  // g_dunc / (2 dunc): derivative of sqrt(V)
+    if (gdu != 0.f) {
+        float s_v = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { const float dz = s_z - z[e]; s_v += w[e] * (dz * dz); }
+        s_v = wave_sum(s_v);
+        kv = gdu / (2.0f * sqrtf(s_v));
+        gd += kv * 2.0f * s_z * (s_w - 1.0f);        // dV/d depth = 2 depth (sum w - 1)
+    }
+    const float base = gt_ - 2.0f * (1.0f - s_w) * gu;
+    float G[EPL], Gw_local = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const float dz = s_z - z[e];
+        G[e] = base + gd * z[e] + (gc[0] * c[e][0] + gc[1] * c[e][1] + gc[2] * c[e][2]) + kv * (dz * dz);
+        Gw_local += G[e] * w[e];
+    }
+    // suffix sums of G*w strictly after each element
+    const float after_lane = wave_excl_suffix_sum(Gw_local, lane);
+    float dbeta_local = 0.f;
+    float run = after_lane;                          // sum over elements after the current one (filled backwards)
+#pragma unroll
+    for (int e = EPL - 1; e >= 0; --e) {
+        const int s = lane * EPL + e;
+        const float da = G[e] * T[e] - run / tl[e];
+        run += G[e] * w[e];
+        if (s < S) {
+            // a = 1 - exp(-beta*sig), sig = sigmoid(-beta*sdf)
+            const float dsig = sg[e] * (1.0f - sg[e]);
+            const float da_dsdf = -(beta * beta) * ex[e] * dsig;
+            const float da_dbeta = ex[e] * (sg[e] - beta * sdf[e] * dsig);
+            float4 o;
+            o.x = gc[0] * w[e]; o.y = gc[1] * w[e]; o.z = gc[2] * w[e];
+            o.w = da * da_dsdf + (g_sdf ? g_sdf[ray * S + s] : 0.f);
+            *reinterpret_cast<float4*>(d_raw + (ray * S + s) * 4) = o;
+            dbeta_local += da * da_dbeta;
+        }
+    }
+    if (d_beta) {
+        dbeta_local = wave_sum(dbeta_local);
+        if (lane == 0 && dbeta_local != 0.f) atomicAdd(d_beta, dbeta_local);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: masked losses.  Phase 1: per-ray partial sums/counts -> fixed-order reduction.  Phase 2: gradients.
+// ---------------------------------------------------------------------------------------------------------------
+struct RayGate { bool sdf_depth; bool color; };
+
+__device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float unc, const float* median) {
+    RayGate g; g.sdf_depth = true; g.color = true;
+    const bool alpha_mask = (1.0f - unc) > 0.99f;                       // Mapper.py:414-415 / Tracker.py:210-211
+    if (mode == US_LOSS_MAP_ORIGINAL) {
+        g.sdf_depth = (gt > 0.0f) && alpha_mask;                        // Mapper.py:417-419; colour uses all rays (:427)
+    } else if (mode == US_LOSS_TRK_ORIGINAL) {
+        const float err = fabsf(gt - d);
+        g.sdf_depth = (err < 10.0f * median[0]) && alpha_mask;          // Tracker.py:214-218
+        g.color = g.sdf_depth;                                          // Tracker.py:225
+    }
+    return g;
+}
+
+#define LOSS_NSTAT 10
+__global__ __launch_bounds__(256) void k_loss_partials(int mode, const float* __restrict__ sdf_p, int64_t sdf_stride,
+                                                       const uint8_t* __restrict__ valid,
+                                                       const float* __restrict__ z_vals, const float* __restrict__ gt_depth,
+                                                       const float* __restrict__ gt_color, const float* __restrict__ depth,
+                                                       const float* __restrict__ rgb, const float* __restrict__ unc,
+                                                       const float* __restrict__ median, int64_t n_rays, int S, float tr,
+                                                       float tr04, float* __restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float gt = gt_depth[ray], d = depth[ray];
+    RayGate gate = ray_gate(mode, gt, d, unc[ray], median);
+    if (valid && !valid[ray]) { gate.sdf_depth = false; gate.color = false; }
+    float s[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f};
+    if (gate.sdf_depth) {
+        for (int k = lane; k < S; k += 64) {
+            const float z = z_vals[ray * S + k], sdf = sdf_p[(ray * S + k) * sdf_stride];
+            const bool front = z < (gt - tr), back = z > (gt + tr);
+            const bool center = (z > (gt - tr04)) && (z < (gt + tr04));
+            if (front) { const float r = sdf - 1.0f; s[0] += r * r; n[0] += 1.f; }
+            else if (center) { const float r = (z + sdf * tr) - gt; s[1] += r * r; n[1] += 1.f; }   // front & center are disjoint
+            else if (!back) { const float r = (z + sdf * tr) - gt; s[2] += r * r; n[2] += 1.f; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s[k] = wave_sum(s[k]); n[k] = wave_sum(n[k]); }
+    if (lane == 0) {
+        float* p = partials + ray * LOSS_NSTAT;
+        p[0] = s[0]; p[1] = s[1]; p[2] = s[2]; p[5] = n[0]; p[6] = n[1]; p[7] = n[2];
+        float cs = 0.f;
+        if (gate.color) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float r = gt_color[ray * 3 + k] - rgb[ray * 3 + k]; cs += r * r; }
+        }
+        p[3] = cs; p[8] = gate.color ? 3.f : 0.f;
+        const float r = gt - d;
+        p[4] = gate.sdf_depth ? r * r : 0.f; p[9] = gate.sdf_depth ? 1.f : 0.f;
+    }
+}
+
+// one workgroup, fixed summation order -> bitwise reproducible statistics
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ partials, int64_t n_rays,
+                                                      float* __restrict__ stats) {
+    __shared__ double sh[1024];
+    for (int k = 0; k < LOSS_NSTAT; ++k) {
+        double acc = 0.0;
+        for (int64_t r = threadIdx.x; r < n_rays; r += 1024) acc += (double)partials[r * LOSS_NSTAT + k];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) stats[k] = (float)sh[0];
+        __syncthreads();
+    }
+}
+
+struct LossW { float w[5]; };
+
+__global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __restrict__ sdf_p, int64_t sdf_stride,
+                                                   const uint8_t* __restrict__ valid, const float* __restrict__ z_vals,
+                                                   const float* __restrict__ gt_depth, const float* __restrict__ gt_color,
+                                                   const float* __restrict__ depth, const float* __restrict__ rgb,
+                                                   const float* __restrict__ unc, const float* __restrict__ median,
+                                                   int64_t n_rays, int S, float tr, float tr04, LossW lw,
+                                                   const float* __restrict__ stats, float* __restrict__ g_sdf,
+                                                   float* __restrict__ g_depth, float* __restrict__ g_rgb,
+                                                   float* __restrict__ loss_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
+        float l = 0.f;
+        for (int k = 0; k < 5; ++k) l += lw.w[k] * (stats[k] / stats[5 + k]);      // 0/0 -> NaN like torch.mean([])
+        loss_out[0] = l;
+    }
+    if (ray >= n_rays) return;
+    const float gt = gt_depth[ray], d = depth[ray];
+    RayGate gate = ray_gate(mode, gt, d, unc[ray], median);
+    if (valid && !valid[ray]) { gate.sdf_depth = false; gate.color = false; }
+    const float k_fs = 2.0f * lw.w[0] / stats[5], k_ce = 2.0f * lw.w[1] / stats[6], k_ta = 2.0f * lw.w[2] / stats[7];
+    for (int k = lane; k < S; k += 64) {
+        float gval = 0.f;
+        if (gate.sdf_depth) {
+            const float z = z_vals[ray * S + k], sdf = sdf_p[(ray * S + k) * sdf_stride];
+            const bool front = z < (gt - tr), back = z > (gt + tr);
+            const bool center = (z > (gt - tr04)) && (z < (gt + tr04));
+            if (front) gval = k_fs * (sdf - 1.0f);
+            else if (center) gval = k_ce * ((z + sdf * tr) - gt) * tr;
+            else if (!back) gval = k_ta * ((z + sdf * tr) - gt) * tr;
+        }
+        g_sdf[ray * S + k] = gval;
+    }
+    if (lane == 0) {
+        g_depth[ray] = gate.sdf_depth ? (2.0f * lw.w[4] / stats[9]) * (d - gt) : 0.f;
+        const float kc = 2.0f * lw.w[3] / stats[8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_rgb[ray * 3 + k] = gate.color ? kc * (rgb[ray * 3 + k] - gt_color[ray * 3 + k]) : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam op order: lerp, mul+addcmul, sqrt/div/add, addcdiv)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float one_minus_b1, float b2,
+                                              float one_minus_b2, float bc2_sqrt, float eps, float step_size) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (one_minus_b2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (-step_size) * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+static unsigned grid_1d(int64_t n, int threads, int cap) {
+    int64_t b = us_cdiv(n, threads);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int us_sample_z(const float* gt_depth, int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf,
+                           int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand, float* z_vals,
+                           void* stream) {
+    US_REQUIRE(gt_depth && t_uni && t_surf && z_vals, US_ERR_NULL, "us_sample_z: NULL pointer");
+    const int S = n_strat + n_imp;
+    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_sample_z: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    const int rpb = 256 / S;
+    hipLaunchKernelGGL(k_sample_z, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float),
+                       (hipStream_t)stream, gt_depth, n_rays, t_uni, n_strat, t_surf, n_imp, c_free, surf_off, surf_span,
+                       t_rand, z_vals, rpb);
+    US_CHECK_LAUNCH("us_sample_z");
+    return US_OK;
+}
+
+static Bound3 make_bound(const float* b) {
+    Bound3 bd;
+    for (int k = 0; k < 3; ++k) { bd.lo[k] = b[k]; bd.span[k] = b[3 + k] - b[k]; }
+    return bd;
+}
+
+extern "C" int us_bbox_filter(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
+                              int64_t n_rays, int require_depth, uint8_t* valid, float* far_out, void* stream) {
+    US_REQUIRE(rays_o && rays_d && bound_host && (valid || far_out), US_ERR_NULL, "us_bbox_filter: NULL pointer");
+    US_REQUIRE(!valid || gt_depth, US_ERR_NULL, "us_bbox_filter: valid[] needs gt_depth");
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    Bound3 bd;                                       // lo and HI (not span): the reference divides (bound - o) / d
+    for (int k = 0; k < 3; ++k) { bd.lo[k] = bound_host[k]; bd.span[k] = bound_host[3 + k]; }
+    hipLaunchKernelGGL(k_bbox_filter, dim3(grid_1d(n_rays, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth,
+                       bd, n_rays, require_depth, valid, far_out);
+    US_CHECK_LAUNCH("us_bbox_filter");
+    return US_OK;
+}
+
+extern "C" int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, const float* bound_host,
+                             int64_t n_rays, int n_samples, float* pts, void* stream) {
+    US_REQUIRE(rays_o && rays_d && z_vals && bound_host && pts, US_ERR_NULL, "us_ray_points: NULL pointer");
+    US_REQUIRE(n_samples >= 1, US_ERR_SHAPE, "us_ray_points: n_samples %d", n_samples);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    const int64_t n = n_rays * n_samples;
+    hipLaunchKernelGGL(k_ray_points, dim3(grid_1d(n, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_vals,
+                       make_bound(bound_host), n, n_samples, pts);
+    US_CHECK_LAUNCH("us_ray_points");
+    return US_OK;
+}
+
+extern "C" int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
+                                 int n_samples, float* dL_do, float* dL_dd, void* stream) {
+    US_REQUIRE(dL_dpts && z_vals && bound_host, US_ERR_NULL, "us_ray_points_bwd: NULL pointer");
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    hipLaunchKernelGGL(k_ray_points_bwd, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dpts, z_vals,
+                       make_bound(bound_host), n_rays, n_samples, dL_do, dL_dd);
+    US_CHECK_LAUNCH("us_ray_points_bwd");
+    return US_OK;
+}
+
+extern "C" int us_gather_rays(const float* c2ws, const float* pool_depth, const float* pool_color, const float* pool_dirs,
+                              const int64_t* idx, int b, int64_t pool_size, int64_t n_per_frame, float* rays_o,
+                              float* rays_d, float* depth, float* color, void* stream) {
+    US_REQUIRE(c2ws && pool_depth && pool_color && pool_dirs && idx && rays_o && rays_d && depth && color, US_ERR_NULL,
+               "us_gather_rays: NULL pointer");
+    US_REQUIRE(b >= 1 && pool_size >= 1 && n_per_frame >= 0, US_ERR_SHAPE, "us_gather_rays: bad shape");
+    const int64_t total = (int64_t)b * n_per_frame;
+    if (total == 0) return US_OK;
+    hipLaunchKernelGGL(k_gather_rays, dim3(grid_1d(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, c2ws, pool_depth,
+                       pool_color, pool_dirs, idx, pool_size, n_per_frame, total, rays_o, rays_d, depth, color);
+    US_CHECK_LAUNCH("us_gather_rays");
+    return US_OK;
+}
+
+extern "C" int us_composite_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
+                                float* term, float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* weights,
+                                void* stream) {
+    US_REQUIRE(raw && z_vals && beta && term && pixel_unc && depth && rgb && depth_unc, US_ERR_NULL, "us_composite_fwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_fwd: n_samples %d not in 1..128", n_samples);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights);
+    else
+        hipLaunchKernelGGL((k_composite_fwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights);
+    US_CHECK_LAUNCH("us_composite_fwd");
+    return US_OK;
+}
+
+extern "C" int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
+                                const float* g_term, const float* g_unc, const float* g_depth, const float* g_rgb,
+                                const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, void* stream) {
+    US_REQUIRE(raw && z_vals && beta && d_raw, US_ERR_NULL, "us_composite_bwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_bwd: n_samples %d not in 1..128", n_samples);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta);
+    else
+        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta);
+    US_CHECK_LAUNCH("us_composite_bwd");
+    return US_OK;
+}
+
+extern "C" size_t us_loss_partials_size(int64_t n_rays) { return n_rays > 0 ? (size_t)n_rays * LOSS_NSTAT : 0; }
+
+static int check_loss_mode(const char* fn, int mode, const float* median) {
+    US_REQUIRE(mode >= US_LOSS_MAP_ORIGINAL && mode <= US_LOSS_TRK_NOMASK, US_ERR_CONFIG, "%s: mode %d", fn, mode);
+    US_REQUIRE(mode != US_LOSS_TRK_ORIGINAL || median, US_ERR_NULL, "%s: tracking 'original' mask needs the median pointer", fn);
+    return US_OK;
+}
+
+extern "C" int us_loss_stats(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* valid, const float* z_vals,
+                             const float* gt_depth, const float* gt_color,
+                             const float* depth, const float* rgb, const float* pixel_unc, const float* median,
+                             int64_t n_rays, int n_samples, double truncation, float* partials, float* stats, void* stream) {
+    int rc = check_loss_mode("us_loss_stats", mode, median); if (rc) return rc;
+    US_REQUIRE(sdf && z_vals && gt_depth && gt_color && depth && rgb && pixel_unc && partials && stats, US_ERR_NULL, "us_loss_stats: NULL pointer");
+    US_REQUIRE(sdf_stride >= 1, US_ERR_SHAPE, "us_loss_stats: sdf_stride");
+    US_REQUIRE(n_rays >= 1 && n_samples >= 1, US_ERR_SHAPE, "us_loss_stats: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_partials, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, s, mode, sdf, sdf_stride, valid, z_vals, gt_depth, gt_color,
+                       depth, rgb, pixel_unc, median, n_rays, n_samples, (float)truncation, (float)(0.4 * truncation), partials);
+    US_CHECK_LAUNCH("us_loss_stats(partials)");
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, partials, n_rays, stats);
+    US_CHECK_LAUNCH("us_loss_stats(reduce)");
+    return US_OK;
+}
+
+extern "C" int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* valid, const float* z_vals,
+                            const float* gt_depth, const float* gt_color,
+                            const float* depth, const float* rgb, const float* pixel_unc, const float* median,
+                            int64_t n_rays, int n_samples, double truncation, const float* w_host5, const float* stats,
+                            float* g_sdf, float* g_depth, float* g_rgb, float* loss_out, void* stream) {
+    int rc = check_loss_mode("us_loss_grad", mode, median); if (rc) return rc;
+    US_REQUIRE(sdf && z_vals && gt_depth && gt_color && depth && rgb && pixel_unc && w_host5 && stats && g_sdf && g_depth && g_rgb,
+               US_ERR_NULL, "us_loss_grad: NULL pointer");
+    US_REQUIRE(n_rays >= 1 && n_samples >= 1, US_ERR_SHAPE, "us_loss_grad: empty batch");
+    LossW lw; for (int k = 0; k < 5; ++k) lw.w[k] = w_host5[k];
+    hipLaunchKernelGGL(k_loss_grad, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, mode, sdf, sdf_stride, valid, z_vals,
+                       gt_depth, gt_color, depth, rgb, pixel_unc, median, n_rays, n_samples, (float)truncation,
+                       (float)(0.4 * truncation), lw, stats, g_sdf, g_depth, g_rgb, loss_out);
+    US_CHECK_LAUNCH("us_loss_grad");
+    return US_OK;
+}
+
+extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                            double eps, int step, void* stream) {
+    US_REQUIRE(p && g && m && v, US_ERR_NULL, "us_adam_step: NULL pointer");
+    US_REQUIRE(step >= 1, US_ERR_SHAPE, "us_adam_step: step %d (1-based)", step);
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
+    US_CHECK_LAUNCH("us_adam_step");
+    return US_OK;
+}

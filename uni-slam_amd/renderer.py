@@ -1,0 +1,185 @@
+"""
+Renderer -- API of reference src/utils/Renderer.py (class Renderer, :21-223) on the HIP kernels of csrc/render.hip:
+depth-guided z sampling + jitter (us_sample_z), points in the unit cube (us_ray_points), SDF->alpha compositing
+with its five per-ray reductions (us_composite_fwd/bwd).  render_batch_ray keeps the reference's argument order
+(rays_d BEFORE rays_o) and returns the same 7-tuple.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .common import get_rays, sample_pdf, normalize_3d_coordinate, bbox_far, bound_host
+
+
+class _RayPointsFn(torch.autograd.Function):
+    """pts[R,S,3] = ((o + d z) - lo) / (hi - lo)   (Renderer.py:132-137); z carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z_vals, bhost):
+        o, d, z = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(z_vals)
+        R, S = z.shape
+        pts = torch.empty((R, S, 3), dtype=torch.float32, device=z.device)
+        L.check(L.lib().us_ray_points(L.ptr(o), L.ptr(d), L.ptr(z), bhost, R, S, L.ptr(pts), L.stream()), "us_ray_points")
+        ctx.bhost = bhost
+        ctx.save_for_backward(z)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        R, S = z.shape
+        g = L.f32(g)
+        go = torch.empty((R, 3), dtype=torch.float32, device=z.device) if ctx.needs_input_grad[0] else None
+        gd = torch.empty((R, 3), dtype=torch.float32, device=z.device) if ctx.needs_input_grad[1] else None
+        if go is not None or gd is not None:
+            L.check(L.lib().us_ray_points_bwd(L.ptr(g), L.ptr(z), ctx.bhost, R, S, L.ptr(go), L.ptr(gd), L.stream()),
+                    "us_ray_points_bwd")
+        return go, gd, None, None
+
+
+class _CompositeFn(torch.autograd.Function):
+    """raw[R,S,4], z[R,S], beta[1] -> term, pixel_unc, depth, rgb, depth_unc   (Renderer.py:140-150)"""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, beta):
+        raw, z, b = L.f32(raw.detach()), L.f32(z_vals), L.f32(beta.detach()).reshape(1)
+        R, S = z.shape
+        dev = z.device
+        term = torch.empty(R, device=dev); unc = torch.empty(R, device=dev); depth = torch.empty(R, device=dev)
+        rgb = torch.empty((R, 3), device=dev); dunc = torch.empty(R, device=dev)
+        L.check(L.lib().us_composite_fwd(L.ptr(raw), L.ptr(z), L.ptr(b), R, S, L.ptr(term), L.ptr(unc), L.ptr(depth),
+                                         L.ptr(rgb), L.ptr(dunc), None, L.stream()), "us_composite_fwd")
+        ctx.save_for_backward(raw, z, b)
+        return term, unc, depth, rgb, dunc
+
+    @staticmethod
+    def backward(ctx, g_term, g_unc, g_depth, g_rgb, g_dunc):
+        raw, z, b = ctx.saved_tensors
+        R, S = z.shape
+        c = lambda t: None if t is None else L.f32(t)
+        g_term, g_unc, g_depth, g_rgb, g_dunc = c(g_term), c(g_unc), c(g_depth), c(g_rgb), c(g_dunc)
+        d_raw = torch.empty_like(raw)
+        d_beta = torch.zeros(1, device=z.device) if ctx.needs_input_grad[2] else None
+        L.check(L.lib().us_composite_bwd(L.ptr(raw), L.ptr(z), L.ptr(b), R, S, L.ptr(g_term), L.ptr(g_unc),
+                                         L.ptr(g_depth), L.ptr(g_rgb), L.ptr(g_dunc), None, L.ptr(d_raw),
+                                         L.ptr(d_beta), L.stream()), "us_composite_bwd")
+        return d_raw, None, d_beta
+
+
+def sample_z(gt_depth, truncation, t_uni, t_surf, t_rand=None):
+    """Renderer.py:86-101 for rays with depth > 0: z_vals [R, n_strat+n_imp] (no gradient)."""
+    gt = L.f32(gt_depth.detach()).reshape(-1)
+    R = gt.shape[0]
+    S = t_uni.shape[0] + t_surf.shape[0]
+    z = torch.empty((R, S), dtype=torch.float32, device=gt.device)
+    if R == 0:
+        return z
+    tr = None if t_rand is None else L.f32(t_rand)
+    L.check(L.lib().us_sample_z(L.ptr(gt), R, L.ptr(t_uni), t_uni.shape[0], L.ptr(t_surf), t_surf.shape[0],
+                                ctypes.c_float(1.2), ctypes.c_float(1.5 * truncation), ctypes.c_float(3 * truncation),
+                                L.ptr(tr), L.ptr(z), L.stream()), "us_sample_z")
+    return z
+
+
+class Renderer(object):
+    """
+    Args (same as the reference): cfg (dict), unislam (object with bound, device, H, W, fx, fy, cx, cy),
+    ray_batch_size (int).
+    """
+
+    def __init__(self, cfg, unislam, ray_batch_size=10000):
+        self.ray_batch_size = ray_batch_size
+        self.cfg = cfg
+        self.perturb = cfg['rendering']['perturb']
+        self.n_stratified = cfg['rendering']['n_stratified']
+        self.n_importance = cfg['rendering']['n_importance']
+        self.scale = cfg['scale']
+        self.device = unislam.device
+        self.bound = unislam.bound.to(unislam.device, non_blocking=True)
+        self._bhost = bound_host(unislam.bound)
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = unislam.H, unislam.W, unislam.fx, unislam.fy, unislam.cx, unislam.cy
+        # torch.linspace evaluated once on the CPU (the values the reference's CPU/CUDA linspace produce) and kept
+        # on the device: Renderer.py:83-84 rebuilds them every call
+        self._t_uni = torch.linspace(0., 1., steps=self.n_stratified).to(self.device)
+        self._t_surf = torch.linspace(0., 1., steps=self.n_importance).to(self.device)
+
+    def perturbation(self, z_vals):
+        """Renderer.py:42-57 (torch ops; the depth-guided path applies the jitter inside us_sample_z)."""
+        mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        t_rand = torch.rand(z_vals.shape, device=z_vals.device)
+        return lower + (upper - lower) * t_rand
+
+    def sdf2alpha(self, sdf, beta=10):
+        """Renderer.py:154-158"""
+        return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))
+
+    def _zero_depth_z(self, scene_rep, decoders, rays_o_uni, rays_d_uni, device):
+        """Renderer.py:104-130: coarse uniform pass + sample_pdf for rays without a depth measurement (no grad)."""
+        n_stratified, n_importance = self.n_stratified, self.n_importance
+        with torch.no_grad():
+            far_bb = bbox_far(rays_o_uni, rays_d_uni, self.bound).unsqueeze(-1)
+            far_bb += 0.01
+            z_vals_uni = 0.0 * (1. - self._t_uni) + far_bb * self._t_uni
+            if self.perturb:
+                z_vals_uni = self.perturbation(z_vals_uni)
+            pts_uni = rays_o_uni.unsqueeze(1) + rays_d_uni.unsqueeze(1) * z_vals_uni.unsqueeze(-1)
+            pts_uni_nor = normalize_3d_coordinate(pts_uni.clone(), self.bound)
+            sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(*pts_uni.shape[0:2])
+            alpha_uni = self.sdf2alpha(sdf_uni, decoders.beta)
+            weights_uni = alpha_uni * torch.cumprod(torch.cat([torch.ones((alpha_uni.shape[0], 1), device=device),
+                                                               (1. - alpha_uni + 1e-10)], -1), -1)[:, :-1]
+            z_vals_uni_mid = .5 * (z_vals_uni[..., 1:] + z_vals_uni[..., :-1])
+            z_samples_uni = sample_pdf(z_vals_uni_mid, weights_uni[..., 1:-1], n_importance, det=False, device=device)
+            z_vals_uni, _ = torch.sort(torch.cat([z_vals_uni, z_samples_uni], -1), -1)
+        return z_vals_uni
+
+    def render_batch_ray(self, scene_rep, decoders, rays_d, rays_o, device, truncation, gt_depth=None, t_rand=None):
+        """
+        Renderer.py:59-152.  Returns (termination_prob, pixel_unc, rendered_depth, rendered_rgb, sdf[R,S],
+        z_vals[R,S], rendered_depth_uncertainty).  `t_rand` ([R_with_depth, S], optional) replaces the
+        torch.rand draw of the jitter (parity tests); otherwise it is drawn on the device.
+        """
+        n_rays = rays_o.shape[0]
+        S = self.n_stratified + self.n_importance
+        gt_depth = gt_depth.reshape(-1, 1)
+        gt_mask = (gt_depth > 0).squeeze(-1)
+        all_depth = bool(gt_mask.all())                      # the reference synchronises here too (Renderer.py:104)
+        if all_depth:
+            if self.perturb and t_rand is None:
+                t_rand = torch.rand((n_rays, S), device=device)
+            z_vals = sample_z(gt_depth, truncation, self._t_uni, self._t_surf, t_rand if self.perturb else None)
+        else:
+            z_vals = torch.empty([n_rays, S], device=device)
+            gt_nonzero = gt_depth[gt_mask]
+            if self.perturb and t_rand is None:
+                t_rand = torch.rand((gt_nonzero.shape[0], S), device=device)
+            z_vals[gt_mask] = sample_z(gt_nonzero, truncation, self._t_uni, self._t_surf, t_rand if self.perturb else None)
+            z_vals[~gt_mask] = self._zero_depth_z(scene_rep, decoders, rays_o[~gt_mask].detach(),
+                                                  rays_d[~gt_mask].detach(), device)
+        pts = _RayPointsFn.apply(rays_o, rays_d, z_vals, self._bhost)          # normalised to [0,1] (Renderer.py:137)
+        raw = decoders(pts, scene_rep)
+        beta = decoders.beta if torch.is_tensor(decoders.beta) else torch.tensor([float(decoders.beta)], device=device)
+        term, unc, depth, rgb, dunc = _CompositeFn.apply(raw, z_vals, beta)
+        return term, unc, depth, rgb, raw[..., 3], z_vals, dunc
+
+    def render_img(self, scene_rep, decoders, c2w, truncation, device, gt_depth=None):
+        """Renderer.py:160-223: chunked forward-only render of a whole image."""
+        with torch.no_grad():
+            H, W = self.H, self.W
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            rays_o = rays_o.reshape(-1, 3); rays_d = rays_d.reshape(-1, 3)
+            outs = [[], [], [], [], []]
+            gt_depth = gt_depth.reshape(-1)
+            for i in range(0, rays_d.shape[0], self.ray_batch_size):
+                ret = self.render_batch_ray(scene_rep, decoders, rays_d[i:i + self.ray_batch_size].contiguous(),
+                                            rays_o[i:i + self.ray_batch_size].contiguous(), device, truncation,
+                                            gt_depth=gt_depth[i:i + self.ray_batch_size])
+                term, unc, depth, color, _, _, dunc = ret
+                outs[0].append(term.double()); outs[1].append(unc.double()); outs[2].append(dunc.double())
+                outs[3].append(depth.double()); outs[4].append(color)
+            term, unc, dunc, depth, color = [torch.cat(o, dim=0) for o in outs]
+            return (depth.reshape(H, W), color.reshape(H, W, 3), term.reshape(H, W), unc.reshape(H, W),
+                    dunc.reshape(H, W))
