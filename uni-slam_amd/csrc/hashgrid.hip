@@ -334,9 +334,9 @@ extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const
                                float* dy_dx, int flags, void* stream) {
     const int clamp = flags & US_GRID_CLAMP01;
     int rc = check_desc("us_hashgrid_fwd", d); if (rc) return rc;
-    US_REQUIRE(params && x && out, US_ERR_NULL, "us_hashgrid_fwd: NULL pointer");
     US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_hashgrid_fwd: n < 0");
-    if (n == 0) return US_OK;
+    if (n == 0) return US_OK;                       // empty batches carry NULL data pointers
+    US_REQUIRE(params && x && out, US_ERR_NULL, "us_hashgrid_fwd: NULL pointer");
     const LevelTable t = make_table(d);
     dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -352,8 +352,8 @@ extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const
 extern "C" int us_hashgrid_indices(const us_grid_desc* d, const float* x, int64_t n, uint32_t* idx, int flags, void* stream) {
     const int clamp = flags & US_GRID_CLAMP01;
     int rc = check_desc("us_hashgrid_indices", d); if (rc) return rc;
-    US_REQUIRE(x && idx, US_ERR_NULL, "us_hashgrid_indices: NULL pointer");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(x && idx, US_ERR_NULL, "us_hashgrid_indices: NULL pointer");
     const LevelTable t = make_table(d);
     dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
     hipLaunchKernelGGL(k_indices, grid, block, 0, (hipStream_t)stream, t, d->n_levels, x, n, idx, clamp);
@@ -365,9 +365,9 @@ extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, con
                                       float* grad_params, int mode, int flags, void* stream) {
     const int clamp = flags & US_GRID_CLAMP01;
     int rc = check_desc("us_hashgrid_bwd_params", d); if (rc) return rc;
-    US_REQUIRE(x && dL_dy && grad_params, US_ERR_NULL, "us_hashgrid_bwd_params: NULL pointer");
     US_REQUIRE(mode >= -1 && mode <= 1, US_ERR_CONFIG, "us_hashgrid_bwd_params: mode %d", mode);
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(x && dL_dy && grad_params, US_ERR_NULL, "us_hashgrid_bwd_params: NULL pointer");
     const LevelTable t = make_table(d);
     hipStream_t s = (hipStream_t)stream;
     const uint32_t F = d->n_features, L = d->n_levels;
@@ -417,8 +417,8 @@ extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, con
 
 extern "C" int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t C, float* dL_dx,
                                      void* stream) {
-    US_REQUIRE(dL_dy && dy_dx && dL_dx, US_ERR_NULL, "us_hashgrid_bwd_input: NULL pointer");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(dL_dy && dy_dx && dL_dx, US_ERR_NULL, "us_hashgrid_bwd_input: NULL pointer");
     hipLaunchKernelGGL(k_bwd_input, dim3(point_blocks(n, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, dL_dy, dy_dx, n, C, dL_dx);
     US_CHECK_LAUNCH("us_hashgrid_bwd_input");
     return US_OK;

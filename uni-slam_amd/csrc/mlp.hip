@@ -426,9 +426,9 @@ extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
 extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
                           int64_t out_stride, void* stream) {
     int rc = check_mlp("us_mlp_fwd", d); if (rc) return rc;
-    US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
     US_REQUIRE(out_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_fwd: out_stride %lld < n_out", (long long)out_stride);
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     const int pts = d->width == 64 ? 32 : 64;
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 2048) nb = 2048;
@@ -442,9 +442,9 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
                           int64_t out_stride, const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din,
                           float* grad_params, void* stream) {
     int rc = check_mlp("us_mlp_bwd", d); if (rc) return rc;
-    US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
     US_REQUIRE(out_stride >= (int64_t)d->n_out && dout_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_bwd: stride < n_out");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
     if (!dL_din && !grad_params) return US_OK;
     hipStream_t s = (hipStream_t)stream;
     const int pts = d->width == 64 ? 32 : 64;

@@ -458,10 +458,10 @@ static unsigned grid_1d(int64_t n, int threads, int cap) {
 extern "C" int us_sample_z(const float* gt_depth, int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf,
                            int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand, float* z_vals,
                            void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(gt_depth && t_uni && t_surf && z_vals, US_ERR_NULL, "us_sample_z: NULL pointer");
     const int S = n_strat + n_imp;
     US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_sample_z: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     const int rpb = 256 / S;
     hipLaunchKernelGGL(k_sample_z, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float),
                        (hipStream_t)stream, gt_depth, n_rays, t_uni, n_strat, t_surf, n_imp, c_free, surf_off, surf_span,
@@ -478,9 +478,9 @@ static Bound3 make_bound(const float* b) {
 
 extern "C" int us_bbox_filter(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
                               int64_t n_rays, int require_depth, uint8_t* valid, float* far_out, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(rays_o && rays_d && bound_host && (valid || far_out), US_ERR_NULL, "us_bbox_filter: NULL pointer");
     US_REQUIRE(!valid || gt_depth, US_ERR_NULL, "us_bbox_filter: valid[] needs gt_depth");
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     Bound3 bd;                                       // lo and HI (not span): the reference divides (bound - o) / d
     for (int k = 0; k < 3; ++k) { bd.lo[k] = bound_host[k]; bd.span[k] = bound_host[3 + k]; }
     hipLaunchKernelGGL(k_bbox_filter, dim3(grid_1d(n_rays, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth,
@@ -491,9 +491,9 @@ extern "C" int us_bbox_filter(const float* rays_o, const float* rays_d, const fl
 
 extern "C" int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, const float* bound_host,
                              int64_t n_rays, int n_samples, float* pts, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(rays_o && rays_d && z_vals && bound_host && pts, US_ERR_NULL, "us_ray_points: NULL pointer");
     US_REQUIRE(n_samples >= 1, US_ERR_SHAPE, "us_ray_points: n_samples %d", n_samples);
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     const int64_t n = n_rays * n_samples;
     hipLaunchKernelGGL(k_ray_points, dim3(grid_1d(n, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_vals,
                        make_bound(bound_host), n, n_samples, pts);
@@ -503,8 +503,8 @@ extern "C" int us_ray_points(const float* rays_o, const float* rays_d, const flo
 
 extern "C" int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
                                  int n_samples, float* dL_do, float* dL_dd, void* stream) {
-    US_REQUIRE(dL_dpts && z_vals && bound_host, US_ERR_NULL, "us_ray_points_bwd: NULL pointer");
     if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(dL_dpts && z_vals && bound_host, US_ERR_NULL, "us_ray_points_bwd: NULL pointer");
     hipLaunchKernelGGL(k_ray_points_bwd, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dpts, z_vals,
                        make_bound(bound_host), n_rays, n_samples, dL_do, dL_dd);
     US_CHECK_LAUNCH("us_ray_points_bwd");
@@ -528,9 +528,9 @@ extern "C" int us_gather_rays(const float* c2ws, const float* pool_depth, const 
 extern "C" int us_composite_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
                                 float* term, float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* weights,
                                 void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(raw && z_vals && beta && term && pixel_unc && depth && rgb && depth_unc, US_ERR_NULL, "us_composite_fwd: NULL pointer");
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_fwd: n_samples %d not in 1..128", n_samples);
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     if (n_samples <= 64)
         hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights);
@@ -543,9 +543,9 @@ extern "C" int us_composite_fwd(const float* raw, const float* z_vals, const flo
 extern "C" int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
                                 const float* g_term, const float* g_unc, const float* g_depth, const float* g_rgb,
                                 const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(raw && z_vals && beta && d_raw, US_ERR_NULL, "us_composite_bwd: NULL pointer");
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_bwd: n_samples %d not in 1..128", n_samples);
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     if (n_samples <= 64)
         hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta);
