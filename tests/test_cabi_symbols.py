@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/unislam_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import unislam_amd
+    return unislam_amd
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "unislam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(us_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    names = header_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/unislam_hip.h but not exported"
+    from unislam_amd import _lib
+    assert sorted(_lib.SIGNATURES.keys()) == names            # the ctypes table covers exactly the header
+    assert _lib.lib().us_abi_version() == 1
+
+
+def test_descriptor_and_argument_errors_without_gpu(built):
+    us = built
+    d = us.make_grid_desc(16, 2, 16, 16, 1.2996847159335432)
+    assert d.n_params == 1736800 and list(d.resolution[:16])[-1] == 817
+    with pytest.raises(us.UniSlamHipError):
+        us.make_grid_desc(40, 2, 16, 16, 1.3)                  # too many levels
+    with pytest.raises(us.UniSlamHipError):
+        us.make_grid_desc(16, 3, 16, 16, 1.3)                  # unsupported features per level
+    import torch
+    enc = us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 8,
+                                  "base_resolution": 16, "per_level_scale": 1.5})
+    with pytest.raises(us.UniSlamHipError):
+        enc(torch.rand(5, 3))                                  # CPU tensors are refused: there is no CPU fallback
+    from unislam_amd import _lib
+    assert _lib.lib().us_hashgrid_fwd(None, None, None, 5, None, None, 0, None) == -1   # NULL descriptor -> US_ERR_NULL
+    assert b"NULL" in _lib.lib().us_last_error()
+
+
+def test_descriptor_matches_oracle(built):
+    import unislam_oracle as O
+    for res, l2 in [(816, 16), (816, 19), (456, 16), (744, 16)]:
+        a = built.make_grid_desc(16, 2, l2, 16, O.per_level_scale(res))
+        b = O.make_grid_desc(16, 2, l2, 16, O.per_level_scale(res))
+        assert a.n_params == b.n_params
+        assert list(a.scale[:16]) == list(b.scale[:16]) and list(a.offset[:17]) == list(b.offset[:17])
+
+
+def test_modules_pickle_deepcopy_and_state_dict_keys(built):
+    import copy
+    import pickle
+    import torch
+    us = built
+    cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}}
+    dec = us.Decoders(cfg)
+    assert set(dec.state_dict().keys()) == {"beta", "linears.0.weight", "linears.0.bias", "linears.1.weight", "linears.1.bias",
+                                            "c_linears.0.weight", "c_linears.0.bias", "c_linears.1.weight", "c_linears.1.bias",
+                                            "output_linear.weight", "output_linear.bias", "c_output_linear.weight",
+                                            "c_output_linear.bias"}
+    d2 = pickle.loads(pickle.dumps(dec)); d3 = copy.deepcopy(dec)
+    for a, b, c in zip(dec.parameters(), d2.parameters(), d3.parameters()):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    enc = us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 8,
+                                  "base_resolution": 16, "per_level_scale": 1.5})
+    e2 = pickle.loads(pickle.dumps(enc)); e3 = copy.deepcopy(enc)
+    assert torch.equal(enc.params, e2.params) and torch.equal(enc.params, e3.params) and e2.desc.n_params == enc.desc.n_params
+    packed = us.Decoders.pack_linear_params(dec.linears, dec.output_linear)
+    assert packed.numel() == 32 * 16 + 16 * 16 + 16 * 16 + 16 + 16 + 16

@@ -1,0 +1,129 @@
+"""
+CPU, world_size 2, gloo: the data-parallel orchestration of unislam_amd.dist.dp_iterate (local sums/counts ->
+all-reduce -> backward scaled by GLOBAL counts -> ONE gradient all-reduce(sum) -> Adam) gives the parameters of a
+single process run on the concatenated batch.  The compute engine here is the CPU oracle (test infrastructure)
+behind the same engine protocol MapStep implements on the HIP kernels.
+"""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import unislam_oracle as O
+
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+W = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+WK = ["fs", "center", "tail", "color", "depth"]
+ECFG = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 9, "base_resolution": 16,
+        "per_level_scale": 1.4}
+
+
+class OracleEngine:
+    """engine protocol of unislam_amd.dist on the CPU oracle"""
+
+    def __init__(self):
+        torch.manual_seed(0)
+        self.dec = O.DecodersOracle(c_dim=16)
+        self.es, self.ec = O.HashGridOracle(3, ECFG), O.HashGridOracle(3, ECFG)
+        with torch.no_grad():
+            self.es.params.mul_(3000); self.ec.params.mul_(3000)
+        self.params = list(self.dec.parameters()) + [self.es.params, self.ec.params]
+        self.opt = torch.optim.Adam([{"params": list(self.dec.parameters()), "lr": 0.001},
+                                     {"params": [self.es.params], "lr": 0.05}, {"params": [self.ec.params], "lr": 0.05}])
+        self.stats = torch.zeros(10)
+        self.grad = torch.zeros(sum(p.numel() for p in self.params))
+
+    def forward(self, ro, rd, gd, gc, t_rand):
+        ret = O.render_batch_ray(([self.es], [self.ec]), self.dec, rd, ro, 0.06, gd, BOUND, 32, 8, True, {"z": t_rand})
+        _, unc, depth, color, sdf, z, _ = ret
+        m = (gd > 0) & ((1 - unc.detach()) > 0.99)                       # Mapper.py:414-419
+        front, _, center, tail = O.sdf_loss_masks(z[m], gd[m], 0.06)
+        pred = z[m] + sdf[m] * 0.06
+        g = gd[m][:, None].expand(z[m].shape)
+        sums = [((sdf[m][front] - 1.0) ** 2).sum(), ((pred[center] - g[center]) ** 2).sum(),
+                ((pred[tail] - g[tail]) ** 2).sum(), ((gc - color) ** 2).sum(), ((gd[m] - depth[m]) ** 2).sum()]
+        counts = [front.sum(), center.sum(), tail.sum(), torch.tensor(gc.numel()), m.sum()]
+        self._sums = sums
+        self.stats = torch.stack([s.detach() for s in sums] + [c.float() for c in counts])
+
+    def backward(self):
+        loss_local = sum(W[k] * self._sums[i] / self.stats[5 + i] for i, k in enumerate(WK))   # GLOBAL counts
+        self.opt.zero_grad()
+        loss_local.backward()
+        self.grad = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+        return sum(W[k] * self.stats[i] / self.stats[5 + i] for i, k in enumerate(WK))
+
+    def adam_step(self):
+        o = 0
+        for p in self.params:
+            p.grad = self.grad[o:o + p.numel()].view_as(p).clone(); o += p.numel()
+        self.opt.step()
+
+    def flat(self):
+        return torch.cat([p.detach().reshape(-1) for p in self.params])
+
+
+def make_batch(R, seed):
+    g = torch.Generator().manual_seed(seed)
+    ro = torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05
+    rd = torch.randn(R, 3, generator=g); rd = rd / rd.norm(dim=-1, keepdim=True)
+    gd = torch.rand(R, generator=g) * 2 + 0.4
+    gd[::6] = 30.0                                   # uneven mask counts across the two halves
+    gd[:R // 4] = 0.7
+    return ro, rd, gd, torch.rand(R, 3, generator=g), torch.rand(R, 40, generator=g)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from unislam_amd.dist import dp_iterate, init_from_env, shard_frames
+    r, _, w = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and shard_frames(5, rank, world) == list(range(rank, 5, world))
+    eng = OracleEngine()
+    losses = []
+    for it in range(2):
+        full = make_batch(48, 100 + it)
+        half = tuple(t[rank::world] for t in full)                    # ray slices: frames/rays shard naturally
+        losses.append(float(dp_iterate(eng, half, group=True)))
+    flat = eng.flat()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        assert torch.equal(gathered[0], gathered[1])                  # replicas stay bit-identical
+        np.savez(out_path, flat=flat.numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    from unislam_amd.dist import dp_iterate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r0.npz")
+        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        res = np.load(out)
+    eng = OracleEngine()
+    losses = []
+    for it in range(2):
+        full = make_batch(48, 100 + it)
+        # same ray order as the two slices concatenated does not matter: every term is a sum over rays
+        losses.append(float(dp_iterate(eng, full, group=None)))
+    np.testing.assert_allclose(res["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(res["flat"], eng.flat().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_averaging_local_means_is_not_equivalent():
+    """the naive scheme (each rank normalises by its own counts, gradients averaged) differs: documents why counts travel"""
+    eng = OracleEngine()
+    full = make_batch(48, 100)
+    eng.forward(*full); g_full = None
+    eng.backward(); g_full = eng.grad.clone()
+    gs = []
+    for r in range(2):
+        e = OracleEngine()
+        e.forward(*tuple(t[:12] if r == 0 else t[12:] for t in full)); e.backward(); gs.append(e.grad.clone())
+    naive = 0.5 * (gs[0] + gs[1])
+    assert (naive - g_full).abs().max() > 1e-3 * g_full.abs().max()     # uneven slices: 12 vs 36 rays

@@ -1,0 +1,134 @@
+"""
+GPU: MapStep (the straight-line, autograd-free mapping iteration on preallocated buffers) against the autograd path
+(Renderer + Decoders + losses + torch.optim.Adam) and against the CPU oracle, on identical rays and random draws.
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import unislam_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+W = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+LR = dict(decoders=0.001, sdf_grid=0.05, color_grid=0.05)
+
+
+def _cfg(tcnn, ns=32, ni=8):
+    return {"rendering": {"perturb": True, "n_stratified": ns, "n_importance": ni}, "scale": 1, "grid_mode": "hash_grid",
+            "grid": {"tcnn_network": tcnn}}
+
+
+def _ecfg(log2T):
+    return {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2T,
+            "base_resolution": 16, "per_level_scale": O.per_level_scale(816)}
+
+
+def _scene(us, tcnn, seed=0):
+    torch.manual_seed(seed)
+    dec = us.Decoders(_cfg(tcnn), c_dim=32, truncation=0.06).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+    return dec, es, ec
+
+
+def _rays(R, seed=1, zero_depth=False, outside=False):
+    g = torch.Generator().manual_seed(seed)
+    ro = torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05
+    rd = torch.randn(R, 3, generator=g); rd = rd / rd.norm(dim=-1, keepdim=True)
+    gd = torch.rand(R, generator=g) * 2 + 0.4
+    if zero_depth:
+        gd[::5] = 0.0
+    if outside:
+        gd[1::7] = 50.0                       # beyond the scene box -> dropped by the pre-filter
+    gc = torch.rand(R, 3, generator=g)
+    return ro.to(DEV), rd.to(DEV), gd.to(DEV), gc.to(DEV)
+
+
+@pytest.mark.parametrize("tcnn", [False, True])
+@pytest.mark.parametrize("outside", [False, True])
+def test_mapstep_matches_autograd_path(tcnn, outside):
+    import unislam_amd as us
+    dec, es, ec = _scene(us, tcnn)
+    dec2, es2, ec2 = copy.deepcopy(dec), copy.deepcopy(es), copy.deepcopy(ec)
+    R, S = 300, 40
+    ro, rd, gd, gc = _rays(R, outside=outside)
+    t_rand = torch.rand(R, S, device=DEV)
+    # --- autograd path, reference structure (filter -> render -> loss -> backward -> Adam)
+    rend = us.Renderer(_cfg(tcnn), types.SimpleNamespace(bound=BOUND, device=DEV, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5))
+    opt = torch.optim.Adam([{"params": list(dec2.parameters()), "lr": LR["decoders"]},
+                            {"params": [es2.params], "lr": LR["sdf_grid"]}, {"params": [ec2.params], "lr": LR["color_grid"]}])
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+    for it in range(3):
+        inside = us.common.bbox_filter(ro, rd, gd, BOUND)
+        ret = rend.render_batch_ray(([es2], [ec2]), dec2, rd[inside], ro[inside], DEV, 0.06, gt_depth=gd[inside], t_rand=t_rand[inside])
+        loss_a = us.mapping_loss(ret, gd[inside], gc[inside], 0.06, W)
+        opt.zero_grad(); loss_a.backward()
+        # --- MapStep on the same inputs
+        loss_b = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+        np.testing.assert_allclose(float(loss_b), float(loss_a), rtol=2e-5)
+        ga = torch.cat([p.grad.reshape(-1) for p in (es2.params, ec2.params)])
+        gb = torch.cat([es.params.grad.reshape(-1), ec.params.grad.reshape(-1)])
+        assert torch.allclose(ga, gb, rtol=2e-4, atol=1e-5 * ga.abs().max().item())
+        for (n, pa), (_, pb) in zip(dec2.named_parameters(), dec.named_parameters()):
+            assert torch.allclose(pa.grad, pb.grad, rtol=2e-4, atol=1e-5 * max(1.0, pa.grad.abs().max().item())), n
+        opt.step(); step.adam_step()
+        for (n, pa), (_, pb) in zip(dec2.named_parameters(), dec.named_parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-4, atol=2e-6), n
+        assert torch.allclose(es2.params, es.params, rtol=1e-4, atol=2e-5)
+        assert torch.allclose(ec2.params, ec.params, rtol=1e-4, atol=2e-5)
+    # the adopted modules still serialise with the reference's key names
+    keys = set(dec.state_dict().keys())
+    assert keys == ({"beta", "sdf_decoder.params", "color_decoder.params"} if tcnn else set(O.DecodersOracle().state_dict().keys()))
+
+
+def test_mapstep_zero_depth_rays_and_oracle():
+    import unislam_amd as us
+    dec, es, ec = _scene(us, False, seed=3)
+    R, S = 160, 40
+    ro, rd, gd, gc = _rays(R, seed=4, zero_depth=True)
+    n1, n0 = int((gd > 0).sum()), int((gd <= 0).sum())
+    torch.manual_seed(9)
+    tr1, tr0, u0 = torch.rand(n1, S), torch.rand(n0, 32), torch.rand(n0, 8)
+    # oracle on CPU with the same draws
+    od = O.DecodersOracle(); od.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    oes, oec = O.HashGridOracle(3, _ecfg(14)), O.HashGridOracle(3, _ecfg(15))
+    with torch.no_grad():
+        oes.params.copy_(es.params.cpu()); oec.params.copy_(ec.params.cpu())
+    ret_o = O.render_batch_ray(([oes], [oec]), od, rd.cpu(), ro.cpu(), 0.06, gd.cpu(), BOUND, 32, 8, True,
+                               {"z": tr1, "z_uni": tr0, "u": u0})
+    loss_o = O.mapping_loss(ret_o, gd.cpu(), gc.cpu(), 0.06, W)
+    loss_o.backward()
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=64)        # forces a buffer re-allocation too
+    t_rand = torch.zeros(R, S); t_rand[(gd > 0).cpu()] = tr1
+    draws = [tr0.to(DEV), u0.to(DEV)]
+    real = torch.rand
+    try:
+        torch.rand = lambda *a, **k: draws.pop(0)
+        loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV))
+    finally:
+        torch.rand = real
+    assert not draws
+    z = step.rendered()[5]
+    np.testing.assert_allclose(z.cpu().numpy(), ret_o[5].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loss), float(loss_o), rtol=1e-3)
+    go = oes.params.grad
+    assert torch.allclose(es.params.grad.cpu(), go, rtol=2e-3, atol=1e-4 * go.abs().max().item())
+
+
+def test_mapstep_bench_shape_runs_and_decreases_loss():
+    """BASELINE cfg2 shape: 4096 rays x 64 samples, room0 tables (log2T 16 / 19), 2x32 MLP; 20 iterations."""
+    import unislam_amd as us
+    torch.manual_seed(0)
+    cfg = _cfg(False, 48, 16)
+    dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
+    step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=4096)
+    ro, rd, gd, gc = _rays(4096, seed=2)
+    losses = [float(step.iterate(ro, rd, gd, gc, has_zero_depth=False)) for _ in range(20)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -82,6 +82,44 @@ def sample_z(gt_depth, truncation, t_uni, t_surf, t_rand=None):
     return z
 
 
+def _perturb(z_vals):
+    """Renderer.py:42-57 in torch ops (the depth-guided path applies the jitter inside us_sample_z)."""
+    mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = torch.cat([mids, z_vals[..., -1:]], -1)
+    lower = torch.cat([z_vals[..., :1], mids], -1)
+    t_rand = torch.rand(z_vals.shape, device=z_vals.device)
+    return lower + (upper - lower) * t_rand
+
+
+def sdf2alpha(sdf, beta=10):
+    """Renderer.py:154-158"""
+    return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))
+
+
+def zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, bound, t_uni, n_importance, perturb, device):
+    """
+    Renderer.py:104-130: rays WITHOUT a depth measurement get a coarse uniform pass (SDF grid + SDF decoder on the
+    HIP kernels), then inverse-CDF samples from the resulting weights (common.sample_pdf, pdf left un-normalised
+    as in the reference) merged into the uniform ones.  No gradient.  Returns z [R0, n_strat + n_imp].
+    """
+    with torch.no_grad():
+        far_bb = bbox_far(rays_o_uni, rays_d_uni, bound).unsqueeze(-1)
+        far_bb += 0.01
+        z_vals_uni = 0.0 * (1. - t_uni) + far_bb * t_uni
+        if perturb:
+            z_vals_uni = _perturb(z_vals_uni)
+        pts_uni = rays_o_uni.unsqueeze(1) + rays_d_uni.unsqueeze(1) * z_vals_uni.unsqueeze(-1)
+        pts_uni_nor = normalize_3d_coordinate(pts_uni.clone(), bound)
+        sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(*pts_uni.shape[0:2])
+        alpha_uni = sdf2alpha(sdf_uni, decoders.beta)
+        weights_uni = alpha_uni * torch.cumprod(torch.cat([torch.ones((alpha_uni.shape[0], 1), device=device),
+                                                           (1. - alpha_uni + 1e-10)], -1), -1)[:, :-1]
+        z_vals_uni_mid = .5 * (z_vals_uni[..., 1:] + z_vals_uni[..., :-1])
+        z_samples_uni = sample_pdf(z_vals_uni_mid, weights_uni[..., 1:-1], n_importance, det=False, device=device)
+        z_vals_uni, _ = torch.sort(torch.cat([z_vals_uni, z_samples_uni], -1), -1)
+    return z_vals_uni
+
+
 class Renderer(object):
     """
     Args (same as the reference): cfg (dict), unislam (object with bound, device, H, W, fx, fy, cx, cy),
@@ -105,36 +143,16 @@ class Renderer(object):
         self._t_surf = torch.linspace(0., 1., steps=self.n_importance).to(self.device)
 
     def perturbation(self, z_vals):
-        """Renderer.py:42-57 (torch ops; the depth-guided path applies the jitter inside us_sample_z)."""
-        mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        t_rand = torch.rand(z_vals.shape, device=z_vals.device)
-        return lower + (upper - lower) * t_rand
+        """Renderer.py:42-57"""
+        return _perturb(z_vals)
 
     def sdf2alpha(self, sdf, beta=10):
         """Renderer.py:154-158"""
-        return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))
+        return sdf2alpha(sdf, beta)
 
     def _zero_depth_z(self, scene_rep, decoders, rays_o_uni, rays_d_uni, device):
-        """Renderer.py:104-130: coarse uniform pass + sample_pdf for rays without a depth measurement (no grad)."""
-        n_stratified, n_importance = self.n_stratified, self.n_importance
-        with torch.no_grad():
-            far_bb = bbox_far(rays_o_uni, rays_d_uni, self.bound).unsqueeze(-1)
-            far_bb += 0.01
-            z_vals_uni = 0.0 * (1. - self._t_uni) + far_bb * self._t_uni
-            if self.perturb:
-                z_vals_uni = self.perturbation(z_vals_uni)
-            pts_uni = rays_o_uni.unsqueeze(1) + rays_d_uni.unsqueeze(1) * z_vals_uni.unsqueeze(-1)
-            pts_uni_nor = normalize_3d_coordinate(pts_uni.clone(), self.bound)
-            sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(*pts_uni.shape[0:2])
-            alpha_uni = self.sdf2alpha(sdf_uni, decoders.beta)
-            weights_uni = alpha_uni * torch.cumprod(torch.cat([torch.ones((alpha_uni.shape[0], 1), device=device),
-                                                               (1. - alpha_uni + 1e-10)], -1), -1)[:, :-1]
-            z_vals_uni_mid = .5 * (z_vals_uni[..., 1:] + z_vals_uni[..., :-1])
-            z_samples_uni = sample_pdf(z_vals_uni_mid, weights_uni[..., 1:-1], n_importance, det=False, device=device)
-            z_vals_uni, _ = torch.sort(torch.cat([z_vals_uni, z_samples_uni], -1), -1)
-        return z_vals_uni
+        return zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, self.bound, self._t_uni, self.n_importance,
+                            self.perturb, device)
 
     def render_batch_ray(self, scene_rep, decoders, rays_d, rays_o, device, truncation, gt_depth=None, t_rand=None):
         """

@@ -1,0 +1,236 @@
+"""
+MapStep -- the body of the reference's mapping hot loop (src/Mapper.py:366-445: sample -> render -> masked loss ->
+backward -> Adam) as ONE straight-line sequence of HIP kernel launches on preallocated buffers: no autograd graph,
+no boolean-mask compaction, no host synchronisation.  Results are the same as driving Renderer / Decoders / losses
+through autograd (tests/test_gpu_step.py holds the two paths against each other and against the oracle).
+
+Parameter storage.  All trainable parameters live in ONE flat fp32 buffer
+
+    [ sdf decoder | colour decoder | beta | pad ][ sdf hash table ][ colour hash table ]
+
+laid out so that each decoder segment is directly the flat vector the fused MLP kernel consumes (nn.Linear weights are
+re-pointed to views of it; the last matrix is zero-padded to 16 rows) and each table segment is the encoder's
+`params`.  The modules keep working (state_dict, deepcopy, Tracker reading the shared tables); gradients live in a
+second flat buffer of the same layout, which is what the single RCCL all-reduce per optimiser step moves
+(BASELINE.json north_star), and Adam runs over the three learning-rate groups of Mapper.create_optimizer
+(src/Mapper.py:111-139).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .common import bound_host
+from .decoders import Decoders
+from .hashgrid import HashGridEncoding
+from .network import make_mlp_desc, mlp_n_params
+from .renderer import zero_depth_z
+from .dist import dp_iterate
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class MapStep:
+    def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1):
+        """
+        hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
+        weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
+        lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
+        group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
+        """
+        assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
+        assert isinstance(decoders, Decoders)
+        self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
+        dev = hash_grid_sdf.params.device
+        if dev.type != "cuda":
+            raise L.UniSlamHipError("MapStep needs the model on the GPU")
+        self.device = dev
+        self.S = n_stratified + n_importance
+        self.n_strat, self.n_imp = n_stratified, n_importance
+        self.truncation = float(truncation)
+        self.w5 = L.host_floats([weights["fs"], weights["center"], weights["tail"], weights["color"], weights["depth"]])
+        self.mode = {"original": 0, "no_mask": 1}[mask_mode]
+        self.perturb = perturb
+        self.group = group
+        self.bwd_mode = bwd_mode
+        self.bound = bound.to(dev)
+        self.bhost = bound_host(bound)
+        self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
+        self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
+        self.lr = dict(lr)
+        self._adopt_parameters()
+        self._alloc(max_rays)
+        self.reset_optimizer(1.0)
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _adopt_parameters(self):
+        dec, dev = self.dec, self.device
+        if dec.tcnn_network:
+            self.desc_s, self.desc_c = dec.sdf_decoder.desc, dec.color_decoder.desc
+        else:
+            self.desc_s = make_mlp_desc(dec.c_dim, dec.hidden_size, dec.n_blocks, 1, "tanh", True)
+            self.desc_c = make_mlp_desc(dec.c_dim, dec.hidden_size, dec.n_blocks, 3, "sigmoid", True)
+        n_s, n_c = mlp_n_params(self.desc_s), mlp_n_params(self.desc_c)
+        self.has_beta = isinstance(dec.beta, nn.Parameter)
+        self.o_dec_s, self.o_dec_c, self.o_beta = 0, n_s, n_s + n_c
+        self.n_dec = _align(n_s + n_c + 1)
+        self.o_tab_s = self.n_dec
+        self.o_tab_c = self.o_tab_s + _align(self.es.desc.n_params)
+        self.n_flat = self.o_tab_c + _align(self.ec.desc.n_params)
+        flat = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
+        grad = torch.zeros_like(flat)
+
+        def adopt(p, off, shape=None):
+            n = p.numel()
+            view = flat[off:off + n].view(p.shape if shape is None else shape)
+            view.copy_(p.detach())
+            p.data = view
+            p.grad = grad[off:off + n].view(view.shape)
+
+        if dec.tcnn_network:
+            adopt(dec.sdf_decoder.params, self.o_dec_s)
+            adopt(dec.color_decoder.params, self.o_dec_c)
+        else:
+            for base, hidden, out in ((self.o_dec_s, dec.linears, dec.output_linear),
+                                      (self.o_dec_c, dec.c_linears, dec.c_output_linear)):
+                o = base
+                for l in hidden:
+                    adopt(l.weight, o); o += l.weight.numel()
+                adopt(out.weight, o); o += 16 * out.weight.shape[1]          # rows n_out..15 stay zero (padding)
+                for l in hidden:
+                    adopt(l.bias, o); o += l.bias.numel()
+                adopt(out.bias, o); o += 16
+        if self.has_beta:
+            adopt(dec.beta, self.o_beta)
+        else:
+            flat[self.o_beta] = float(dec.beta)
+        adopt(self.es.params, self.o_tab_s)
+        adopt(self.ec.params, self.o_tab_c)
+        self.flat, self.grad = flat, grad
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+
+    def reset_optimizer(self, lr_factor=1.0):
+        """Mapper.py:358-364: a fresh Adam for every mapped frame (moments and step count restart)."""
+        self.m.zero_(); self.v.zero_()
+        self.opt_step = 0
+        self.lr_factor = float(lr_factor)
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _alloc(self, R):
+        dev, S = self.device, self.S
+        N = R * S
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.max_rays = R
+        self.z, self.pts = f(R, S), f(R, S, 3)
+        self.feat_s, self.feat_c = f(N, 32), f(N, 32)
+        self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
+        self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32)
+        self.term, self.unc, self.depth, self.dunc, self.rgb = f(R), f(R), f(R), f(R), f(R, 3)
+        self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
+        self.partials = f(int(L.lib().us_loss_partials_size(R)))
+        self.stats, self.loss = f(10), f(1)
+        self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------------------------------ the iteration
+    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+        """
+        Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
+        has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
+        knows every ray carries a depth (e.g. checked once per mapped frame on the pixel pools); True -> run the
+        importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
+        """
+        lib, st = L.lib(), L.stream()
+        o, d, gd, gc = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()), L.f32(gt_color.detach())
+        R, S = o.shape[0], self.S
+        if R > self.max_rays:
+            self._alloc(R)
+        N = R * S
+        P = L.ptr
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        # pre-filter against the scene box (Mapper.py:396-406) as a validity flag instead of a compaction
+        L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 0, P(self.valid), None, st), "us_bbox_filter")
+        if self.perturb and t_rand is None:
+            t_rand = torch.rand((R, S), device=self.device)
+        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
+        L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2),
+                                ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, P(self.z), st),
+                "us_sample_z")
+        if has_zero_depth is None or has_zero_depth:
+            m0 = gd <= 0
+            if bool(m0.any()):
+                self.z[:R][m0] = zero_depth_z(([self.es], [self.ec]), self.dec, o[m0], d[m0], self.bound, self.t_uni,
+                                              self.n_imp, self.perturb, self.device)
+        L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
+        fl = self.flat
+        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
+        L.check(lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 1, st), "us_hashgrid_fwd")
+        L.check(lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 1, st), "us_hashgrid_fwd")
+        L.check(lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, st), "us_mlp_fwd")
+        L.check(lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, st), "us_mlp_fwd")
+        beta = off(fl, self.o_beta)
+        L.check(lib.us_composite_fwd(P(self.raw), P(self.z), beta, R, S, P(self.term), P(self.unc), P(self.depth), P(self.rgb),
+                                     P(self.dunc), None, st), "us_composite_fwd")
+        L.check(lib.us_loss_stats(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
+                                  P(self.rgb), P(self.unc), None, R, S, self.truncation, P(self.partials), P(self.stats), st),
+                "us_loss_stats")
+        self._batch = (o, d, gd, gc, R)
+        return self.stats
+
+    def backward(self):
+        """Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad."""
+        lib, st = L.lib(), L.stream()
+        o, d, gd, gc, R = self._batch
+        S, N = self.S, R * self.S
+        P = L.ptr
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        fl = self.flat
+        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
+        beta = off(fl, self.o_beta)
+        L.check(lib.us_loss_grad(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
+                                 P(self.rgb), P(self.unc), None, R, S, self.truncation, self.w5, P(self.stats), P(self.g_sdf),
+                                 P(self.g_depth), P(self.g_rgb), P(self.loss), st), "us_loss_grad")
+        self.grad.zero_()
+        gbeta = off(self.grad, self.o_beta) if self.has_beta else None
+        L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
+                                     P(self.g_sdf), P(self.d_raw), gbeta, st), "us_composite_bwd")
+        L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N,
+                               P(self.d_feat_s), off(self.grad, self.o_dec_s), st), "us_mlp_bwd")
+        L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N,
+                               P(self.d_feat_c), off(self.grad, self.o_dec_c), st), "us_mlp_bwd")
+        L.check(lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s), self.bwd_mode, 1,
+                                           st), "us_hashgrid_bwd_params")
+        L.check(lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c), self.bwd_mode, 1,
+                                           st), "us_hashgrid_bwd_params")
+        self.n_rays = R
+        return self.loss
+
+    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+        """single-process forward + backward (no optimiser step); returns loss[1]"""
+        self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
+        return self.backward()
+
+    def adam_step(self):
+        lib, st = L.lib(), L.stream()
+        self.opt_step += 1
+        f = self.lr_factor
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        for (o, n, lr) in ((0, self.n_dec, self.lr["decoders"] * f),
+                           (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
+                           (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f)):
+            L.check(lib.us_adam_step(off(self.flat, o), off(self.grad, o), off(self.m, o), off(self.v, o), n, lr, 0.9, 0.999,
+                                     1e-8, self.opt_step, st), "us_adam_step")
+
+    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+        """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
+        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth), self.group)
+
+    def rendered(self):
+        """views of the last iteration's per-ray outputs: (term, pixel_unc, depth, rgb, sdf, z_vals, depth_unc)"""
+        R = self.n_rays
+        return (self.term[:R], self.unc[:R], self.depth[:R], self.rgb[:R], self.raw[:R, :, 3], self.z[:R], self.dunc[:R])
