@@ -65,6 +65,9 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
 /* flags for the three grid entry points: US_GRID_CLAMP01 folds decoders.py:101's torch.clamp(p, 0, 1) into the
  * position load (and zeroes dy_dx where the clamp is active, like torch.clamp's backward) */
 #define US_GRID_CLAMP01 1
+/* US_GRID_LEVEL_MAJOR: `out` of us_hashgrid_fwd / `dL_dy` of us_hashgrid_bwd_params are laid out [L][N][F] (each level's
+ * plane contiguous) instead of the torch view [N][L*F]; dy_dx is not affected */
+#define US_GRID_LEVEL_MAJOR 2
 
 /* out[N][C] = encode(x[N][3]);  dy_dx[N][C][3] optional (NULL when positions need no gradient) */
 int us_hashgrid_fwd(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n,
@@ -105,14 +108,19 @@ typedef struct us_mlp_desc {
  * then if has_bias: b0[width], (n_hidden-1) x b[width], blast[16]. */
 size_t us_mlp_n_params(const us_mlp_desc* d);
 
+/* flags: US_MLP_LEVEL_MAJOR -> `in` (and `dL_din`) are the hash grid's level-major [16][N][2] planes (feature k lives in
+ * plane k/2, component k%2) instead of row-major [N][32] */
+#define US_MLP_LEVEL_MAJOR 1
+
 /* out[i*out_stride + o] = act(MLP(in[i][:]))[o], o < n_out   (out_stride lets two decoders write one raw[N][4]) */
 int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n,
-               float* out, int64_t out_stride, void* stream);
+               float* out, int64_t out_stride, int flags, void* stream);
 
 /* dL_din[N][n_in] (nullable) and grad_params += (nullable), from dL_dout[i*dout_stride + o].
  * `out` is the forward result (same layout as in us_mlp_fwd) used for the activation derivative. */
 int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out, int64_t out_stride,
-               const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, void* stream);
+               const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, int flags,
+               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray sampling / points  (replaces src/utils/Renderer.py:81-101,132-137 and src/common.py:152-166 gather+rotate)

@@ -102,6 +102,43 @@ def test_hashgrid_backward(us, mode, log2T, n):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), O.hashgrid_bwd_input(dy, dydx), rtol=2e-4, atol=1e-3)
 
 
+def test_level_major_layout_matches_row_major(us):
+    """the fused path's [L][N][F] planes (US_GRID_LEVEL_MAJOR / US_MLP_LEVEL_MAJOR) against the torch-view layout"""
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n = 3001
+    x = torch.rand((n, 3), device=DEV, generator=g)
+    enc = us.HashGridEncoding(3, enc_cfg(15)).to(DEV)
+    with torch.no_grad():
+        enc.params.copy_(torch.randn(enc.params.shape, device=DEV, generator=g))
+    rm = enc(x).detach()
+    lm = torch.empty((16, n, 2), device=DEV)
+    L.check(L.lib().us_hashgrid_fwd(ctypes.byref(enc.desc), L.ptr(enc.params.detach()), L.ptr(x), n, L.ptr(lm), None, 2, L.stream()), "fwd")
+    assert torch.equal(lm.permute(1, 0, 2).reshape(n, 32), rm)
+    dy = torch.randn((n, 32), device=DEV, generator=g)
+    dy_lm = dy.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    for mode in (0, 1):
+        ga, gb = torch.zeros_like(enc.params), torch.zeros_like(enc.params)
+        L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(enc.desc), L.ptr(x), L.ptr(dy), n, L.ptr(ga), mode, 0, L.stream()), "bwd")
+        L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(enc.desc), L.ptr(x), L.ptr(dy_lm), n, L.ptr(gb), mode, 2, L.stream()), "bwd")
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-5 * ga.abs().max().item())
+    # MLP on level-major input / input-gradient
+    desc = us.make_mlp_desc(32, 32, 2, 3, "sigmoid", True)
+    p = torch.randn(us.network.mlp_n_params(desc), device=DEV, generator=g) * 0.3
+    y_rm, y_lm = torch.empty((n, 3), device=DEV), torch.empty((n, 3), device=DEV)
+    L.check(L.lib().us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(rm), n, L.ptr(y_rm), 3, 0, L.stream()), "mlp")
+    L.check(L.lib().us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(lm), n, L.ptr(y_lm), 3, 1, L.stream()), "mlp")
+    assert torch.equal(y_rm, y_lm)
+    dyo = torch.randn((n, 3), device=DEV, generator=g)
+    dx_rm, dx_lm = torch.empty((n, 32), device=DEV), torch.empty((16, n, 2), device=DEV)
+    g1, g2 = torch.zeros_like(p), torch.zeros_like(p)
+    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(rm), L.ptr(y_rm), 3, L.ptr(dyo), 3, n, L.ptr(dx_rm), L.ptr(g1), 0, L.stream()), "mlpb")
+    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(lm), L.ptr(y_lm), 3, L.ptr(dyo), 3, n, L.ptr(dx_lm), L.ptr(g2), 1, L.stream()), "mlpb")
+    assert torch.equal(dx_lm.permute(1, 0, 2).reshape(n, 32), dx_rm)
+    assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5 * g1.abs().max().item())
+
+
 def test_hashgrid_empty_and_features_1_4(us):
     enc = us.HashGridEncoding(3, enc_cfg(12)).to(DEV)
     assert enc(torch.empty(0, 3, device=DEV)).shape == (0, 32)

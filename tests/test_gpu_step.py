@@ -92,6 +92,8 @@ def test_mapstep_zero_depth_rays_and_oracle():
     dec, es, ec = _scene(us, False, seed=3)
     R, S = 160, 40
     ro, rd, gd, gc = _rays(R, seed=4, zero_depth=True)
+    far = O.bbox_far(ro.cpu(), rd.cpu(), BOUND)
+    gd = torch.where(gd > 0, torch.minimum(gd, 0.9 * far.to(DEV)), gd)        # every ray inside the box: the oracle call below has no pre-filter
     n1, n0 = int((gd > 0).sum()), int((gd <= 0).sum())
     torch.manual_seed(9)
     tr1, tr0, u0 = torch.rand(n1, S), torch.rand(n0, 32), torch.rand(n0, 8)
@@ -116,6 +118,12 @@ def test_mapstep_zero_depth_rays_and_oracle():
     assert not draws
     z = step.rendered()[5]
     np.testing.assert_allclose(z.cpu().numpy(), ret_o[5].numpy(), rtol=1e-4, atol=1e-5)
+    # mask counts must agree before the loss can (a ray on the 0.99 opacity threshold would flip a count)
+    _, unc_o, depth_o = ret_o[0], ret_o[1], ret_o[2]
+    m_o = (gd.cpu() > 0) & ((1 - unc_o.detach()) > 0.99)
+    print("counts hip", step.stats[5:].tolist(), "oracle depth-mask rays", int(m_o.sum()), "loss", float(loss), float(loss_o))
+    np.testing.assert_allclose(step.rendered()[1].cpu().numpy(), unc_o.detach().numpy(), rtol=1e-3, atol=1e-6)
+    assert int(step.stats[9]) == int(m_o.sum())
     np.testing.assert_allclose(float(loss), float(loss_o), rtol=1e-3)
     go = oes.params.grad
     assert torch.allclose(es.params.grad.cpu(), go, rtol=2e-3, atol=1e-4 * go.abs().max().item())

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunislam_hip.so")
 US_MAX_LEVELS = 32
 US_GRID_CLAMP01 = 1
+US_GRID_LEVEL_MAJOR = 2
+US_MLP_LEVEL_MAJOR = 1
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -50,8 +52,8 @@ SIGNATURES = {
     "us_hashgrid_bwd_params": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_int, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),
-    "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_f]),
-    "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f]),
+    "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_int, c_f]),
+    "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f]),
     "us_sample_z": (c_int, [c_f, c_i64, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt, c_f, c_f, c_f]),
     "us_ray_points": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f]),
     "us_ray_points_bwd": (c_int, [c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),

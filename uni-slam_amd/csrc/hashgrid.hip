@@ -114,6 +114,13 @@ __device__ __forceinline__ float load_x(const float* __restrict__ x, int64_t i, 
     return clamp ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
 }
 
+// feature / gradient tensor layouts: row-major [N][L*F] (the torch module's view) or level-major [L][N][F]
+// (US_GRID_LEVEL_MAJOR: what the fused MapStep path uses; a level's plane is contiguous, so a workgroup that owns
+// one level streams N*F floats instead of touching every 128-byte row of the [N][32] matrix)
+__device__ __forceinline__ int64_t feat_index(int lm, int64_t i, int64_t n, uint32_t level, uint32_t C, int F) {
+    return lm ? ((int64_t)level * n + i) * F : i * C + (int64_t)level * F;
+}
+
 // weights in tcnn's multiplication order: w = ((1*a0)*a1)*a2
 __device__ __forceinline__ float corner_weight(int c, const float pos[3]) {
     float w = (c & 1) ? pos[0] : 1.0f - pos[0];
@@ -138,7 +145,7 @@ template <> __device__ __forceinline__ void feat_to_array<4>(const float4& v, fl
 template <int F, bool DYDX>
 __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
                                              const float* __restrict__ x, int64_t n, float* __restrict__ out,
-                                             float* __restrict__ dy_dx, int clamp) {
+                                             float* __restrict__ dy_dx, int clamp, int lm) {
     const uint32_t level = blockIdx.y;
     const LevelGeom g = level_geom(tab, level);
     const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, 
 #pragma unroll
             for (int f = 0; f < F; ++f) res[f] = fmaf(w, va[c][f], res[f]);
         }
-        float* o = out + i * C + level * F;
+        float* o = out + feat_index(lm, i, n, level, C, F);
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = res[f];
         if (DYDX) {
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256) void k_indices(LevelTable tab, uint32_t n_leve
 template <int F>
 __global__ __launch_bounds__(256) void k_bwd_atomic(LevelTable tab, uint32_t n_levels, uint32_t level_mask,
                                                     const float* __restrict__ x, const float* __restrict__ dL_dy,
-                                                    int64_t n, float* __restrict__ grad, int clamp) {
+                                                    int64_t n, float* __restrict__ grad, int clamp, int lm) {
     const uint32_t level = blockIdx.y;
     if (!((level_mask >> level) & 1u)) return;
     const LevelGeom g = level_geom(tab, level);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void k_bwd_atomic(LevelTable tab, uint32_t n_l
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float dy[F]; bool any = false;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { dy[f] = dL_dy[i * C + level * F + f]; any |= (dy[f] != 0.0f); }
+        for (int f = 0; f < F; ++f) { dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f]; any |= (dy[f] != 0.0f); }
         if (!any) continue;                    // adding zeros changes nothing
         float pos[3]; uint32_t cell[3];
 #pragma unroll
@@ -242,20 +249,37 @@ __global__ __launch_bounds__(256) void k_bwd_atomic(LevelTable tab, uint32_t n_l
 // ---------------------------------------------------------------------------------------------------------------
 // backward wrt table: LDS-privatised slices
 // ---------------------------------------------------------------------------------------------------------------
-#define US_SLICE_FLOATS 32768            // 128 KiB of the 160 KiB LDS
 #define US_SLICE_THREADS 1024
+#define US_SLICE_WAVES (US_SLICE_THREADS / 64)
+#define US_QCAP 128                      // per-wave compaction queue entries (>= 2 x 64)
+
+// LDS budget (160 KiB): accumulator slice + 16 per-wave queues of (index, F values)
+template <int F> struct SliceCfg {
+    static constexpr int QUEUE_FLOATS = US_SLICE_WAVES * US_QCAP * (1 + F);
+    static constexpr int SLICE_FLOATS = (F == 4) ? 24576 : 32768;          // 96 / 128 KiB
+    static_assert((SLICE_FLOATS + QUEUE_FLOATS) * 4 <= 163840, "LDS budget");
+};
+static uint32_t slice_entries_for(uint32_t F) { return (F == 4 ? 24576u : 32768u) / F; }
 
 struct SliceMap {                        // prefix sum of slices per level (only levels in the mask have slices)
     uint32_t first[US_MAX_LEVELS + 1];
 };
 
-template <int F>
+// A ds_add_f32 wave-instruction occupies the LDS for ~64 cycles however few lanes are active (measured: 16 sparse
+// atomics per wave-iteration made the first version of this kernel 10x slower than its VALU work).  So hits are first
+// COMPACTED: each wave appends its in-slice (index, values) pairs to a private LDS queue (ballot + mbcnt prefix, plain
+// ds_write), and only full groups of 64 queue entries are turned into atomics -> 1/16 .. 1/32 of the instructions.
+template <int F, bool COMPACT>
 __global__ __launch_bounds__(US_SLICE_THREADS) void k_bwd_sliced(LevelTable tab, SliceMap smap, uint32_t n_levels,
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ dL_dy, int64_t n,
-                                                                 float* __restrict__ grad, int clamp) {
-    __shared__ float acc[US_SLICE_FLOATS];
-    constexpr uint32_t SLICE_ENTRIES = US_SLICE_FLOATS / F;
+                                                                 float* __restrict__ grad, int clamp, int lm, int exclusive) {
+    typedef SliceCfg<F> SC;
+    __shared__ __attribute__((aligned(16))) float acc[SC::SLICE_FLOATS];
+    __shared__ uint32_t q_idx[US_SLICE_WAVES][US_QCAP];
+    __shared__ float q_val[US_SLICE_WAVES][F][US_QCAP];
+    constexpr uint32_t SLICE_ENTRIES = SC::SLICE_FLOATS / F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // which (level, slice) is blockIdx.y ?   (wave-uniform scalar search over <= 32 levels)
     uint32_t level = 0;
     while (level + 1 < n_levels && smap.first[level + 1] <= blockIdx.y) ++level;
@@ -263,36 +287,104 @@ __global__ __launch_bounds__(US_SLICE_THREADS) void k_bwd_sliced(LevelTable tab,
     const LevelGeom g = level_geom(tab, level);
     const uint32_t lo = slice * SLICE_ENTRIES;
     const uint32_t cnt = min(SLICE_ENTRIES, g.hs - lo);
-    for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) acc[k] = 0.0f;
+    {
+        float4* a4 = reinterpret_cast<float4*>(acc);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t k = threadIdx.x; k < (cnt * F + 3) / 4; k += US_SLICE_THREADS) a4[k] = z4;
+    }
     __syncthreads();
 
     const uint32_t C = n_levels * F;
-    // contiguous partition of the points for this blockIdx.x
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;      // contiguous partition of the points for this blockIdx.x
     const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(n, i0 + per);
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += US_SLICE_THREADS) {
-        float dy[F]; bool any = false;
+    uint32_t qn = 0;                                          // wave-uniform queue fill
+    uint32_t* qi = q_idx[wave];
+    // Every workgroup of a level streams the SAME x / dy addresses.  Started together they walk them in lockstep and all
+    // 32 CUs of an XCD hammer one L2 channel at a time (measured: 10-30k cycles per step).  Rotating the start of each
+    // workgroup's sweep by a slice-dependent amount spreads the requests over all channels.
+    const int64_t n_steps = (i1 - i0 + US_SLICE_THREADS - 1) / US_SLICE_THREADS;
+    const int64_t rot = n_steps > 0 ? (int64_t)((blockIdx.y * 2654435761u) >> 8) % n_steps : 0;
+    for (int64_t step = 0; step < n_steps; ++step) {          // uniform trip count: ballots need whole waves
+        int64_t sstep = step + rot; if (sstep >= n_steps) sstep -= n_steps;
+        const int64_t i = i0 + sstep * US_SLICE_THREADS + threadIdx.x;
+        bool live = i < i1;
+        float dy[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) { dy[f] = dL_dy[i * C + level * F + f]; any |= (dy[f] != 0.0f); }
-        if (!any) continue;
-        float pos[3]; uint32_t cell[3];
+        for (int f = 0; f < F; ++f) dy[f] = 0.0f;
+        float pos[3] = {0.f, 0.f, 0.f}; uint32_t cell[3] = {0u, 0u, 0u};
+        if (live) {
+            bool any = false;
+#if defined(US_EXP_NO_LOADS)
+            for (int f = 0; f < F; ++f) { dy[f] = 1.0f; any = true; }
+            for (int k = 0; k < 3; ++k) pos_fract((float)((uint32_t)(i * 2654435761u + k * 40503u) >> 8) * (1.0f / 16777216.0f), g.scale, pos[k], cell[k]);
+#else
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+            for (int f = 0; f < F; ++f) { dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f]; any |= (dy[f] != 0.0f); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
+#endif
+            live = any;                                       // adding zeros changes nothing
+        }
+        if (!COMPACT && !live) continue;                      // whole waves of zero-gradient samples skip the hashing
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t e = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1)) - lo;
-            if (e < cnt) {                     // unsigned compare also rejects e < lo
-                const float w = corner_weight(c, pos);
+            const bool hit = live && (e < cnt);               // unsigned compare also rejects e < lo
+            if (!COMPACT) {
+                if (hit) {
+                    const float w = corner_weight(c, pos);
 #pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[e * F + f], w * dy[f]);     // ds_add_f32
+                    for (int f = 0; f < F; ++f) {
+#if defined(US_EXP_NO_LDS_ATOMIC)
+                        acc[e * F + f] = w * dy[f];
+#elif defined(US_EXP_INT_ATOMIC)
+                        atomicAdd(reinterpret_cast<unsigned*>(&acc[e * F + f]), __float_as_uint(w * dy[f]));
+#else
+                        atomicAdd(&acc[e * F + f], w * dy[f]);      // ds_add_f32: ~3 cycles per active lane
+#endif
+                    }
+                }
+                continue;
             }
+            const unsigned long long mask = __ballot(hit);
+            if (mask == 0ull) continue;                       // wave-uniform
+            if (hit) {
+                const uint32_t p = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const float w = corner_weight(c, pos);
+                qi[p] = e * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) q_val[wave][f][p] = w * dy[f];
+            }
+            qn += (uint32_t)__popcll(mask);
+            if (qn >= 64u) {                                  // drain the LAST 64 entries with all 64 lanes active
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t k = qn - 64u + lane;
+                const uint32_t a = qi[k];
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[a + f], q_val[wave][f][k]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qn -= 64u;
+            }
+        }
+    }
+    if (qn) {                                                 // remainder (< 64 entries), once per wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < qn) {
+            const uint32_t a = qi[lane];
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(&acc[a + f], q_val[wave][f][lane]);
         }
     }
     __syncthreads();
     float* gl = grad + ((size_t)tab.off[level] + lo) * F;
-    for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) {
-        const float v = acc[k];
-        if (v != 0.0f) atomicAdd(gl + k, v);   // contiguous lanes -> 64-B atomic requests, full atomic rate
+    if (exclusive) {
+        // this workgroup is the only one that touches this slice in this launch: plain read-modify-write
+        for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) { const float v = acc[k]; if (v != 0.0f) gl[k] += v; }
+    } else {
+        for (uint32_t k = threadIdx.x; k < cnt * F; k += US_SLICE_THREADS) {
+            const float v = acc[k];
+            if (v != 0.0f) atomicAdd(gl + k, v);              // contiguous lanes -> 64-B atomic requests, full atomic rate
+        }
     }
 }
 
@@ -332,7 +424,7 @@ static unsigned point_blocks(int64_t n, int threads, int cap) {
 
 extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out,
                                float* dy_dx, int flags, void* stream) {
-    const int clamp = flags & US_GRID_CLAMP01;
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0; (void)lm;
     int rc = check_desc("us_hashgrid_fwd", d); if (rc) return rc;
     US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_hashgrid_fwd: n < 0");
     if (n == 0) return US_OK;                       // empty batches carry NULL data pointers
@@ -341,8 +433,8 @@ extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const
     dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_FWD(F)                                                                                         \
-    if (dy_dx) hipLaunchKernelGGL((k_fwd<F, true>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp); \
-    else hipLaunchKernelGGL((k_fwd<F, false>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp);
+    if (dy_dx) hipLaunchKernelGGL((k_fwd<F, true>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm); \
+    else hipLaunchKernelGGL((k_fwd<F, false>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm);
     switch (d->n_features) { case 1: LAUNCH_FWD(1) break; case 2: LAUNCH_FWD(2) break; default: LAUNCH_FWD(4) break; }
 #undef LAUNCH_FWD
     US_CHECK_LAUNCH("us_hashgrid_fwd");
@@ -350,7 +442,7 @@ extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const
 }
 
 extern "C" int us_hashgrid_indices(const us_grid_desc* d, const float* x, int64_t n, uint32_t* idx, int flags, void* stream) {
-    const int clamp = flags & US_GRID_CLAMP01;
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0; (void)lm;
     int rc = check_desc("us_hashgrid_indices", d); if (rc) return rc;
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(x && idx, US_ERR_NULL, "us_hashgrid_indices: NULL pointer");
@@ -363,20 +455,20 @@ extern "C" int us_hashgrid_indices(const us_grid_desc* d, const float* x, int64_
 
 extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n,
                                       float* grad_params, int mode, int flags, void* stream) {
-    const int clamp = flags & US_GRID_CLAMP01;
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0; (void)lm;
     int rc = check_desc("us_hashgrid_bwd_params", d); if (rc) return rc;
-    US_REQUIRE(mode >= -1 && mode <= 1, US_ERR_CONFIG, "us_hashgrid_bwd_params: mode %d", mode);
+    US_REQUIRE(mode >= -1 && mode <= 2, US_ERR_CONFIG, "us_hashgrid_bwd_params: mode %d", mode);
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(x && dL_dy && grad_params, US_ERR_NULL, "us_hashgrid_bwd_params: NULL pointer");
     const LevelTable t = make_table(d);
     hipStream_t s = (hipStream_t)stream;
     const uint32_t F = d->n_features, L = d->n_levels;
-    const uint32_t slice_entries = US_SLICE_FLOATS / F;
+    const uint32_t slice_entries = slice_entries_for(F);
     // per level: slices pay when the level receives many more updates (8 per point) than it has entries
     uint32_t sliced_mask = 0;
     for (uint32_t l = 0; l < L; ++l) {
         const uint64_t hs = d->offset[l + 1] - d->offset[l];
-        bool sliced = mode == 1 || (mode == -1 && (uint64_t)n * 8ull >= hs);
+        bool sliced = mode >= 1 || (mode == -1 && (uint64_t)n * 8ull >= hs);
         if (sliced) sliced_mask |= 1u << l;
     }
     const uint32_t all = L == 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
@@ -384,9 +476,9 @@ extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, con
     if (atomic_mask) {
         dim3 grid(point_blocks(n, 256, 1 << 20), L), block(256);
         switch (F) {
-            case 1: hipLaunchKernelGGL((k_bwd_atomic<1>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
-            case 2: hipLaunchKernelGGL((k_bwd_atomic<2>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
-            default: hipLaunchKernelGGL((k_bwd_atomic<4>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp); break;
+            case 1: hipLaunchKernelGGL((k_bwd_atomic<1>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp, lm); break;
+            case 2: hipLaunchKernelGGL((k_bwd_atomic<2>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp, lm); break;
+            default: hipLaunchKernelGGL((k_bwd_atomic<4>), grid, block, 0, s, t, L, atomic_mask, x, dL_dy, n, grad_params, clamp, lm); break;
         }
         US_CHECK_LAUNCH("us_hashgrid_bwd_params(atomic)");
     }
@@ -398,17 +490,22 @@ extern "C" int us_hashgrid_bwd_params(const us_grid_desc* d, const float* x, con
         }
         for (uint32_t l = L; l <= US_MAX_LEVELS; ++l) sm.first[l] = total;
         // levels outside the mask get zero slices: first[l+1] == first[l], the in-kernel search skips them.
-        // point partitions: enough workgroups to fill 256 CUs a few times, but >= 8192 points each so that the
-        // slice flush (<= 128 KiB of atomics per workgroup) stays small next to the accumulation work
+        // point partitions: ~4 workgroups per CU (one is resident at a time: the slice fills the LDS) keeps the tail of the
+        // launch short; never fewer than 8192 points per workgroup so the <= 128 KiB slice flush stays a small part
         int64_t parts = us_cdiv(1024, total);
         const int64_t max_parts = us_cdiv(n, 8192);
         if (parts > max_parts) parts = max_parts;
         if (parts < 1) parts = 1;
+        const int exclusive = parts == 1 ? 1 : 0;
         dim3 grid((unsigned)parts, total), block(US_SLICE_THREADS);
         switch (F) {
-            case 1: hipLaunchKernelGGL((k_bwd_sliced<1>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
-            case 2: hipLaunchKernelGGL((k_bwd_sliced<2>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
-            default: hipLaunchKernelGGL((k_bwd_sliced<4>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp); break;
+#define LAUNCH_SLICED(F)                                                                                                      \
+    if (mode == 2) hipLaunchKernelGGL((k_bwd_sliced<F, true>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp, lm, exclusive); \
+    else hipLaunchKernelGGL((k_bwd_sliced<F, false>), grid, block, 0, s, t, sm, L, x, dL_dy, n, grad_params, clamp, lm, exclusive);
+            case 1: LAUNCH_SLICED(1) break;
+            case 2: LAUNCH_SLICED(2) break;
+            default: LAUNCH_SLICED(4) break;
+#undef LAUNCH_SLICED
         }
         US_CHECK_LAUNCH("us_hashgrid_bwd_params(sliced)");
     }

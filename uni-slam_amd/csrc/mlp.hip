@@ -146,16 +146,25 @@ __device__ __forceinline__ void load_weights(float* lds, const float* __restrict
 }
 
 // input features of 64 points as B operands: xb[q][b][c] = in[p(q)][16b + 4g + c]
+// LM: level-major planes [NIN/2][N][2]: features 16b+4g .. +3 are planes 8b+2g and 8b+2g+1 (two float2 loads)
 template <int NQ, int NIN>
 __device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_t base, int64_t n, int row, int g,
-                                            v4f (&xb)[NQ][NIN / 16]) {
+                                            v4f (&xb)[NQ][NIN / 16], int lm) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int64_t p = base + 16 * q + row;
 #pragma unroll
         for (int b = 0; b < NIN / 16; ++b) {
             v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (p < n) v = *reinterpret_cast<const v4f*>(in + p * NIN + 16 * b + 4 * g);
+            if (p < n) {
+                if (lm) {
+                    const float2 lo = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g) * n + p) * 2);
+                    const float2 hi = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g + 1) * n + p) * 2);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+                } else {
+                    v = *reinterpret_cast<const v4f*>(in + p * NIN + 16 * b + 4 * g);
+                }
+            }
             xb[q][b] = v;
         }
     }
@@ -167,7 +176,7 @@ __device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_
 template <int NIN, int WIDTH, int NHID>
 __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict__ params, int has_bias, int n_out,
                                                          int act, const float* __restrict__ in, int64_t n,
-                                                         float* __restrict__ out, int64_t out_stride) {
+                                                         float* __restrict__ out, int64_t out_stride, int lm) {
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_FWD_END];
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict
     for (int64_t chunk = (int64_t)blockIdx.x * MLP_WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * MLP_WAVES) {
         const int64_t base = chunk * PTS;
         v4f xb[NQ][C::KB_IN];
-        load_inputs<NQ, NIN>(in, base, n, row, g, xb);
+        load_inputs<NQ, NIN>(in, base, n, row, g, xb, lm);
         v4f h0[NQ][C::MT];
         dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
         relu_<NQ, C::MT>(h0);
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
                                                          const float* __restrict__ out, int64_t out_stride,
                                                          const float* __restrict__ dL_dout, int64_t dout_stride,
                                                          int64_t n, float* __restrict__ dL_din,
-                                                         float* __restrict__ grad_params) {
+                                                         float* __restrict__ grad_params, int lm) {
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t base = (grp * MLP_WAVES + wave) * PTS;
         v4f xb[NQ][C::KB_IN];
-        load_inputs<NQ, NIN>(in, base, n, row, g, xb);
+        load_inputs<NQ, NIN>(in, base, n, row, g, xb, lm);
         v4f h0[NQ][C::MT], h1[NQ][C::MT];
         dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
         relu_<NQ, C::MT>(h0);
@@ -371,8 +380,14 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
                 const int64_t p = base + 16 * q + row;
                 if (p < n) {
 #pragma unroll
-                    for (int b = 0; b < C::KB_IN; ++b)
-                        *reinterpret_cast<v4f*>(dL_din + p * NIN + 16 * b + 4 * g) = dx[q][b];
+                    for (int b = 0; b < C::KB_IN; ++b) {
+                        if (lm) {
+                            *reinterpret_cast<float2*>(dL_din + ((int64_t)(8 * b + 2 * g) * n + p) * 2) = make_float2(dx[q][b][0], dx[q][b][1]);
+                            *reinterpret_cast<float2*>(dL_din + ((int64_t)(8 * b + 2 * g + 1) * n + p) * 2) = make_float2(dx[q][b][2], dx[q][b][3]);
+                        } else {
+                            *reinterpret_cast<v4f*>(dL_din + p * NIN + 16 * b + 4 * g) = dx[q][b];
+                        }
+                    }
                 }
             }
         }
@@ -424,7 +439,8 @@ extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
     } while (0)
 
 extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
-                          int64_t out_stride, void* stream) {
+                          int64_t out_stride, int flags, void* stream) {
+    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_fwd", d); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_fwd: out_stride %lld < n_out", (long long)out_stride);
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
@@ -433,14 +449,15 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     const int pts = d->width == 64 ? 32 : 64;
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 2048) nb = 2048;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
-    MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride);
+    MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
     US_CHECK_LAUNCH("us_mlp_fwd");
     return US_OK;
 }
 
 extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out,
                           int64_t out_stride, const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din,
-                          float* grad_params, void* stream) {
+                          float* grad_params, int flags, void* stream) {
+    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_bwd", d); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out && dout_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_bwd: stride < n_out");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
@@ -451,7 +468,7 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 512) nb = 512;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
     MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
-                 dout_stride, n, dL_din, grad_params);
+                 dout_stride, n, dL_din, grad_params, lm);
     US_CHECK_LAUNCH("us_mlp_bwd");
     return US_OK;
 }

@@ -64,6 +64,7 @@ class Decoders(nn.Module):
     def __deepcopy__(self, memo):
         new = Decoders(self.cfg, self.c_dim, self.hidden_size, self.truncation, self.n_blocks,
                        isinstance(self.beta, nn.Parameter))
+        new.to(next(self.parameters()).device)
         new.load_state_dict(self.state_dict())
         for (_, a), (_, b) in zip(self.named_parameters(), new.named_parameters()):
             b.requires_grad_(a.requires_grad)

@@ -63,8 +63,10 @@ class _HashGridFn(torch.autograd.Function):
                                                   L.ptr(gx), L.stream()), "us_hashgrid_bwd_input")
         if ctx.needs_input_grad[1]:
             gp = torch.zeros(desc.n_params, dtype=torch.float32, device=x.device)
-            L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp),
-                                                   ctx.bwd_mode, ctx.flags, L.stream()), "us_hashgrid_bwd_params")
+            # the table-gradient kernel streams one level at a time: hand it level-major planes [L][N][F]
+            dy_lm = dy.view(n, desc.n_levels, desc.n_features).permute(1, 0, 2).contiguous()
+            L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(desc), L.ptr(x), L.ptr(dy_lm), n, L.ptr(gp), ctx.bwd_mode,
+                                                   ctx.flags | L.US_GRID_LEVEL_MAJOR, L.stream()), "us_hashgrid_bwd_params")
         return gx, gp, None, None, None
 
 
@@ -107,7 +109,7 @@ class HashGridEncoding(nn.Module):
     def __deepcopy__(self, memo):
         new = HashGridEncoding(3, self.encoding_config)
         new.bwd_mode, new.clamp_input = self.bwd_mode, self.clamp_input
-        new.params = nn.Parameter(self.params.detach().clone(), requires_grad=self.params.requires_grad)
+        new.params = nn.Parameter(self.params.detach().clone(), requires_grad=self.params.requires_grad)   # same device
         return new
 
     def forward(self, x, clamp=None):

@@ -39,7 +39,7 @@ class _MlpFn(torch.autograd.Function):
         p = L.f32(params.detach())
         n = x.shape[0]
         out = torch.empty((n, desc.n_out), dtype=torch.float32, device=x.device)
-        L.check(L.lib().us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(out), desc.n_out, L.stream()),
+        L.check(L.lib().us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(out), desc.n_out, 0, L.stream()),
                 "us_mlp_fwd")
         ctx.desc = desc
         ctx.save_for_backward(x, p, out)
@@ -55,7 +55,7 @@ class _MlpFn(torch.autograd.Function):
         gp = torch.zeros_like(p) if ctx.needs_input_grad[1] else None
         if gx is not None or gp is not None:
             L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(out), desc.n_out, L.ptr(dy),
-                                       desc.n_out, n, L.ptr(gx), L.ptr(gp), L.stream()), "us_mlp_bwd")
+                                       desc.n_out, n, L.ptr(gx), L.ptr(gp), 0, L.stream()), "us_mlp_bwd")
         return gx, gp, None
 
 

@@ -62,6 +62,7 @@ class MapStep:
         self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
         self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
         self.lr = dict(lr)
+        self.probe = None               # dict name -> [(start_event, end_event)]: per-kernel HIP-event timing (bench.py)
         self._adopt_parameters()
         self._alloc(max_rays)
         self.reset_optimizer(1.0)
@@ -135,6 +136,17 @@ class MapStep:
         self.stats, self.loss = f(10), f(1)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
 
+    def _timed(self, name, rc_fn):
+        """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
+        if self.probe is None:
+            L.check(rc_fn(), name)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(rc_fn(), name)
+        e1.record()
+        self.probe.setdefault(name, []).append((e0, e1))
+
     # ------------------------------------------------------------------------------------------ the iteration
     def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
         """
@@ -168,10 +180,10 @@ class MapStep:
         fl = self.flat
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        L.check(lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 1, st), "us_hashgrid_fwd")
-        L.check(lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 1, st), "us_hashgrid_fwd")
-        L.check(lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, st), "us_mlp_fwd")
-        L.check(lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, st), "us_mlp_fwd")
+        self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st))
+        self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
+        self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
+        self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
         beta = off(fl, self.o_beta)
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), beta, R, S, P(self.term), P(self.unc), P(self.depth), P(self.rgb),
                                      P(self.dunc), None, st), "us_composite_fwd")
@@ -199,14 +211,14 @@ class MapStep:
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, st), "us_composite_bwd")
-        L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N,
-                               P(self.d_feat_s), off(self.grad, self.o_dec_s), st), "us_mlp_bwd")
-        L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N,
-                               P(self.d_feat_c), off(self.grad, self.o_dec_c), st), "us_mlp_bwd")
-        L.check(lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s), self.bwd_mode, 1,
-                                           st), "us_hashgrid_bwd_params")
-        L.check(lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c), self.bwd_mode, 1,
-                                           st), "us_hashgrid_bwd_params")
+        self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
+                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1, st))
+        self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
+                                                            N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, st))
+        self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
+                                                                          off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
+        self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
+                                                                            off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
         self.n_rays = R
         return self.loss
 
