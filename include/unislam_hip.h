@@ -80,9 +80,19 @@ int us_hashgrid_indices(const us_grid_desc* desc_host, const float* x, int64_t n
 /* grad_params[n_params] += scatter(dL_dy[N][C]).  Caller zeroes grad_params when it wants a fresh gradient.
  * mode 0: direct global float atomics (tcnn's kernel_grid_backward shape);
  * mode 1: LDS-privatised table slices (one workgroup accumulates a slice of one level over all points
- *         in LDS, then flushes it with contiguous atomics);  mode -1: pick by shape. */
+ *         in LDS, then flushes it with contiguous atomics);  mode 2: the same with per-wave compaction queues;
+ * mode -1: pick per level by shape (slices where a level receives more updates than it has entries). */
 int us_hashgrid_bwd_params(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
                            float* grad_params, int mode, int flags, void* stream);
+
+/* Same result as us_hashgrid_bwd_params, by "bin once, accumulate in f64" (csrc/hashgrid_binned.hip): every (point,
+ * level) is hashed a constant number of times, contributions of neighbouring samples in the same cell are combined in
+ * registers, records are binned by entry index mod n_bins and each bin is summed in LDS with ds_add_f64.  Needs a caller-
+ * provided workspace of us_hashgrid_bwd_workspace_bytes(desc, n) bytes (scratch: contents undefined afterwards).
+ * This is the path MapStep uses for the 4096 x 64 mapping batch. */
+size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* desc_host, int64_t n);
+int us_hashgrid_bwd_binned(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
+                           float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
 int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics [-DUS_EXP_...] tools/bwd_bench.hip -o /tmp/bwd_bench
 #include "../uni-slam_amd/csrc/api.cpp"
 #include "../uni-slam_amd/csrc/hashgrid.hip"
+#include "../uni-slam_amd/csrc/hashgrid_binned.hip"
 #include <vector>
 #include <random>
 
@@ -32,6 +33,20 @@ int main(int argc, char** argv) {
                 float ms; hipEventElapsedTime(&ms, a, b);
                 printf("log2T %2u  n %ld  mode %d  layout %s : %8.3f ms\n", log2T, (long)n, mode, lm ? "level-major" : "row-major", ms / 3);
             }
+        }
+        {
+            const size_t wsb = us_hashgrid_bwd_workspace_bytes(&d, n);
+            void* ws; hipMalloc(&ws, wsb);
+            for (int lm : {0, 2}) {
+                int rc = us_hashgrid_bwd_binned(&d, x, dy, n, g, lm, ws, wsb, 0); hipDeviceSynchronize();
+                if (rc) printf("binned rc=%d %s\n", rc, us_last_error());
+                hipEventRecord(a);
+                for (int r = 0; r < 3; ++r) us_hashgrid_bwd_binned(&d, x, dy, n, g, lm, ws, wsb, 0);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                printf("log2T %2u  n %ld  BINNED  layout %s : %8.3f ms   (workspace %.0f MB)\n", log2T, (long)n, lm ? "level-major" : "row-major", ms / 3, wsb / 1e6);
+            }
+            hipFree(ws);
         }
         hipFree(x); hipFree(dy); hipFree(g);
     }

@@ -10,6 +10,7 @@
 __device__ __forceinline__ uint32_t rng(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
 // MODE 0: ds_add_f32 all lanes random | 1: ds_add_f32, 2 of 64 lanes active | 2: ds_add_u32 all lanes | 3: plain ds_write
+// 8: ds_add_u64 random | 9: ds_add_u64 same address | 10: ds_add_u32 same address | 11: ds_add_f64 random | 12: u64 run-of-8 conflicts | 13: f32 run-of-8
 // 4: read+add+write (non atomic) | 5: ds_add_f32 all lanes SAME address | 6: ds_add_rtn_f32 all lanes random | 7: ds_add_f32 4 lanes
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(float* out, int active_div) {
@@ -30,6 +31,12 @@ __global__ __launch_bounds__(1024) void k(float* out, int active_div) {
         if (MODE == 5) atomicAdd(&lds[it & 1023], v);
         if (MODE == 6) acc += atomicAdd(&lds[idx], v);
         if (MODE == 7) { if ((lane % 16) == 0) atomicAdd(&lds[idx], v); }
+        if (MODE == 8) atomicAdd((unsigned long long*)&lds[(idx & (LDS_FLOATS / 2 - 1)) * 2], (unsigned long long)idx);
+        if (MODE == 9) atomicAdd((unsigned long long*)&lds[(it & 511) * 2], (unsigned long long)idx);
+        if (MODE == 10) atomicAdd((unsigned*)&lds[it & 1023], idx);
+        if (MODE == 11) atomicAdd((double*)&lds[(idx & (LDS_FLOATS / 2 - 1)) * 2], (double)v);
+        if (MODE == 12) { const uint32_t j = __shfl(idx, lane & ~7); atomicAdd((unsigned long long*)&lds[(j & (LDS_FLOATS / 2 - 1)) * 2], (unsigned long long)idx); }
+        if (MODE == 13) { const uint32_t j = __shfl(idx, lane & ~7); atomicAdd(&lds[j], v); }
     }
     __syncthreads();
     float t = acc;
@@ -62,6 +69,9 @@ int main() {
             run<0>("ds_add_f32 64 lanes random", 1024); run<1>("ds_add_f32 2 lanes active", 1024); run<7>("ds_add_f32 4 lanes active", 1024);
             run<2>("ds_add_u32 64 lanes random", 1024); run<3>("ds_write_b32 random", 1024); run<4>("read+add+write non-atomic", 1024);
             run<5>("ds_add_f32 64 lanes same address", 1024); run<6>("ds_add_rtn_f32 random", 1024);
+            run<8>("ds_add_u64 64 lanes random", 1024); run<9>("ds_add_u64 64 lanes same address", 1024);
+            run<10>("ds_add_u32 64 lanes same address", 1024); run<11>("ds_add_f64 64 lanes random", 1024);
+            run<12>("ds_add_u64 runs of 8 equal addresses", 1024); run<13>("ds_add_f32 runs of 8 equal addresses", 1024);
         }
     }
     return 0;

@@ -50,6 +50,8 @@ SIGNATURES = {
     "us_hashgrid_fwd": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_f, c_int, c_f]),
     "us_hashgrid_indices": (c_int, [_GP, c_f, c_i64, c_f, c_int, c_f]),
     "us_hashgrid_bwd_params": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_int, c_f]),
+    "us_hashgrid_bwd_workspace_bytes": (ctypes.c_size_t, [_GP, c_i64]),
+    "us_hashgrid_bwd_binned": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),
     "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_int, c_f]),

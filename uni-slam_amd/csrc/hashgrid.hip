@@ -25,18 +25,7 @@
 #include <math.h>
 #include <string.h>
 
-struct LevelTable {                 // passed by value: ~400 B of kernel arguments
-    float    scale[US_MAX_LEVELS];
-    uint32_t res[US_MAX_LEVELS];
-    uint32_t off[US_MAX_LEVELS + 1];
-};
-
-static LevelTable make_table(const us_grid_desc* d) {
-    LevelTable t;
-    for (int l = 0; l < US_MAX_LEVELS; ++l) { t.scale[l] = d->scale[l]; t.res[l] = d->resolution[l]; }
-    for (int l = 0; l <= US_MAX_LEVELS; ++l) t.off[l] = d->offset[l];
-    return t;
-}
+#include "hashgrid_dev.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // host: descriptor (tcnn GridEncodingTemplated constructor arithmetic, fp32 like the original)
@@ -69,75 +58,6 @@ extern "C" int us_grid_desc_init(us_grid_desc* d, uint32_t n_levels, uint32_t n_
     d->n_params = (uint32_t)(offset * n_features);
     return US_OK;
 }
-
-// ---------------------------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------------------------
-struct LevelGeom {          // wave-uniform
-    float scale; uint32_t res; uint32_t hs; bool hashed; uint32_t res2;
-};
-
-__device__ __forceinline__ LevelGeom level_geom(const LevelTable& t, uint32_t level) {
-    LevelGeom g;
-    g.scale = t.scale[level]; g.res = t.res[level]; g.hs = t.off[level + 1] - t.off[level];
-    // tcnn grid_index: dims are accumulated while stride <= hashmap_size; the hash replaces the sum when the
-    // final stride exceeds hashmap_size.  For a Hash grid that is exactly "res^3 (uint32) > hashmap_size", also
-    // when the loop stopped early (res or res^2 already > hashmap_size).
-    uint32_t stride = 1; bool early = false;
-    for (int dim = 0; dim < 3; ++dim) { if (stride <= g.hs) stride *= g.res; else early = true; }
-    g.hashed = early || (g.hs < stride);
-    g.res2 = g.res * g.res;
-    return g;
-}
-
-__device__ __forceinline__ void pos_fract(float x, float scale, float& pos, uint32_t& cell) {
-    const float p = fmaf(scale, x, 0.5f);
-    const float f = floorf(p);
-    cell = (uint32_t)(int)f;
-    pos = p - f;
-}
-
-// entry index of vertex (gx,gy,gz) inside the level
-__device__ __forceinline__ uint32_t grid_index(const LevelGeom& g, uint32_t gx, uint32_t gy, uint32_t gz) {
-    if (g.hashed) {
-        const uint32_t h = gx ^ (gy * 2654435761u) ^ (gz * 805459861u);
-        return h & (g.hs - 1u);                 // hashed levels always hold exactly 2^log2T entries
-    }
-    uint32_t idx = gx + gy * g.res + gz * g.res2;
-    if (idx >= g.hs) idx %= g.hs;               // wrap-around of the +1 vertex at x == 1 (rare)
-    return idx;
-}
-
-// decoders.py:101 clamps positions to [0,1] before the encoder; US_GRID_CLAMP01 folds that clamp into the load
-__device__ __forceinline__ float load_x(const float* __restrict__ x, int64_t i, int k, int clamp) {
-    const float v = x[i * 3 + k];
-    return clamp ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
-}
-
-// feature / gradient tensor layouts: row-major [N][L*F] (the torch module's view) or level-major [L][N][F]
-// (US_GRID_LEVEL_MAJOR: what the fused MapStep path uses; a level's plane is contiguous, so a workgroup that owns
-// one level streams N*F floats instead of touching every 128-byte row of the [N][32] matrix)
-__device__ __forceinline__ int64_t feat_index(int lm, int64_t i, int64_t n, uint32_t level, uint32_t C, int F) {
-    return lm ? ((int64_t)level * n + i) * F : i * C + (int64_t)level * F;
-}
-
-// weights in tcnn's multiplication order: w = ((1*a0)*a1)*a2
-__device__ __forceinline__ float corner_weight(int c, const float pos[3]) {
-    float w = (c & 1) ? pos[0] : 1.0f - pos[0];
-    w *= (c & 2) ? pos[1] : 1.0f - pos[1];
-    w *= (c & 4) ? pos[2] : 1.0f - pos[2];
-    return w;
-}
-
-template <int F> struct Feat;
-template <> struct Feat<1> { typedef float  T; };
-template <> struct Feat<2> { typedef float2 T; };
-template <> struct Feat<4> { typedef float4 T; };
-
-template <int F> __device__ __forceinline__ void feat_to_array(const typename Feat<F>::T& v, float* a);
-template <> __device__ __forceinline__ void feat_to_array<1>(const float& v, float* a) { a[0] = v; }
-template <> __device__ __forceinline__ void feat_to_array<2>(const float2& v, float* a) { a[0] = v.x; a[1] = v.y; }
-template <> __device__ __forceinline__ void feat_to_array<4>(const float4& v, float* a) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward

@@ -1,0 +1,292 @@
+// hashgrid_binned.hip -- table gradient of the hash grid by "bin once, accumulate in f64" (gfx950).
+//
+// Why (all measured on MI355X, tools/lds_atomic_bench.hip, tools/bwd_bench.hip):
+//   * memory-side float atomics serve ~20 G requests/s chip-wide: 67 M scattered lane-atomics per grid = 4.8 ms;
+//   * privatising table slices in LDS and re-hashing every point once per slice (hashgrid.hip k_bwd_sliced) is bound by
+//     ds_add_f32: ~3 cycles per ACTIVE LANE (195 cycles per 64-lane instruction), ~18 per lane on equal addresses, and
+//     consecutive samples of a ray do fall into the same cells; the 4 MiB colour levels also need 32 slices = 32x re-hashing;
+//   * ds_add_f64 runs at 21 cycles per 64 lanes (9x faster than f32), ds_add_u32 at 7.
+// So each (point, level) is hashed a constant number of times instead of once per slice:
+//   A0 k_bin<COUNT>   every workgroup takes 1024 consecutive points through ALL levels.  Per level, lanes whose neighbours
+//                     (inside aligned groups of 8 lanes = 8 consecutive samples of one ray) sit in the same grid cell are
+//                     RUN-COMBINED with DPP row shifts (segmented inclusive scan of the 8 corner contributions), so a run
+//                     emits one record per corner instead of one per sample.  Records are counted per BIN, where
+//                     bin = entry index mod n_bins(level): interleaving makes bins equally loaded whatever the geometry.
+//   scan              exclusive scan of the bin counts -> exact, gap-free record ranges (no over-allocation, no overflow).
+//   A1 k_bin<WRITE>   same pass again, now writing {local entry, F values} records into their bin's range.
+//   B  k_bin_accum    one workgroup per bin: 128 KiB of f64 accumulators in LDS, ds_add_f64 over the bin's records, then a
+//                     plain (non-atomic) add into the gradient table: a bin owns its entries exclusively.
+// Sums are formed in double precision; the only global atomics left are the per-workgroup bin-cursor reservations.
+#include "hashgrid_dev.h"
+#include <string.h>
+
+#define BIN_THREADS 1024
+#define BIN_MAX_TOTAL 2048               // bins over all levels (LDS counters: 2 x 8 KiB)
+#define BIN_ACC_DOUBLES 16384            // 128 KiB of f64 accumulators per bin
+
+struct BinMap {
+    uint32_t first[US_MAX_LEVELS + 1];   // prefix sum of bins per level
+    uint8_t  log2nb[US_MAX_LEVELS];      // bins per level = 1 << log2nb
+};
+
+static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
+
+static int make_binmap(const us_grid_desc* d, BinMap* bm) {
+    uint32_t total = 0;
+    const uint32_t be = bin_entries(d->n_features);
+    for (uint32_t l = 0; l < US_MAX_LEVELS; ++l) {
+        bm->first[l] = total; bm->log2nb[l] = 0;
+        if (l >= d->n_levels) continue;
+        const uint32_t hs = d->offset[l + 1] - d->offset[l];
+        uint32_t lg = 0;
+        while (((uint64_t)be << lg) < hs) ++lg;
+        bm->log2nb[l] = (uint8_t)lg;
+        total += 1u << lg;
+    }
+    bm->first[US_MAX_LEVELS] = total;
+    for (uint32_t l = d->n_levels; l <= US_MAX_LEVELS; ++l) bm->first[l] = total;
+    return (int)total;
+}
+
+// ---- DPP row shifts (within rows of 16 lanes): shr: lane i <- lane i-n ; shl: lane i <- lane i+n
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
+}
+#define DPP_ROW_SHL1 0x101
+#define DPP_ROW_SHR(n) (0x110 + (n))
+
+// one level of one point: corner records after run-combining.  emit[c] says whether this lane owns a record for corner c.
+template <int F>
+struct LevelRecords {
+    float val[8][F];
+    uint32_t idx[8];
+    bool tail;
+};
+
+template <int F>
+__device__ __forceinline__ void level_records(const LevelGeom& g, const float xv[3], const float dy[F], bool live, int lane,
+                                              LevelRecords<F>& r) {
+    float pos[3]; uint32_t cell[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos_fract(xv[k], g.scale, pos[k], cell[k]);
+    // run key: the cell (resolutions <= 1023 per axis; larger grids get unique keys = no combining)
+#ifdef US_EXP_NO_COMBINE
+    const bool packable = false;
+#else
+    const bool packable = g.res <= 1023u;
+#endif
+    uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
+    if (!live || !packable) key = 0xC0000000u | (uint32_t)lane;      // bits 30..31 set: never equals a packed cell, unique per lane
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w = corner_weight(c, pos);
+#pragma unroll
+        for (int f = 0; f < F; ++f) r.val[c][f] = live ? w * dy[f] : 0.0f;
+        r.idx[c] = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1));
+    }
+    // Segmented inclusive scan over aligned groups of 8 lanes (Hillis-Steele with head flags, steps 1, 2, 4).  A run is a
+    // maximal stretch of ADJACENT lanes in the same cell; equal cells that are not adjacent (arbitrary point order) stay
+    // separate runs, so the scan is exact for any input, and simply finds nothing to merge on unordered points.
+    const int l8 = lane & 7;
+    // NB: every DPP move must execute with the whole wave active (a lane disabled by EXEC reads as 0 to its neighbours):
+    // hoist them out of any short-circuit / divergent expression.
+    const uint32_t kprev = dpp_u32<DPP_ROW_SHR(1)>(key), knext = dpp_u32<DPP_ROW_SHL1>(key);
+    bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
+    const bool next_is_head = (l8 == 7) | (knext != key);
+#define US_SCAN_STEP(O)                                                                                              \
+    {                                                                                                                \
+        const bool take = !flag && (l8 >= (O));                                                                      \
+        const bool fprev = dpp_u32<DPP_ROW_SHR(O)>(flag ? 1u : 0u) != 0u;                                            \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                               \
+            _Pragma("unroll") for (int f = 0; f < F; ++f) {                                                         \
+                const float t = dpp_f32<DPP_ROW_SHR(O)>(r.val[c][f]);                                                \
+                r.val[c][f] += take ? t : 0.0f;                                                                      \
+            }                                                                                                        \
+        flag = flag | ((l8 >= (O)) & fprev);                                                                         \
+    }
+    US_SCAN_STEP(1)
+    US_SCAN_STEP(2)
+    US_SCAN_STEP(4)
+#undef US_SCAN_STEP
+    r.tail = live & next_is_head;
+}
+
+// A0 (WRITE = false): counts[bin] += records ;  A1 (WRITE = true): records written at cursors (initialised to the scan)
+template <int F, bool WRITE>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, uint32_t n_levels, const float* __restrict__ x,
+                                                     const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
+                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
+                                                     uint32_t* __restrict__ rec) {
+    __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
+    __shared__ uint32_t lbase[BIN_MAX_TOTAL];
+    const uint32_t TB = bm.first[n_levels];
+    for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t C = n_levels * F;
+    float xv[3] = {0.f, 0.f, 0.f};
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xv[k] = load_x(x, i, k, clamp);
+    }
+    // two sweeps over the levels: first local bin counts, then (WRITE) ranks + stores.  Hashing twice is cheap;
+    // keeping 16 levels x 8 records in registers is not possible.
+    for (int sweep = 0; sweep < (WRITE ? 2 : 1); ++sweep) {
+        for (uint32_t level = 0; level < n_levels; ++level) {
+            const LevelGeom g = level_geom(tab, level);
+            const uint32_t nbm1 = (1u << bm.log2nb[level]) - 1u, lg = bm.log2nb[level], first = bm.first[level];
+            float dy[F]; bool live = false;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dy[f] = 0.0f;
+            if (in) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) { dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f]; live |= (dy[f] != 0.0f); }
+            }
+            if (__ballot(live) == 0ull) continue;               // whole wave has zero gradient on this level
+            LevelRecords<F> r;
+            level_records<F>(g, xv, dy, live, lane, r);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                bool nz = false;
+#pragma unroll
+                for (int f = 0; f < F; ++f) nz |= (r.val[c][f] != 0.0f);
+                const bool e = r.tail && nz;
+                const unsigned long long mask = __ballot(e);
+                if (mask == 0ull) continue;
+                const uint32_t b = first + (r.idx[c] & nbm1);
+                // rank inside the workgroup's share of the bin.  Fast path: every emitting lane of the wave hits the same
+                // bin (dense levels, one ray per wave): one LDS atomic for the wave instead of <= 64 serialised ones.
+                const uint32_t b0 = __builtin_amdgcn_readlane(b, __ffsll((long long)mask) - 1);
+                uint32_t rank = 0;
+                if (__ballot(e && b == b0) == mask) {
+                    uint32_t base = 0;
+                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
+                    base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
+                    rank = base + mb;
+                } else if (e) {
+                    rank = atomicAdd(&lcnt[b], 1u);
+                }
+                if (WRITE && sweep == 1 && e) {
+                    uint32_t* dst = rec + (size_t)(lbase[b] + rank) * (1 + F);
+                    dst[0] = r.idx[c] >> lg;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(r.val[c][f]);
+                }
+            }
+        }
+        __syncthreads();
+        if (sweep == 0) {
+            for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) {
+                const uint32_t c = lcnt[t];
+                if (WRITE) { lbase[t] = c ? atomicAdd(&cursors[t], c) : 0u; lcnt[t] = 0; }
+                else if (c) atomicAdd(&counts[t], c);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// exclusive scan of counts[0..TB) -> offsets[0..TB], cursors[t] = offsets[t]
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
+                                                   uint32_t* __restrict__ cursors) {
+    __shared__ uint32_t sh[BIN_MAX_TOTAL];
+    const uint32_t t = threadIdx.x;
+    // two elements per thread
+    const uint32_t a = (2 * t < TB) ? counts[2 * t] : 0u, b = (2 * t + 1 < TB) ? counts[2 * t + 1] : 0u;
+    sh[t] = a + b;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = (t >= o) ? sh[t - o] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = sh[t] - (a + b);
+    if (2 * t < TB) { offsets[2 * t] = excl; cursors[2 * t] = excl; }
+    if (2 * t + 1 < TB) { offsets[2 * t + 1] = excl + a; cursors[2 * t + 1] = excl + a; }
+    if (t == 1023) offsets[TB] = sh[1023];
+}
+
+// B: one workgroup per bin
+template <int F>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels,
+                                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ rec,
+                                                           float* __restrict__ grad) {
+    __shared__ double acc[BIN_ACC_DOUBLES];
+    const uint32_t b = blockIdx.x;
+    uint32_t level = 0;
+    while (level + 1 < n_levels && bm.first[level + 1] <= b) ++level;
+    const uint32_t lg = bm.log2nb[level], bl = b - bm.first[level];
+    const uint32_t hs = tab.off[level + 1] - tab.off[level];
+    const uint32_t r0 = offsets[b], r1 = offsets[b + 1];
+    if (r0 == r1) return;                                        // nothing landed in this bin (wave-uniform)
+    const uint32_t n_local = bl < hs ? ((hs - 1u - bl) >> lg) + 1u : 0u;      // entries e with (e & (nb-1)) == bl
+    for (uint32_t k = threadIdx.x; k < n_local * F; k += BIN_THREADS) acc[k] = 0.0;
+    __syncthreads();
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += BIN_THREADS) {
+        const uint32_t* src = rec + (size_t)r * (1 + F);
+        const uint32_t loc = src[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&acc[loc * F + f], (double)__uint_as_float(src[1 + f]));   // ds_add_f64
+    }
+    __syncthreads();
+    float* gl = grad + (size_t)tab.off[level] * F;
+    for (uint32_t k = threadIdx.x; k < n_local * F; k += BIN_THREADS) {
+        const double v = acc[k];
+        if (v != 0.0) {
+            const uint32_t e = ((k / F) << lg) | bl, f = k % F;
+            gl[(size_t)e * F + f] += (float)v;                   // this bin is the only writer of its entries
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+static size_t header_bytes() { return (size_t)(3 * (BIN_MAX_TOTAL + 64)) * sizeof(uint32_t); }
+
+extern "C" size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* d, int64_t n) {
+    if (!d || n <= 0) return 0;
+    return header_bytes() + (size_t)n * 8u * d->n_levels * (1u + d->n_features) * sizeof(uint32_t);
+}
+
+extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
+                                      int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(d, US_ERR_NULL, "us_hashgrid_bwd_binned: desc is NULL");
+    US_REQUIRE(d->n_levels >= 1 && d->n_levels <= US_MAX_LEVELS && (d->n_features == 1 || d->n_features == 2 || d->n_features == 4) &&
+               d->n_params == d->offset[d->n_levels] * d->n_features, US_ERR_CONFIG, "us_hashgrid_bwd_binned: bad descriptor");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(x && dL_dy && grad_params && workspace, US_ERR_NULL, "us_hashgrid_bwd_binned: NULL pointer");
+    US_REQUIRE((uint64_t)n * 8ull * d->n_levels < 0xFFFFFFFFull, US_ERR_SHAPE, "us_hashgrid_bwd_binned: n too large for 32-bit record ranks");
+    US_REQUIRE(workspace_bytes >= us_hashgrid_bwd_workspace_bytes(d, n), US_ERR_WORKSPACE,
+               "us_hashgrid_bwd_binned: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_bwd_workspace_bytes(d, n));
+    BinMap bm;
+    const int TB = make_binmap(d, &bm);
+    US_REQUIRE(TB <= BIN_MAX_TOTAL, US_ERR_CONFIG, "us_hashgrid_bwd_binned: %d bins > %d (table too large for this path)", TB, BIN_MAX_TOTAL);
+    const LevelTable t = make_table(d);
+    hipStream_t s = (hipStream_t)stream;
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
+    uint32_t* counts = (uint32_t*)workspace;
+    uint32_t* offsets = counts + (BIN_MAX_TOTAL + 64);
+    uint32_t* cursors = offsets + (BIN_MAX_TOTAL + 64);
+    uint32_t* rec = (uint32_t*)((char*)workspace + header_bytes());
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(BIN_MAX_TOTAL + 64) * sizeof(uint32_t), s);
+    if (e != hipSuccess) { us_set_error("us_hashgrid_bwd_binned: memset: %s", hipGetErrorString(e)); return (int)e; }
+    dim3 gridA((unsigned)us_cdiv(n, BIN_THREADS)), block(BIN_THREADS);
+    const uint32_t L = d->n_levels;
+#define LAUNCH_BIN(F)                                                                                                          \
+    hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);         \
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, (uint32_t)TB, offsets, cursors);                         \
+    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);          \
+    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), block, 0, s, t, bm, L, offsets, rec, grad_params);
+    switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
+#undef LAUNCH_BIN
+    US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
+    return US_OK;
+}

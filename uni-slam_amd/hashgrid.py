@@ -63,10 +63,18 @@ class _HashGridFn(torch.autograd.Function):
                                                   L.ptr(gx), L.stream()), "us_hashgrid_bwd_input")
         if ctx.needs_input_grad[1]:
             gp = torch.zeros(desc.n_params, dtype=torch.float32, device=x.device)
-            # the table-gradient kernel streams one level at a time: hand it level-major planes [L][N][F]
-            dy_lm = dy.view(n, desc.n_levels, desc.n_features).permute(1, 0, 2).contiguous()
-            L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(desc), L.ptr(x), L.ptr(dy_lm), n, L.ptr(gp), ctx.bwd_mode,
-                                                   ctx.flags | L.US_GRID_LEVEL_MAJOR, L.stream()), "us_hashgrid_bwd_params")
+            mode = ctx.bwd_mode
+            if mode == 3 or (mode == -1 and n >= 16384):
+                # bin once, accumulate in f64 (csrc/hashgrid_binned.hip); scratch comes from torch's caching allocator
+                nbytes = int(L.lib().us_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), n))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp), ctx.flags, L.ptr(ws),
+                                                       nbytes, L.stream()), "us_hashgrid_bwd_binned")
+            else:
+                # the sliced kernel streams one level at a time: hand it level-major planes [L][N][F]
+                dy_lm = dy.view(n, desc.n_levels, desc.n_features).permute(1, 0, 2).contiguous()
+                L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(desc), L.ptr(x), L.ptr(dy_lm), n, L.ptr(gp), mode,
+                                                       ctx.flags | L.US_GRID_LEVEL_MAJOR, L.stream()), "us_hashgrid_bwd_params")
         return gx, gp, None, None, None
 
 
@@ -86,7 +94,7 @@ class HashGridEncoding(nn.Module):
                                    int(c.get("log2_hashmap_size", 19)), int(c.get("base_resolution", 16)),
                                    float(c.get("per_level_scale", 2.0)))
         self.n_output_dims = self.desc.n_levels * self.desc.n_features
-        self.bwd_mode = -1              # -1 auto | 0 global atomics | 1 LDS slices   (us_hashgrid_bwd_params)
+        self.bwd_mode = -1              # -1 auto | 0 global atomics | 1 LDS slices | 2 slices+compaction | 3 binned f64
         self.clamp_input = False        # Decoders sets this to fold its torch.clamp(p, 0, 1) into the kernel
         g = torch.Generator().manual_seed(seed)
         # tcnn initialises grid parameters U(-1e-4, 1e-4) from a pcg32 stream seeded 1337; same distribution here,

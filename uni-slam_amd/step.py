@@ -135,6 +135,10 @@ class MapStep:
         self.partials = f(int(L.lib().us_loss_partials_size(R)))
         self.stats, self.loss = f(10), f(1)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
+        lib = L.lib()
+        self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
+                            int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
 
     def _timed(self, name, rc_fn):
         """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
@@ -215,10 +219,16 @@ class MapStep:
                                                           off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1, st))
         self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                             N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, st))
-        self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
-                                                                          off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
-        self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
-                                                                            off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
+        if self.ws is not None:
+            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
+                                                                              3, P(self.ws), self.ws_bytes, st))
+            self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
+                                                                                3, P(self.ws), self.ws_bytes, st))
+        else:
+            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
+                                                                              off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
+            self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
+                                                                                off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
         self.n_rays = R
         return self.loss
 
