@@ -14,15 +14,18 @@
 //                     bin = entry index mod n_bins(level): interleaving makes bins equally loaded whatever the geometry.
 //   scan              exclusive scan of the bin counts -> exact, gap-free record ranges (no over-allocation, no overflow).
 //   A1 k_bin<WRITE>   same pass again, now writing {local entry, F values} records into their bin's range.
-//   B  k_bin_accum    one workgroup per bin: 128 KiB of f64 accumulators in LDS, ds_add_f64 over the bin's records, then a
+//   B  k_bin_accum    one 256-thread workgroup per bin: 32 KiB of f64 accumulators in LDS (thousands of bins, ~5 resident
+//                     workgroups per CU, 8 record loads in flight per thread), ds_add_f64 over the bin's records, then a
 //                     plain (non-atomic) add into the gradient table: a bin owns its entries exclusively.
 // Sums are formed in double precision; the only global atomics left are the per-workgroup bin-cursor reservations.
 #include "hashgrid_dev.h"
 #include <string.h>
 
-#define BIN_THREADS 1024
-#define BIN_MAX_TOTAL 2048               // bins over all levels (LDS counters: 2 x 8 KiB)
-#define BIN_ACC_DOUBLES 16384            // 128 KiB of f64 accumulators per bin
+#define BIN_THREADS 1024                 // binning kernels: 1024 consecutive points per workgroup
+#define BIN_MAX_TOTAL 4096               // bins over all levels (LDS counters: 2 x 16 KiB)
+#define BIN_ACC_DOUBLES 4096             // 32 KiB of f64 accumulators per bin -> ~5 accumulate workgroups per CU
+#define ACC_THREADS 256
+#define ACC_UNROLL 8                     // record loads in flight per thread (the accumulate kernel is a latency-bound stream)
 
 struct BinMap {
     uint32_t first[US_MAX_LEVELS + 1];   // prefix sum of bins per level
@@ -31,15 +34,22 @@ struct BinMap {
 
 static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
 
-static int make_binmap(const us_grid_desc* d, BinMap* bm) {
+// bins per level: enough for the f64 slice to fit the LDS budget (capacity) AND enough to keep every bin near
+// BIN_TARGET_RECORDS records whatever the level's size (a 4096-entry level receives as many records as a 4 MiB one)
+#define BIN_TARGET_RECORDS 8192
+static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
     uint32_t total = 0;
     const uint32_t be = bin_entries(d->n_features);
+    uint32_t want = 0;
+    while (((int64_t)BIN_TARGET_RECORDS << want) < n * 8 && want < 8) ++want;
     for (uint32_t l = 0; l < US_MAX_LEVELS; ++l) {
         bm->first[l] = total; bm->log2nb[l] = 0;
         if (l >= d->n_levels) continue;
         const uint32_t hs = d->offset[l + 1] - d->offset[l];
         uint32_t lg = 0;
-        while (((uint64_t)be << lg) < hs) ++lg;
+        while (((uint64_t)be << lg) < hs) ++lg;                  // capacity
+        if (lg < want) lg = want;                                // load
+        while (lg > 0 && (1u << lg) > hs) --lg;                  // never more bins than entries
         bm->log2nb[l] = (uint8_t)lg;
         total += 1u << lg;
     }
@@ -114,14 +124,15 @@ __device__ __forceinline__ void level_records(const LevelGeom& g, const float xv
     r.tail = live & next_is_head;
 }
 
-// A0 (WRITE = false): counts[bin] += records ;  A1 (WRITE = true): records written at cursors (initialised to the scan)
+// A0 (WRITE = false): counts[bin] += records of this workgroup (one flush at the end).
+// A1 (WRITE = true) : per level: count in LDS -> reserve the workgroup's share of every bin from the global cursors
+//                     (initialised to the scan) -> store the records, which stayed in registers meanwhile.
 template <int F, bool WRITE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, uint32_t n_levels, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                      uint32_t* __restrict__ rec) {
     __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
-    __shared__ uint32_t lbase[BIN_MAX_TOTAL];
     const uint32_t TB = bm.first[n_levels];
     for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0;
     __syncthreads();
@@ -134,72 +145,92 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
 #pragma unroll
         for (int k = 0; k < 3; ++k) xv[k] = load_x(x, i, k, clamp);
     }
-    // two sweeps over the levels: first local bin counts, then (WRITE) ranks + stores.  Hashing twice is cheap;
-    // keeping 16 levels x 8 records in registers is not possible.
-    for (int sweep = 0; sweep < (WRITE ? 2 : 1); ++sweep) {
-        for (uint32_t level = 0; level < n_levels; ++level) {
-            const LevelGeom g = level_geom(tab, level);
-            const uint32_t nbm1 = (1u << bm.log2nb[level]) - 1u, lg = bm.log2nb[level], first = bm.first[level];
-            float dy[F]; bool live = false;
+    // all levels' gradients of this point are fetched up front (one memory round trip instead of one per level)
+    constexpr int LCH = 16;
+    float dyv[LCH][F];
+    for (uint32_t level = 0; level < n_levels; ++level) {
+        if ((level % LCH) == 0) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) dy[f] = 0.0f;
-            if (in) {
+            for (int q = 0; q < LCH; ++q)
 #pragma unroll
-                for (int f = 0; f < F; ++f) { dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f]; live |= (dy[f] != 0.0f); }
+                for (int f = 0; f < F; ++f)
+                    dyv[q][f] = (in && level + q < n_levels) ? dL_dy[feat_index(lm, i, n, level + q, C, F) + f] : 0.0f;
+        }
+        const LevelGeom g = level_geom(tab, level);
+        const uint32_t nb = 1u << bm.log2nb[level], lg = bm.log2nb[level], first = bm.first[level];
+        float dy[F]; bool live = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) dy[f] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < LCH; ++q)                           // static register indexing (level % LCH is wave-uniform)
+            if ((int)(level % LCH) == q) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) { dy[f] = dyv[q][f]; live |= (dy[f] != 0.0f); }
             }
-            if (__ballot(live) == 0ull) continue;               // whole wave has zero gradient on this level
-            LevelRecords<F> r;
-            level_records<F>(g, xv, dy, live, lane, r);
+        LevelRecords<F> r;
+        uint32_t rank[8];
+        bool emit[8];
+        const bool wave_live = __ballot(live) != 0ull;           // a wave whose samples all have zero gradient skips the hashing
+        if (wave_live) level_records<F>(g, xv, dy, live, lane, r);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            emit[c] = false; rank[c] = 0;
+            if (!wave_live) continue;
+            bool nz = false;
+#pragma unroll
+            for (int f = 0; f < F; ++f) nz |= (r.val[c][f] != 0.0f);
+            const bool e = r.tail & nz;
+            emit[c] = e;
+            const unsigned long long mask = __ballot(e);
+            if (mask == 0ull) continue;
+            const uint32_t b = first + (r.idx[c] & (nb - 1u));
+            // rank inside the workgroup's share of the bin.  Fast path: every emitting lane of the wave hits the same
+            // bin: one LDS atomic for the wave instead of <= 64 serialised ones.
+            const int lead = __ffsll((long long)mask) - 1;
+            const uint32_t b0 = __builtin_amdgcn_readlane(b, lead);
+            if (__ballot(e && b == b0) == mask) {
+                uint32_t base = 0;
+                const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
+                base = __builtin_amdgcn_readlane(base, lead);
+                rank[c] = base + mb;
+            } else if (e) {
+                rank[c] = atomicAdd(&lcnt[b], 1u);
+            }
+        }
+        if (WRITE) {
+            __syncthreads();                                     // this level's local counts are complete
+            for (uint32_t t = threadIdx.x; t < nb; t += BIN_THREADS) {
+                const uint32_t c = lcnt[first + t];
+                lcnt[first + t] = c ? atomicAdd(&cursors[first + t], c) : 0u;      // count -> global base of our share
+            }
+            __syncthreads();
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                bool nz = false;
-#pragma unroll
-                for (int f = 0; f < F; ++f) nz |= (r.val[c][f] != 0.0f);
-                const bool e = r.tail && nz;
-                const unsigned long long mask = __ballot(e);
-                if (mask == 0ull) continue;
-                const uint32_t b = first + (r.idx[c] & nbm1);
-                // rank inside the workgroup's share of the bin.  Fast path: every emitting lane of the wave hits the same
-                // bin (dense levels, one ray per wave): one LDS atomic for the wave instead of <= 64 serialised ones.
-                const uint32_t b0 = __builtin_amdgcn_readlane(b, __ffsll((long long)mask) - 1);
-                uint32_t rank = 0;
-                if (__ballot(e && b == b0) == mask) {
-                    uint32_t base = 0;
-                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
-                    base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
-                    rank = base + mb;
-                } else if (e) {
-                    rank = atomicAdd(&lcnt[b], 1u);
-                }
-                if (WRITE && sweep == 1 && e) {
-                    uint32_t* dst = rec + (size_t)(lbase[b] + rank) * (1 + F);
+                if (emit[c]) {
+                    uint32_t* dst = rec + (size_t)(lcnt[first + (r.idx[c] & (nb - 1u))] + rank[c]) * (1 + F);
                     dst[0] = r.idx[c] >> lg;
 #pragma unroll
                     for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(r.val[c][f]);
                 }
             }
         }
+    }
+    if (!WRITE) {
         __syncthreads();
-        if (sweep == 0) {
-            for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) {
-                const uint32_t c = lcnt[t];
-                if (WRITE) { lbase[t] = c ? atomicAdd(&cursors[t], c) : 0u; lcnt[t] = 0; }
-                else if (c) atomicAdd(&counts[t], c);
-            }
-            __syncthreads();
-        }
+        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) { const uint32_t c = lcnt[t]; if (c) atomicAdd(&counts[t], c); }
     }
 }
 
-// exclusive scan of counts[0..TB) -> offsets[0..TB], cursors[t] = offsets[t]
+// exclusive scan of counts[0..TB) -> offsets[0..TB], cursors[t] = offsets[t]   (TB <= 4096: 4 elements per thread)
 __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
                                                    uint32_t* __restrict__ cursors) {
-    __shared__ uint32_t sh[BIN_MAX_TOTAL];
+    __shared__ uint32_t sh[1024];
     const uint32_t t = threadIdx.x;
-    // two elements per thread
-    const uint32_t a = (2 * t < TB) ? counts[2 * t] : 0u, b = (2 * t + 1 < TB) ? counts[2 * t + 1] : 0u;
-    sh[t] = a + b;
+    uint32_t c[4], s4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = (4 * t + k < TB) ? counts[4 * t + k] : 0u; s4 += c[k]; }
+    sh[t] = s4;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
         const uint32_t v = (t >= o) ? sh[t - o] : 0u;
@@ -207,15 +238,18 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
         sh[t] += v;
         __syncthreads();
     }
-    const uint32_t excl = sh[t] - (a + b);
-    if (2 * t < TB) { offsets[2 * t] = excl; cursors[2 * t] = excl; }
-    if (2 * t + 1 < TB) { offsets[2 * t + 1] = excl + a; cursors[2 * t + 1] = excl + a; }
+    uint32_t run = sh[t] - s4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (4 * t + k < TB) { offsets[4 * t + k] = run; cursors[4 * t + k] = run; }
+        run += c[k];
+    }
     if (t == 1023) offsets[TB] = sh[1023];
 }
 
 // B: one workgroup per bin
 template <int F>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels,
+__global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ rec,
                                                            float* __restrict__ grad) {
     __shared__ double acc[BIN_ACC_DOUBLES];
@@ -227,17 +261,40 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_accum(LevelTable tab, BinMa
     const uint32_t r0 = offsets[b], r1 = offsets[b + 1];
     if (r0 == r1) return;                                        // nothing landed in this bin (wave-uniform)
     const uint32_t n_local = bl < hs ? ((hs - 1u - bl) >> lg) + 1u : 0u;      // entries e with (e & (nb-1)) == bl
-    for (uint32_t k = threadIdx.x; k < n_local * F; k += BIN_THREADS) acc[k] = 0.0;
+    for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) acc[k] = 0.0;
     __syncthreads();
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += BIN_THREADS) {
-        const uint32_t* src = rec + (size_t)r * (1 + F);
-        const uint32_t loc = src[0];
+    for (uint32_t base = r0; base < r1; base += ACC_THREADS * ACC_UNROLL) {
+        uint32_t loc[ACC_UNROLL]; float v[ACC_UNROLL][F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&acc[loc * F + f], (double)__uint_as_float(src[1 + f]));   // ds_add_f64
+        for (int u = 0; u < ACC_UNROLL; ++u) {                   // issue every load of the group before the first use
+            const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
+            loc[u] = 0xFFFFFFFFu;
+            if (r < r1) {
+                const uint32_t* src = rec + (size_t)r * (1 + F);
+                loc[u] = src[0];
+#pragma unroll
+                for (int f = 0; f < F; ++f) v[u][f] = __uint_as_float(src[1 + f]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ACC_UNROLL; ++u) {
+            if (loc[u] != 0xFFFFFFFFu) {
+#if defined(US_EXP_B_NOATOMIC)
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[loc[u] * F + f] = (double)v[u][f];
+#elif defined(US_EXP_B_SPREAD)
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[((loc[u] + threadIdx.x * 7u) & (BIN_ACC_DOUBLES / F - 1)) * F + f], (double)v[u][f]);
+#else
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[loc[u] * F + f], (double)v[u][f]);            // ds_add_f64
+#endif
+            }
+        }
     }
     __syncthreads();
     float* gl = grad + (size_t)tab.off[level] * F;
-    for (uint32_t k = threadIdx.x; k < n_local * F; k += BIN_THREADS) {
+    for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) {
         const double v = acc[k];
         if (v != 0.0) {
             const uint32_t e = ((k / F) << lg) | bl, f = k % F;
@@ -267,7 +324,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     US_REQUIRE(workspace_bytes >= us_hashgrid_bwd_workspace_bytes(d, n), US_ERR_WORKSPACE,
                "us_hashgrid_bwd_binned: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_bwd_workspace_bytes(d, n));
     BinMap bm;
-    const int TB = make_binmap(d, &bm);
+    const int TB = make_binmap(d, n, &bm);
     US_REQUIRE(TB <= BIN_MAX_TOTAL, US_ERR_CONFIG, "us_hashgrid_bwd_binned: %d bins > %d (table too large for this path)", TB, BIN_MAX_TOTAL);
     const LevelTable t = make_table(d);
     hipStream_t s = (hipStream_t)stream;
@@ -284,7 +341,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);         \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, (uint32_t)TB, offsets, cursors);                         \
     hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);          \
-    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), block, 0, s, t, bm, L, offsets, rec, grad_params);
+    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), dim3(ACC_THREADS), 0, s, t, bm, L, offsets, rec, grad_params);
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
 #undef LAUNCH_BIN
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
