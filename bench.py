@@ -68,9 +68,15 @@ def cpu_baseline(bound, n_strat, n_imp, hidden, budget_s=15.0):
     """the CPU oracle port of the same iteration (oracle/unislam_oracle.py) on the host cores; bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unislam_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share of the host (oversubscribing its 256 hardware threads makes the CPU
+    # run ~40x slower); use what the scheduler really grants, at most 16
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ["OMP_NUM_THREADS"] = str(cores)           # read by libgomp when oracle/libhashgrid_ref.so is first used
     pls = per_level_scale(816)
     mk = lambda l2: O.HashGridOracle(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
                                          "log2_hashmap_size": l2, "base_resolution": 16, "per_level_scale": pls})
