@@ -127,10 +127,14 @@ int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64
                float* out, int64_t out_stride, int flags, void* stream);
 
 /* dL_din[N][n_in] (nullable) and grad_params += (nullable), from dL_dout[i*dout_stride + o].
- * `out` is the forward result (same layout as in us_mlp_fwd) used for the activation derivative. */
+ * `out` is the forward result (same layout as in us_mlp_fwd) used for the activation derivative.
+ * workspace (nullable, us_mlp_bwd_workspace_bytes(d) bytes): per-workgroup partial weight gradients are stored there and
+ * summed in a fixed order by a second small kernel (reproducible, no contended atomics); without it every workgroup adds
+ * its partial vector with one float atomic per parameter. */
+size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d);
 int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out, int64_t out_stride,
                const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, int flags,
-               void* stream);
+               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray sampling / points  (replaces src/utils/Renderer.py:81-101,132-137 and src/common.py:152-166 gather+rotate)

@@ -133,8 +133,8 @@ def test_level_major_layout_matches_row_major(us):
     dyo = torch.randn((n, 3), device=DEV, generator=g)
     dx_rm, dx_lm = torch.empty((n, 32), device=DEV), torch.empty((16, n, 2), device=DEV)
     g1, g2 = torch.zeros_like(p), torch.zeros_like(p)
-    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(rm), L.ptr(y_rm), 3, L.ptr(dyo), 3, n, L.ptr(dx_rm), L.ptr(g1), 0, L.stream()), "mlpb")
-    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(lm), L.ptr(y_lm), 3, L.ptr(dyo), 3, n, L.ptr(dx_lm), L.ptr(g2), 1, L.stream()), "mlpb")
+    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(rm), L.ptr(y_rm), 3, L.ptr(dyo), 3, n, L.ptr(dx_rm), L.ptr(g1), 0, None, 0, L.stream()), "mlpb")
+    L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(lm), L.ptr(y_lm), 3, L.ptr(dyo), 3, n, L.ptr(dx_lm), L.ptr(g2), 1, None, 0, L.stream()), "mlpb")
     assert torch.equal(dx_lm.permute(1, 0, 2).reshape(n, 32), dx_rm)
     assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5 * g1.abs().max().item())
 

@@ -55,7 +55,8 @@ SIGNATURES = {
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),
     "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_int, c_f]),
-    "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f]),
+    "us_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [_MP]),
+    "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_sample_z": (c_int, [c_f, c_i64, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt, c_f, c_f, c_f]),
     "us_ray_points": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f]),
     "us_ray_points_bwd": (c_int, [c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),

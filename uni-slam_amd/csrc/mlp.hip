@@ -255,30 +255,43 @@ __device__ __forceinline__ void bias_acc(v4f (&db)[MT], const v4f (&dh)[NQ][MT])
         for (int q = 0; q < NQ; ++q) db[m] += dh[q][m];
 }
 
-// flush a weight-gradient accumulator: tile (mo, mi) holds dW[16mo + 4g + r][16mi + row]
+// Weight-gradient hand-off.  Every wave holds a full set of partial dW tiles.  Letting each wave add them to the global
+// gradient made 2048 waves hammer the same ~3 K addresses with float atomics (measured: 190 of 240 us).  Instead the
+// waves of a workgroup are summed in LDS (one after the other: no LDS atomics), and the workgroup's vector goes either
+// to its row of a partials workspace (plain stores; k_mlp_reduce sums the rows in a fixed order) or, without a
+// workspace, to the gradient with ONE atomic per parameter per workgroup.
 template <int MO, int MI>
-__device__ __forceinline__ void flush_wgrad(float* gw, int K, const v4f (&acc)[MO][MI], int row, int g) {
+__device__ __forceinline__ void stage_wgrad(float* stage, int poff, int K, const v4f (&acc)[MO][MI], int row, int g, bool first) {
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[mo][mi][r];
-                if (v != 0.0f) atomicAdd(gw + (16 * mo + 4 * g + r) * K + 16 * mi + row, v);
+                float* d = stage + poff + (16 * mo + 4 * g + r) * K + 16 * mi + row;
+                *d = first ? acc[mo][mi][r] : *d + acc[mo][mi][r];
             }
 }
 
 template <int MT>
-__device__ __forceinline__ void flush_bgrad(float* gb, v4f (&db)[MT], int row, int g) {
+__device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT], int row, int g, bool first) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = db[m][r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (row == 0 && v != 0.0f) atomicAdd(gb + 16 * m + 4 * g + r, v);
+            if (row == 0) { float* d = stage + poff + 16 * m + 4 * g + r; *d = first ? v : *d + v; }
         }
+}
+
+// sum of the per-workgroup partial rows, fixed order -> bitwise reproducible decoder gradients
+__global__ __launch_bounds__(256) void k_mlp_reduce(const float* __restrict__ partials, int n_rows, int np, float* __restrict__ grad) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    float s = 0.0f;
+    for (int r = 0; r < n_rows; ++r) s += partials[(size_t)r * np + k];
+    grad[k] += s;
 }
 
 template <int NIN, int WIDTH, int NHID>
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
                                                          const float* __restrict__ out, int64_t out_stride,
                                                          const float* __restrict__ dL_dout, int64_t dout_stride,
                                                          int64_t n, float* __restrict__ dL_din,
-                                                         float* __restrict__ grad_params, int lm) {
+                                                         float* __restrict__ grad_params, int lm, float* __restrict__ partials) {
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
@@ -393,13 +406,27 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
         }
     }
     if (grad_params) {
-        flush_wgrad<C::MT, C::KB_IN>(grad_params + C::P_W0, NIN, gW0, row, g);
-        if (NHID == 2) flush_wgrad<C::MT, C::MT>(grad_params + C::P_WH, WIDTH, gWH, row, g);
-        flush_wgrad<1, C::MT>(grad_params + C::P_WL, WIDTH, gWL, row, g);
-        if (has_bias) {
-            flush_bgrad<C::MT>(grad_params + C::P_B0, gB0, row, g);
-            if (NHID == 2) flush_bgrad<C::MT>(grad_params + C::P_BH, gBH, row, g);
-            flush_bgrad<1>(grad_params + C::P_BL, gBL, row, g);
+        constexpr int NP = C::N_W + C::N_B;
+        static_assert(NP <= MLP_WAVES * C::SCR_PER_WAVE, "staging area");
+        float* stage = lds + C::L_SCR;                            // the scratch images are dead now
+        for (int w = 0; w < MLP_WAVES; ++w) {
+            __syncthreads();
+            if (wave == w) {
+                const bool first = (w == 0);
+                stage_wgrad<C::MT, C::KB_IN>(stage, C::P_W0, NIN, gW0, row, g, first);
+                if (NHID == 2) stage_wgrad<C::MT, C::MT>(stage, C::P_WH, WIDTH, gWH, row, g, first);
+                stage_wgrad<1, C::MT>(stage, C::P_WL, WIDTH, gWL, row, g, first);
+                stage_bgrad<C::MT>(stage, C::P_B0, gB0, row, g, first);
+                if (NHID == 2) stage_bgrad<C::MT>(stage, C::P_BH, gBH, row, g, first);
+                stage_bgrad<1>(stage, C::P_BL, gBL, row, g, first);
+            }
+        }
+        __syncthreads();
+        const int np = has_bias ? NP : C::N_W;
+        if (partials) {
+            for (int k = threadIdx.x; k < np; k += MLP_THREADS) partials[(size_t)blockIdx.x * np + k] = stage[k];
+        } else {
+            for (int k = threadIdx.x; k < np; k += MLP_THREADS) { const float v = stage[k]; if (v != 0.0f) atomicAdd(grad_params + k, v); }
         }
     }
 }
@@ -454,9 +481,15 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     return US_OK;
 }
 
+#define MLP_BWD_MAX_WG 256
+
+extern "C" size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d) {
+    return d ? (size_t)MLP_BWD_MAX_WG * us_mlp_n_params(d) * sizeof(float) : 0;
+}
+
 extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out,
                           int64_t out_stride, const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din,
-                          float* grad_params, int flags, void* stream) {
+                          float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream) {
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_bwd", d); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out && dout_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_bwd: stride < n_out");
@@ -465,10 +498,21 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     if (!dL_din && !grad_params) return US_OK;
     hipStream_t s = (hipStream_t)stream;
     const int pts = d->width == 64 ? 32 : 64;
-    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 512) nb = 512;
+    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;      // one workgroup per CU
     dim3 grid((unsigned)nb), block(MLP_THREADS);
+    float* partials = nullptr;
+    if (grad_params && workspace) {
+        US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(d), US_ERR_WORKSPACE, "us_mlp_bwd: workspace %zu B < %zu B",
+                   workspace_bytes, us_mlp_bwd_workspace_bytes(d));
+        partials = (float*)workspace;
+    }
     MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
-                 dout_stride, n, dL_din, grad_params, lm);
+                 dout_stride, n, dL_din, grad_params, lm, partials);
     US_CHECK_LAUNCH("us_mlp_bwd");
+    if (partials) {
+        const int np = (int)us_mlp_n_params(d);
+        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 256)), dim3(256), 0, s, partials, (int)nb, np, grad_params);
+        US_CHECK_LAUNCH("us_mlp_bwd(reduce)");
+    }
     return US_OK;
 }

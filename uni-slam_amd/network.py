@@ -54,8 +54,12 @@ class _MlpFn(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gp = torch.zeros_like(p) if ctx.needs_input_grad[1] else None
         if gx is not None or gp is not None:
+            ws, nbytes = None, 0
+            if gp is not None:
+                nbytes = int(L.lib().us_mlp_bwd_workspace_bytes(ctypes.byref(desc)))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(out), desc.n_out, L.ptr(dy),
-                                       desc.n_out, n, L.ptr(gx), L.ptr(gp), 0, L.stream()), "us_mlp_bwd")
+                                       desc.n_out, n, L.ptr(gx), L.ptr(gp), 0, L.ptr(ws), nbytes, L.stream()), "us_mlp_bwd")
         return gx, gp, None
 
 

@@ -139,6 +139,9 @@ class MapStep:
         self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
+        self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
+                                int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
+        self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
 
     def _timed(self, name, rc_fn):
         """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
@@ -216,9 +219,10 @@ class MapStep:
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, st), "us_composite_bwd")
         self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1, st))
+                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                          P(self.mlp_ws), self.mlp_ws_bytes, st))
         self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                            N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, st))
+                                                            N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
         if self.ws is not None:
             self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
                                                                               3, P(self.ws), self.ws_bytes, st))
