@@ -30,7 +30,14 @@
 struct BinMap {
     uint32_t first[US_MAX_LEVELS + 1];   // prefix sum of bins per level
     uint8_t  log2nb[US_MAX_LEVELS];      // bins per level = 1 << log2nb
+    uint8_t  shift[US_MAX_LEVELS];       // > 0: BLOCKED bins (bin = entry >> shift, local = entry & mask): hashed levels, whose
+                                         //      entries are already uniformly loaded -> the slice is a contiguous table range
+                                         // = 0: INTERLEAVED bins (bin = entry & (nb-1), local = entry >> log2nb): dense levels,
+                                         //      where geometry concentrates the hits in a few places
 };
+
+__device__ __forceinline__ uint32_t bin_of(uint32_t e, uint32_t lg, uint32_t sh) { return sh ? (e >> sh) : (e & ((1u << lg) - 1u)); }
+__device__ __forceinline__ uint32_t local_of(uint32_t e, uint32_t lg, uint32_t sh) { return sh ? (e & ((1u << sh) - 1u)) : (e >> lg); }
 
 static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
 
@@ -43,7 +50,7 @@ static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
     uint32_t want = 0;
     while (((int64_t)BIN_TARGET_RECORDS << want) < n * 8 && want < 8) ++want;
     for (uint32_t l = 0; l < US_MAX_LEVELS; ++l) {
-        bm->first[l] = total; bm->log2nb[l] = 0;
+        bm->first[l] = total; bm->log2nb[l] = 0; bm->shift[l] = 0;
         if (l >= d->n_levels) continue;
         const uint32_t hs = d->offset[l + 1] - d->offset[l];
         uint32_t lg = 0;
@@ -51,6 +58,12 @@ static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
         if (lg < want) lg = want;                                // load
         while (lg > 0 && (1u << lg) > hs) --lg;                  // never more bins than entries
         bm->log2nb[l] = (uint8_t)lg;
+        // hashed level <=> the slab holds exactly 2^log2T entries and the dense grid would not fit (tcnn grid_index)
+        const uint64_t res = d->resolution[l];
+        const bool hashed = (hs == (1u << d->log2_hashmap_size)) && (res * res * res > hs);
+        uint32_t sh = 0;
+        if (hashed && lg > 0) { while ((1u << (sh + lg)) < hs) ++sh; }       // hs is a power of two here: hs >> lg entries per bin
+        bm->shift[l] = (uint8_t)sh;
         total += 1u << lg;
     }
     bm->first[US_MAX_LEVELS] = total;
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
                     dyv[q][f] = (in && level + q < n_levels) ? dL_dy[feat_index(lm, i, n, level + q, C, F) + f] : 0.0f;
         }
         const LevelGeom g = level_geom(tab, level);
-        const uint32_t nb = 1u << bm.log2nb[level], lg = bm.log2nb[level], first = bm.first[level];
+        const uint32_t nb = 1u << bm.log2nb[level], lg = bm.log2nb[level], first = bm.first[level], sh = bm.shift[level];
         float dy[F]; bool live = false;
 #pragma unroll
         for (int f = 0; f < F; ++f) dy[f] = 0.0f;
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
             emit[c] = e;
             const unsigned long long mask = __ballot(e);
             if (mask == 0ull) continue;
-            const uint32_t b = first + (r.idx[c] & (nb - 1u));
+            const uint32_t b = first + bin_of(r.idx[c], lg, sh);
             // rank inside the workgroup's share of the bin.  Fast path: every emitting lane of the wave hits the same
             // bin: one LDS atomic for the wave instead of <= 64 serialised ones.
             const int lead = __ffsll((long long)mask) - 1;
@@ -208,8 +221,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (emit[c]) {
-                    uint32_t* dst = rec + (size_t)(lcnt[first + (r.idx[c] & (nb - 1u))] + rank[c]) * (1 + F);
-                    dst[0] = r.idx[c] >> lg;
+                    uint32_t* dst = rec + (size_t)(lcnt[first + bin_of(r.idx[c], lg, sh)] + rank[c]) * (1 + F);
+                    dst[0] = local_of(r.idx[c], lg, sh);
 #pragma unroll
                     for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(r.val[c][f]);
                 }
@@ -260,7 +273,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
     const uint32_t hs = tab.off[level + 1] - tab.off[level];
     const uint32_t r0 = offsets[b], r1 = offsets[b + 1];
     if (r0 == r1) return;                                        // nothing landed in this bin (wave-uniform)
-    const uint32_t n_local = bl < hs ? ((hs - 1u - bl) >> lg) + 1u : 0u;      // entries e with (e & (nb-1)) == bl
+    const uint32_t sh = bm.shift[level];
+    const uint32_t n_local = sh ? (1u << sh) : (bl < hs ? ((hs - 1u - bl) >> lg) + 1u : 0u);   // entries owned by this bin
     for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) acc[k] = 0.0;
     __syncthreads();
     for (uint32_t base = r0; base < r1; base += ACC_THREADS * ACC_UNROLL) {
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
     for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) {
         const double v = acc[k];
         if (v != 0.0) {
-            const uint32_t e = ((k / F) << lg) | bl, f = k % F;
+            const uint32_t e = sh ? ((bl << sh) | (k / F)) : (((k / F) << lg) | bl), f = k % F;
             gl[(size_t)e * F + f] += (float)v;                   // this bin is the only writer of its entries
         }
     }
