@@ -173,10 +173,12 @@ int us_composite_fwd(const float* raw, const float* z_vals, const float* beta, i
                      float* term, float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* weights,
                      void* stream);
 /* upstream per-ray grads (any may be NULL = zero) + direct grad on the returned sdf[R][S] (nullable);
- * d_raw[R][S][4] written, d_beta[1] accumulated (+=). */
+ * d_raw[R][S][4] written, d_beta[1] accumulated (+=).  beta_partials (nullable, R floats of scratch): per-ray beta
+ * gradients are stored there and summed in a fixed order instead of R float atomics on one address. */
 int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
                      const float* g_term, const float* g_unc, const float* g_depth, const float* g_rgb,
-                     const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, void* stream);
+                     const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, float* beta_partials,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Uncertainty-gated losses  (replaces src/Mapper.py:141-175,411-440 and src/Tracker.py:113-147,206-238)

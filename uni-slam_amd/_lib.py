@@ -63,7 +63,7 @@ SIGNATURES = {
     "us_bbox_filter": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),
     "us_gather_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_int, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f]),
     "us_composite_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    "us_composite_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_composite_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_loss_partials_size": (ctypes.c_size_t, [c_i64]),
     "us_loss_stats": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, c_f, c_f, c_f]),
     "us_loss_grad": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, _HF, c_f,

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
                                                        const float* __restrict__ g_term, const float* __restrict__ g_unc,
                                                        const float* __restrict__ g_depth, const float* __restrict__ g_rgb,
                                                        const float* __restrict__ g_dunc, const float* __restrict__ g_sdf,
-                                                       float* __restrict__ d_raw, float* __restrict__ d_beta) {
+                                                       float* __restrict__ d_raw, float* __restrict__ d_beta,
+                                                       float* __restrict__ beta_partials) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -306,10 +307,23 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             dbeta_local += da * da_dbeta;
         }
     }
-    if (d_beta) {
+    if (beta_partials) {                              // one value per ray; k_beta_reduce sums them in a fixed order
+        dbeta_local = wave_sum(dbeta_local);
+        if (lane == 0) beta_partials[ray] = dbeta_local;
+    } else if (d_beta) {                              // fallback: R atomics on ONE address (contended: ~45 us at R = 4096)
         dbeta_local = wave_sum(dbeta_local);
         if (lane == 0 && dbeta_local != 0.f) atomicAdd(d_beta, dbeta_local);
     }
+}
+
+__global__ __launch_bounds__(1024) void k_beta_reduce(const float* __restrict__ partials, int64_t n, float* __restrict__ d_beta) {
+    __shared__ double sh[1024];
+    double acc = 0.0;
+    for (int64_t r = threadIdx.x; r < n; r += 1024) acc += (double)partials[r];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) d_beta[0] += (float)sh[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,18 +385,29 @@ __global__ __launch_bounds__(256) void k_loss_partials(int mode, const float* __
     }
 }
 
-// one workgroup, fixed summation order -> bitwise reproducible statistics
+// one workgroup, fixed summation order -> bitwise reproducible statistics (all 10 in one sweep over the rays)
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ partials, int64_t n_rays,
                                                       float* __restrict__ stats) {
-    __shared__ double sh[1024];
+    __shared__ double sh[LOSS_NSTAT][64];
+    double acc[LOSS_NSTAT];
+#pragma unroll
+    for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] = 0.0;
+    for (int64_t r = threadIdx.x; r < n_rays; r += 1024) {
+#pragma unroll
+        for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] += (double)partials[r * LOSS_NSTAT + k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
     for (int k = 0; k < LOSS_NSTAT; ++k) {
-        double acc = 0.0;
-        for (int64_t r = threadIdx.x; r < n_rays; r += 1024) acc += (double)partials[r * LOSS_NSTAT + k];
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) stats[k] = (float)sh[0];
-        __syncthreads();
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_NSTAT) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += sh[threadIdx.x][w];
+        stats[threadIdx.x] = (float)v;
     }
 }
 
@@ -542,16 +567,21 @@ extern "C" int us_composite_fwd(const float* raw, const float* z_vals, const flo
 
 extern "C" int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples,
                                 const float* g_term, const float* g_unc, const float* g_depth, const float* g_rgb,
-                                const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, void* stream) {
+                                const float* g_dunc, const float* g_sdf, float* d_raw, float* d_beta, float* beta_partials,
+                                void* stream) {
     if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(raw && z_vals && beta && d_raw, US_ERR_NULL, "us_composite_bwd: NULL pointer");
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_bwd: n_samples %d not in 1..128", n_samples);
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     if (n_samples <= 64)
-        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta);
+        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr);
     else
-        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta);
+        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr);
     US_CHECK_LAUNCH("us_composite_bwd");
+    if (d_beta && beta_partials) {
+        hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, beta_partials, n_rays, d_beta);
+        US_CHECK_LAUNCH("us_composite_bwd(beta)");
+    }
     return US_OK;
 }
 

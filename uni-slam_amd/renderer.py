@@ -61,9 +61,10 @@ class _CompositeFn(torch.autograd.Function):
         g_term, g_unc, g_depth, g_rgb, g_dunc = c(g_term), c(g_unc), c(g_depth), c(g_rgb), c(g_dunc)
         d_raw = torch.empty_like(raw)
         d_beta = torch.zeros(1, device=z.device) if ctx.needs_input_grad[2] else None
+        part = torch.empty(R, device=z.device) if d_beta is not None else None
         L.check(L.lib().us_composite_bwd(L.ptr(raw), L.ptr(z), L.ptr(b), R, S, L.ptr(g_term), L.ptr(g_unc),
                                          L.ptr(g_depth), L.ptr(g_rgb), L.ptr(g_dunc), None, L.ptr(d_raw),
-                                         L.ptr(d_beta), L.stream()), "us_composite_bwd")
+                                         L.ptr(d_beta), L.ptr(part), L.stream()), "us_composite_bwd")
         return d_raw, None, d_beta
 
 

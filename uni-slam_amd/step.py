@@ -134,6 +134,7 @@ class MapStep:
         self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
         self.partials = f(int(L.lib().us_loss_partials_size(R)))
         self.stats, self.loss = f(10), f(1)
+        self.beta_part = f(R)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
         lib = L.lib()
         self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
@@ -217,7 +218,7 @@ class MapStep:
         self.grad.zero_()
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
-                                     P(self.g_sdf), P(self.d_raw), gbeta, st), "us_composite_bwd")
+                                     P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
         self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                           off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
                                                           P(self.mlp_ws), self.mlp_ws_bytes, st))
