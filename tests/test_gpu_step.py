@@ -140,3 +140,43 @@ def test_mapstep_bench_shape_runs_and_decreases_loss():
     ro, rd, gd, gc = _rays(4096, seed=2)
     losses = [float(step.iterate(ro, rd, gd, gc, has_zero_depth=False)) for _ in range(20)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("mode", ["original", "no_mask"])
+def test_trackstep_reproduces_reference_tracking_iteration(golden, mode):
+    """TrackStep.iterate against the fixture captured from the reference's Tracker.optimize_tracking (g8)."""
+    import unislam_amd as us
+    g = golden("g8_tracking")
+    T = torch.from_numpy
+    H, Wd, fx, fy, cx, cy = g["intr"]; H, Wd = int(H), int(Wd)
+    eh, ew = int(g["edge"][0]), int(g["edge"][1])
+    cfg = _cfg(False)
+    dec = us.Decoders(cfg, c_dim=32, truncation=0.06)
+    dec.load_state_dict({k[len("dec__"):].replace("__", "."): T(v) for k, v in g.items() if k.startswith("dec__")})
+    dec = dec.to(DEV)
+    ecfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 10, "base_resolution": 16,
+            "per_level_scale": O.per_level_scale(64)}
+    es, ec = us.HashGridEncoding(3, ecfg).to(DEV), us.HashGridEncoding(3, ecfg).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(T(g["grid_s"])); ec.params.copy_(T(g["grid_c"]))
+    pose = T(g["pose"]).to(DEV).clone().requires_grad_(True)
+    opt = torch.optim.SGD([pose], lr=0.0)
+    ts = us.TrackStep(es, ec, dec, BOUND, 32, 8, 0.06, dict(fs=10, center=200, tail=50, color=5, depth=1), mask_mode=mode, max_rays=16)
+    torch.manual_seed(int(g["seed"]))
+    n = int(g["n"])
+    idx = torch.randint((H - 2 * eh) * (Wd - 2 * ew), (n,))                 # the reference's CPU draw
+    # the reference jitters only the rays that pass the pre-filter; replay its draw onto those rows
+    c2w = us.common.cam_pose_to_matrix(pose.detach())
+    wi = Wd - 2 * ew
+    i = (ew + idx % wi).float()[None].to(DEV); j = (eh + idx // wi).float()[None].to(DEV)
+    ro, rd = us.common.get_rays_from_uv(i, j, c2w, H, Wd, fx, fy, cx, cy, DEV)
+    gd = T(g["gt_depth"])[0, eh:H - eh, ew:Wd - ew].reshape(-1)[idx].to(DEV)
+    inside = us.common.bbox_filter(ro.reshape(-1, 3), rd.reshape(-1, 3), gd, BOUND, require_depth=True)
+    t_rand = torch.zeros(n, 40)
+    t_rand[inside.cpu()] = torch.rand(int(inside.sum()), 40)
+    loss, unc, valid = ts.iterate(pose, T(g["gt_color"]).to(DEV), T(g["gt_depth"]).to(DEV), n, opt, H, Wd, fx, fy, cx, cy, eh, ew,
+                                  t_rand=t_rand.to(DEV), indices=idx.to(DEV))
+    assert torch.equal(valid.bool(), inside)
+    np.testing.assert_allclose(float(loss), float(g[f"{mode}_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(unc[valid.bool()].cpu().numpy(), g[f"{mode}_unc"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pose.grad.cpu().numpy(), g[f"{mode}_gpose"], rtol=5e-3, atol=5e-3)
