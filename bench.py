@@ -99,6 +99,49 @@ def cpu_baseline(bound, n_strat, n_imp, hidden, budget_s=15.0):
                       f"C hash grid with OpenMP + torch-CPU, {cores} threads), {el:.1f} s", "ms_per_iter": 1e3 * el / n}
 
 
+def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
+    """
+    secondary number (not the headline metric): one Tracker.optimize_tracking iteration (src/Tracker.py:149-244) at the
+    Replica settings -- 2000 rays x 40 samples (configs/Replica/replica.yaml:12, UNISLAM.yaml:88-89), 680x1200 frame,
+    ignore_edge 75, pose = Adam(lr_T 2e-3, lr_R 1e-3, betas (0.5, 0.999)) -- on the same room0 tables and decoders
+    """
+    H, Wd, fx, fy, cx, cy = 680, 1200, 600.0, 600.0, 599.5, 339.5
+    g = torch.Generator().manual_seed(5)
+    gt_depth = (torch.rand(1, H, Wd, generator=g) * 1.5 + 0.8).to(dev)
+    gt_color = torch.rand(1, H, Wd, 3, generator=g).to(dev)
+    centre = bound.mean(dim=1)
+    pose = torch.tensor([[0.9, 0.1, -0.2, 0.3, float(centre[0]), float(centre[1]), float(centre[2])]], device=dev)
+    quad = torch.nn.Parameter(pose[:, :4].clone()); T = torch.nn.Parameter(pose[:, 4:].clone())
+    opt = torch.optim.Adam([{"params": [T], "lr": 2e-3, "betas": (0.5, 0.999)}, {"params": [quad], "lr": 1e-3, "betas": (0.5, 0.999)}],
+                           capturable=True)
+    ts = us.TrackStep(es, ec, dec, bound, 32, 8, 0.06, dict(fs=10, center=200, tail=50, color=5, depth=1), max_rays=2000)
+    step = lambda: ts.iterate(torch.cat([quad, T], -1), gt_color, gt_depth, 2000, opt, H, Wd, fx, fy, cx, cy, 75, 75)
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss, _, _ = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    out = {"workload": "Replica tracking iteration: 2000 rays x 40 samples, pose Adam", "eager_ms_per_iter": ms,
+           "eager_rays_per_s": 2000 / (ms / 1e3), "iters": iters, "final_loss": float(loss)}
+    try:                                                  # the same iteration captured into a hipGraph and replayed
+        it = us.CapturedIteration(step)
+        for _ in range(10):
+            it.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss, _, _ = it.replay()
+        torch.cuda.synchronize()
+        gms = 1e3 * (time.perf_counter() - t0) / iters
+        out.update({"graph_ms_per_iter": gms, "graph_rays_per_s": 2000 / (gms / 1e3), "graph_final_loss": float(loss)})
+    except Exception as e:                                # report, do not hide
+        out["graph_error"] = repr(e)[:300]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +152,7 @@ def main():
     ap.add_argument("--bwd-mode", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true")
     args = ap.parse_args()
 
     import unislam_amd as us
@@ -185,6 +229,8 @@ def main():
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
                                "avg_launch_ms": kern[dom]}
+        if world == 1 and not args.no_tracking:
+            rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(bound, n_strat, n_imp, args.hidden)
         print(json.dumps(rec), flush=True)

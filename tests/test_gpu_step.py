@@ -180,3 +180,37 @@ def test_trackstep_reproduces_reference_tracking_iteration(golden, mode):
     np.testing.assert_allclose(float(loss), float(g[f"{mode}_loss"]), rtol=1e-4)
     np.testing.assert_allclose(unc[valid.bool()].cpu().numpy(), g[f"{mode}_unc"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(pose.grad.cpu().numpy(), g[f"{mode}_gpose"], rtol=5e-3, atol=5e-3)
+
+
+def test_captured_tracking_iteration_equals_eager():
+    """hipGraph replay of TrackStep.iterate (incl. pose Adam) gives the eager trajectory"""
+    import unislam_amd as us
+    dec, es, ec = _scene(us, False, seed=7)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    H, Wd, fx, fy, cx, cy = 60, 80, 40.0, 40.0, 39.5, 29.5
+    g = torch.Generator().manual_seed(2)
+    gt_depth = (torch.rand(1, H, Wd, generator=g) * 1.5 + 0.5).to(DEV); gt_color = torch.rand(1, H, Wd, 3, generator=g).to(DEV)
+    n = 256
+    idx = torch.randint((H - 8) * (Wd - 8), (n,), generator=g).to(DEV)
+    t_rand = torch.rand(n, 40, generator=g).to(DEV)
+    w = dict(fs=10, center=200, tail=50, color=5, depth=1)
+    poses = []
+    for captured in (False, True):
+        pose = torch.nn.Parameter(torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]], device=DEV))
+        opt = torch.optim.Adam([pose], lr=1e-3, betas=(0.5, 0.999), capturable=True)
+        ts = us.TrackStep(es, ec, dec, BOUND, 32, 8, 0.06, w, max_rays=n)
+        fn = lambda: ts.iterate(pose, gt_color, gt_depth, n, opt, H, Wd, fx, fy, cx, cy, 4, 4, t_rand=t_rand, indices=idx)
+        for _ in range(2):                                    # Adam's state must exist before a capture (else the capture
+            fn()                                              # records its zero-initialisation and every replay repeats it)
+        if captured:
+            it = us.CapturedIteration(fn, warmup=0)           # capturing does not execute: 3 replays = 3 more iterations
+            for _ in range(3):
+                loss, _, _ = it.replay()
+        else:
+            for _ in range(3):
+                loss, _, _ = fn()
+        poses.append((pose.detach().clone(), float(loss)))
+    assert torch.allclose(poses[0][0], poses[1][0], rtol=1e-5, atol=1e-6)
+    assert abs(poses[0][1] - poses[1][1]) <= 1e-4 * abs(poses[0][1])
+    assert not torch.allclose(poses[0][0], torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]], device=DEV))   # it moved
