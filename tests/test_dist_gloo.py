@@ -50,11 +50,14 @@ class OracleEngine:
         self._sums = sums
         self.stats = torch.stack([s.detach() for s in sums] + [c.float() for c in counts])
 
-    def backward(self):
+    def backward(self, on_ready=None):
         loss_local = sum(W[k] * self._sums[i] / self.stats[5 + i] for i, k in enumerate(WK))   # GLOBAL counts
         self.opt.zero_grad()
         loss_local.backward()
         self.grad = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+        if on_ready is not None:                        # announce two segments, like MapStep does (colour table first)
+            h = self.grad.numel() // 2
+            on_ready(self.grad[h:]); on_ready(self.grad[:h])
         return sum(W[k] * self.stats[i] / self.stats[5 + i] for i, k in enumerate(WK))
 
     def adam_step(self):

@@ -214,3 +214,25 @@ def test_captured_tracking_iteration_equals_eager():
     assert torch.allclose(poses[0][0], poses[1][0], rtol=1e-5, atol=1e-6)
     assert abs(poses[0][1] - poses[1][1]) <= 1e-4 * abs(poses[0][1])
     assert not torch.allclose(poses[0][0], torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]], device=DEV))   # it moved
+
+
+def test_mapstep_single_rank_process_group_matches_plain():
+    """the data-parallel code path (stats all-reduce, segment-wise async gradient all-reduce over RCCL) with world_size 1"""
+    import os
+    import torch.distributed as dist
+    import unislam_amd as us
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        outs = []
+        for group in (None, True):
+            dec, es, ec = _scene(us, False, seed=11)
+            step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=256, group=group)
+            ro, rd, gd, gc = _rays(256, seed=12)
+            t_rand = torch.rand(256, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
+            for _ in range(3):
+                loss = step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+            outs.append((step.flat.clone(), float(loss)))
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6) and abs(outs[0][1] - outs[1][1]) < 1e-5
+    finally:
+        dist.destroy_process_group()

@@ -11,7 +11,8 @@ the gradient of one process on the concatenated batch (tests/test_dist_gloo.py, 
 
 The engine protocol (MapStep implements it on the HIP kernels; the CPU test drives the same function with the oracle):
     engine.forward(*batch) -> fills engine.stats  (tensor[10]: 5 sums, 5 counts of the LOCAL rays)
-    engine.backward()      -> fills engine.grad   (flat tensor) using engine.stats; returns the loss tensor
+    engine.backward(on_ready=None) -> fills engine.grad (flat tensor) using engine.stats; returns the loss tensor;
+                           may call on_ready(view_of_grad) whenever a contiguous segment is final (enables overlap)
     engine.adam_step()     -> applies the (reduced) gradient
 """
 import os
@@ -25,13 +26,29 @@ def _pg(group):
 
 
 def dp_iterate(engine, batch, group=None):
-    """One optimiser step. group: None (single process) | True (default process group) | a process group."""
+    """
+    One optimiser step. group: None (single process) | True (default process group) | a process group.
+
+    Overlap: engine.backward(on_ready) calls on_ready(view) as soon as a contiguous segment of engine.grad is final; each
+    segment's all-reduce is issued asynchronously right then (RCCL runs it on its own stream, ordered after the kernels
+    launched so far) and overlaps with the rest of the backward pass.  MapStep finishes the 44.7 MB colour-table segment
+    first, so its reduction hides behind the SDF decoder + SDF table backward; all segments are waited for before Adam.
+    """
     engine.forward(*batch)
     if group is not None:
         dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
-    loss = engine.backward()
+    works = []
+
+    def on_ready(view):
+        if group is not None:
+            works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True))
+
+    loss = engine.backward(on_ready)
     if group is not None:
-        dist.all_reduce(engine.grad, op=dist.ReduceOp.SUM, group=_pg(group))
+        if not works:                                   # an engine that does not announce segments: one reduction at the end
+            dist.all_reduce(engine.grad, op=dist.ReduceOp.SUM, group=_pg(group))
+        for w in works:
+            w.wait()
     engine.adam_step()
     return loss
 

@@ -201,8 +201,12 @@ class MapStep:
         self._batch = (o, d, gd, gc, R)
         return self.stats
 
-    def backward(self):
-        """Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad."""
+    def backward(self, on_ready=None):
+        """
+        Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
+        The colour branch runs first; on_ready(view) is called when the colour-table segment, and at the end the
+        [decoders | beta | sdf table] segment, of self.grad are final (dist.dp_iterate overlaps their all-reduces).
+        """
         lib, st = L.lib(), L.stream()
         o, d, gd, gc, R = self._batch
         S, N = self.S, R * self.S
@@ -219,21 +223,28 @@ class MapStep:
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
-        self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
-                                                          P(self.mlp_ws), self.mlp_ws_bytes, st))
         self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                             N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
-        if self.ws is not None:
-            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                              3, P(self.ws), self.ws_bytes, st))
+        binned = self.ws is not None
+        if binned:
             self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
                                                                                 3, P(self.ws), self.ws_bytes, st))
         else:
-            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
-                                                                              off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
             self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                 off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
+        if on_ready is not None:
+            on_ready(self.grad[self.o_tab_c:])
+        self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
+                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                          P(self.mlp_ws), self.mlp_ws_bytes, st))
+        if binned:
+            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
+                                                                              3, P(self.ws), self.ws_bytes, st))
+        else:
+            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
+                                                                              off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
+        if on_ready is not None:
+            on_ready(self.grad[:self.o_tab_c])
         self.n_rays = R
         return self.loss
 
