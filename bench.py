@@ -139,6 +139,30 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
         out.update({"graph_ms_per_iter": gms, "graph_rays_per_s": 2000 / (gms / 1e3), "graph_final_loss": float(loss)})
     except Exception as e:                                # report, do not hide
         out["graph_error"] = repr(e)[:300]
+    try:                                                  # fully fused variant: pose->rays, pose gradient, pose Adam as HIP kernels
+        ts.begin_frame(pose[0], gt_color[0], gt_depth[0], 2e-3, 1e-3, H, Wd, fx, fy, cx, cy, 75, 75)
+        fstep = lambda: ts.iterate_fused(2000)
+        for _ in range(10):
+            fstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss, _, _ = fstep()
+        torch.cuda.synchronize()
+        fms = 1e3 * (time.perf_counter() - t0) / iters
+        out.update({"fused_eager_ms_per_iter": fms})
+        it = us.CapturedIteration(fstep)
+        for _ in range(10):
+            it.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss, _, _ = it.replay()
+        torch.cuda.synchronize()
+        fg = 1e3 * (time.perf_counter() - t0) / iters
+        out.update({"fused_graph_ms_per_iter": fg, "fused_graph_rays_per_s": 2000 / (fg / 1e3), "fused_final_loss": float(loss)})
+    except Exception as e:
+        out["fused_error"] = repr(e)[:300]
     return out
 
 

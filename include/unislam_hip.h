@@ -210,6 +210,26 @@ int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* 
 int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);
 
+/* the same with the 1-based step count in device memory (float[1]): nothing step-dependent is baked into the launch, so the
+ * call can sit inside a captured hipGraph (torch.optim.Adam(capturable=True) arithmetic: bias corrections in fp32) */
+int us_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                     double eps, const float* step_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tracking: camera pose -> rays  (replaces cam_pose_to_matrix src/common.py:196-208 + pytorch3d quaternion_to_matrix,
+ * get_sample_uv / select_uv / get_rays_from_uv src/common.py:95-150 as called by Tracker.optimize_tracking
+ * src/Tracker.py:170-174) and the adjoint that autograd provides there (src/Tracker.py:241)
+ * ---------------------------------------------------------------------------------------------- */
+/* pose[7] = (qr,qi,qj,qk, tx,ty,tz) device; pix[n] int64 = flat indices into the crop [H0:H1, W0:W1] of width crop_w;
+ * depth_img[H][W], color_img[H][W][3]; intr_host4 = {fx, fy, cx, cy}.  Writes rays_o/rays_d/dirs [n][3] (dirs = camera-frame
+ * directions, kept for the adjoint), gt_depth[n], gt_color[n][3]. */
+int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* intr_host4, int W0, int H0, int crop_w,
+                 const float* depth_img, const float* color_img, int W, float* rays_o, float* rays_d, float* dirs,
+                 float* gt_depth, float* gt_color, void* stream);
+/* g_pose[7] = dL/dpose from dL/d rays_o, dL/d rays_d (closed-form chain rule through R(q) = I + 2 M(q)/|q|^2) */
+int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n, float* g_pose,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

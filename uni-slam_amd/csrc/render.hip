@@ -471,6 +471,105 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Tracking: camera pose -> rays and the adjoint (src/common.py:95-107,196-208 + pytorch3d quaternion_to_matrix).
+// pose = (qr, qi, qj, qk, tx, ty, tz); R = I + s*M(q), s = 2/|q|^2; rays_d = R * dir_cam, rays_o = t.
+// ---------------------------------------------------------------------------------------------------------------
+struct Intr { float fx, fy, cx, cy; int W0, H0, wi; };
+
+__device__ __forceinline__ void quat_rot(const float* q, float R[9]) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1.f - s * (j * j + k * k); R[1] = s * (i * j - k * r); R[2] = s * (i * k + j * r);
+    R[3] = s * (i * j + k * r); R[4] = 1.f - s * (i * i + k * k); R[5] = s * (j * k - i * r);
+    R[6] = s * (i * k - j * r); R[7] = s * (j * k + i * r); R[8] = 1.f - s * (i * i + j * j);
+}
+
+// pixel index inside the crop -> (u, v) -> camera direction -> world ray; also gathers gt depth / colour of the pixel
+__global__ __launch_bounds__(256) void k_pose_rays(const float* __restrict__ pose, const int64_t* __restrict__ pix, int64_t n,
+                                                   Intr in, const float* __restrict__ depth_img, const float* __restrict__ color_img,
+                                                   int W, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                   float* __restrict__ dirs, float* __restrict__ gt_depth, float* __restrict__ gt_color) {
+    float R[9]; quat_rot(pose, R);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = pix[t];
+        const int u = in.W0 + (int)(p % in.wi), v = in.H0 + (int)(p / in.wi);
+        const float d0 = ((float)u - in.cx) / in.fx, d1 = -((float)v - in.cy) / in.fy, d2 = -1.0f;
+        dirs[t * 3] = d0; dirs[t * 3 + 1] = d1; dirs[t * 3 + 2] = d2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rays_d[t * 3 + k] = (d0 * R[k * 3] + d1 * R[k * 3 + 1]) + d2 * R[k * 3 + 2];
+            rays_o[t * 3 + k] = pose[4 + k];
+        }
+        const int64_t px = (int64_t)v * W + u;
+        gt_depth[t] = depth_img[px];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gt_color[t * 3 + k] = color_img[px * 3 + k];
+    }
+}
+
+// one workgroup: G = sum_rays g_d (x) dir, gt = sum_rays g_o, then the closed-form chain rule through R(q)
+__global__ __launch_bounds__(1024) void k_pose_grad(const float* __restrict__ pose, const float* __restrict__ g_o,
+                                                    const float* __restrict__ g_d, const float* __restrict__ dirs, int64_t n,
+                                                    float* __restrict__ g_pose) {
+    __shared__ double sh[12][16];
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    for (int64_t t = threadIdx.x; t < n; t += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float ga = g_d[t * 3 + a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[a * 3 + b] += (double)(ga * dirs[t * 3 + b]);
+            acc[9 + a] += (double)g_o[t * 3 + a];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float G[9], gt[3];
+        for (int k = 0; k < 12; ++k) { double v = 0.0; for (int w = 0; w < 16; ++w) v += sh[k][w]; if (k < 9) G[k] = (float)v; else gt[k - 9] = (float)v; }
+        const float r = pose[0], i = pose[1], j = pose[2], k = pose[3];
+        const float s = 2.0f / (r * r + i * i + j * j + k * k);
+        const float M[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k), j * k - i * r,
+                            i * k - j * r, j * k + i * r, -(i * i + j * j)};
+        const float dMr[9] = {0, -k, j, k, 0, -i, -j, i, 0};
+        const float dMi[9] = {0, j, k, j, -2 * i, -r, k, r, -2 * i};
+        const float dMj[9] = {-2 * j, i, r, i, 0, k, -r, k, -2 * j};
+        const float dMk[9] = {-2 * k, -r, i, r, -2 * k, j, i, j, 0};
+        float gm = 0, gr = 0, gi = 0, gj = 0, gk = 0;
+        for (int e = 0; e < 9; ++e) { gm += G[e] * M[e]; gr += G[e] * dMr[e]; gi += G[e] * dMi[e]; gj += G[e] * dMj[e]; gk += G[e] * dMk[e]; }
+        const float ds = -s * s;                                   // d s / d q_m = -s^2 q_m
+        g_pose[0] = ds * r * gm + s * gr; g_pose[1] = ds * i * gm + s * gi;
+        g_pose[2] = ds * j * gm + s * gj; g_pose[3] = ds * k * gm + s * gk;
+        g_pose[4] = gt[0]; g_pose[5] = gt[1]; g_pose[6] = gt[2];
+    }
+}
+
+// Adam with the step counter on the device (graph-capturable; torch.optim.Adam(capturable=True) arithmetic)
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                  const float* __restrict__ step_dev) {
+    const float step = step_dev[0];
+    const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);
+        const float vi = v[i] * b2 + ((1.0f - b2) * gi) * gi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = p[i] + (-step_size) * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 static unsigned grid_1d(int64_t n, int threads, int cap) {
@@ -636,5 +735,38 @@ extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_
     hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
     US_CHECK_LAUNCH("us_adam_step");
+    return US_OK;
+}
+
+extern "C" int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* intr_host4, int W0, int H0, int crop_w,
+                            const float* depth_img, const float* color_img, int W, float* rays_o, float* rays_d, float* dirs,
+                            float* gt_depth, float* gt_color, void* stream) {
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(pose && pix && intr_host4 && depth_img && color_img && rays_o && rays_d && dirs && gt_depth && gt_color, US_ERR_NULL,
+               "us_pose_rays: NULL pointer");
+    US_REQUIRE(crop_w >= 1 && W >= 1, US_ERR_SHAPE, "us_pose_rays: bad image shape");
+    Intr in; in.fx = intr_host4[0]; in.fy = intr_host4[1]; in.cx = intr_host4[2]; in.cy = intr_host4[3]; in.W0 = W0; in.H0 = H0; in.wi = crop_w;
+    hipLaunchKernelGGL(k_pose_rays, dim3(grid_1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, pose, pix, n, in, depth_img, color_img, W,
+                       rays_o, rays_d, dirs, gt_depth, gt_color);
+    US_CHECK_LAUNCH("us_pose_rays");
+    return US_OK;
+}
+
+extern "C" int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n, float* g_pose,
+                            void* stream) {
+    US_REQUIRE(pose && g_rays_o && g_rays_d && dirs && g_pose, US_ERR_NULL, "us_pose_grad: NULL pointer");
+    US_REQUIRE(n >= 1, US_ERR_SHAPE, "us_pose_grad: n < 1");
+    hipLaunchKernelGGL(k_pose_grad, dim3(1), dim3(1024), 0, (hipStream_t)stream, pose, g_rays_o, g_rays_d, dirs, n, g_pose);
+    US_CHECK_LAUNCH("us_pose_grad");
+    return US_OK;
+}
+
+extern "C" int us_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                double eps, const float* step_dev, void* stream) {
+    US_REQUIRE(p && g && m && v && step_dev, US_ERR_NULL, "us_adam_step_dev: NULL pointer");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    hipLaunchKernelGGL(k_adam_dev, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1,
+                       (float)beta2, (float)eps, step_dev);
+    US_CHECK_LAUNCH("us_adam_step_dev");
     return US_OK;
 }

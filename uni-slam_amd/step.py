@@ -417,3 +417,52 @@ class TrackStep:
         torch.autograd.backward([rays_o, rays_d], [g_o, g_d])
         optimizer.step()
         return loss, unc, valid
+
+    # ------------------------------------------------------------------------------------------ fully fused tracking
+    def begin_frame(self, pose7, gt_color, gt_depth, lr_T, lr_R, H, W, fx, fy, cx, cy, ignore_edge_H, ignore_edge_W,
+                    betas=(0.5, 0.999)):
+        """
+        Per-frame set-up of the fused tracking loop (Tracker.py:315-329): pose7 = (quaternion[4], translation[3]) initial
+        guess, gt_color [H,W,3], gt_depth [H,W]; a fresh Adam state for the two parameter groups (lr_R for the quaternion,
+        lr_T for the translation).  The buffers are static, so iterate_fused() can be captured into a hipGraph.
+        """
+        dev = self.device
+        if not hasattr(self, "pose"):
+            f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+            self.pose, self.g_pose, self.pm, self.pv, self.pstep = f(7), f(7), f(7), f(7), f(1)
+            self.img_d, self.img_c = torch.empty((H, W), device=dev), torch.empty((H, W, 3), device=dev)
+        self.pose.copy_(pose7.detach().reshape(7))
+        self.img_d.copy_(gt_depth.reshape(H, W)); self.img_c.copy_(gt_color.reshape(H, W, 3))
+        self.pm.zero_(); self.pv.zero_(); self.pstep.zero_()
+        self.lr_T, self.lr_R, self.betas = float(lr_T), float(lr_R), betas
+        self.frame = (H, W, ignore_edge_H, ignore_edge_W)
+        self.intr = L.host_floats([fx, fy, cx, cy])
+        self.refresh_parameters()
+
+    def iterate_fused(self, batch_size, t_rand=None, indices=None):
+        """
+        One Tracker.optimize_tracking call (Tracker.py:149-244) with everything on the device: pixel draw, pose -> rays
+        (us_pose_rays), render + loss + backward, rays -> pose gradient (us_pose_grad) and Adam on the 7 pose numbers
+        (us_adam_step_dev).  Returns (loss[1], pixel_unc[R], valid[R]); the updated pose is self.pose.
+        """
+        lib, st, P = L.lib(), L.stream(), L.ptr
+        H, W, eh, ew = self.frame
+        H0, H1, W0, W1 = eh, H - eh, ew, W - ew
+        n = int(batch_size)
+        if indices is None:
+            indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.device)              # common.py:116
+        if not hasattr(self, "t_ro") or self.t_ro.shape[0] != n:
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+            self.t_ro, self.t_rd, self.t_dirs, self.t_gd, self.t_gc = f(n, 3), f(n, 3), f(n, 3), f(n), f(n, 3)
+        L.check(lib.us_pose_rays(P(self.pose), P(indices.contiguous()), n, self.intr, W0, H0, W1 - W0, P(self.img_d), P(self.img_c), W,
+                                 P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
+        loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
+        L.check(lib.us_pose_grad(P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.g_pose), st), "us_pose_grad")
+        self.pstep.add_(1.0)
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        b1, b2 = self.betas
+        L.check(lib.us_adam_step_dev(P(self.pose), P(self.g_pose), P(self.pm), P(self.pv), 4, self.lr_R, b1, b2, 1e-8, P(self.pstep), st),
+                "us_adam_step_dev")
+        L.check(lib.us_adam_step_dev(off(self.pose, 4), off(self.g_pose, 4), off(self.pm, 4), off(self.pv, 4), 3, self.lr_T, b1, b2, 1e-8,
+                                     P(self.pstep), st), "us_adam_step_dev")
+        return loss, unc, valid
