@@ -297,3 +297,78 @@ def test_fused_tracking_matches_autograd_tracking():
         # Adam's first steps are +-lr per coordinate whatever the gradient size: the two trajectories stay within a few lr
         assert (ts_b.pose - pa).abs().max().item() <= 2.5 * 2e-3 * (k + 1)
         np.testing.assert_allclose(float(lb), float(la), rtol=2e-2)
+
+
+def test_mapstep_reproduces_reference_optimize_mapping(golden):
+    """MapStep driven like Mapper.optimize_mapping (first frame, 2 iterations incl. Adam) against the reference fixture g9"""
+    import unislam_amd as us
+    g = golden("g9_mapping")
+    T = torch.from_numpy
+    H, Wd, fx, fy, cx, cy = g["intr"]; H, Wd = int(H), int(Wd)
+    dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06)
+    dec.load_state_dict({k[len("dec0__"):].replace("__", "."): T(v) for k, v in g.items() if k.startswith("dec0__")})
+    dec = dec.to(DEV)
+    ecfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 10, "base_resolution": 16,
+            "per_level_scale": O.per_level_scale(64)}
+    es, ec = us.HashGridEncoding(3, ecfg).to(DEV), us.HashGridEncoding(3, ecfg).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(T(g["grid_s0"])); ec.params.copy_(T(g["grid_c0"]))
+    gt_depth, gt_color, c2w = T(g["gt_depth"]), T(g["gt_color"]), T(g["c2w"])
+    cam = O.get_camera_rays(H, Wd, fx, fy, cx, cy)
+    torch.manual_seed(int(g["seed"]))                                         # the reference's CPU random stream
+    idx = torch.randperm(H * Wd)[:int(H * Wd * 0.1)]
+    pool_c, pool_d, pool_r = (gt_color.reshape(-1, 3)[idx][None].to(DEV), gt_depth.reshape(-1)[idx][None].to(DEV),
+                              cam.reshape(-1, 3)[idx][None].to(DEV))
+    n = int(g["pixels"])
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=n)
+    step.reset_optimizer(float(g["lr_factor"]))                               # lr_first_factor on the first frame (Mapper.py:520-525)
+    for _ in range(int(g["iters"])):
+        indices = torch.randint(pool_d.shape[1], (n,)).reshape(1, -1)
+        ro, rd, gd, gc = us.common.get_samples_all(0, H, 0, Wd, n, H, Wd, fx, fy, cx, cy, c2w[None].to(DEV), pool_d, pool_c, DEV, pool_r,
+                                                   indices=indices.to(DEV))
+        inside = us.common.bbox_filter(ro, rd, gd, BOUND).cpu()
+        n_depth = int(((gd.cpu() > 0) & inside).sum()); n_zero = int(((gd.cpu() <= 0) & inside).sum())
+        t_rand = torch.zeros(n, 40)
+        t_rand[((gd.cpu() > 0) & inside)] = torch.rand(n_depth, 40)          # the reference jitters only the rays it kept
+        draws = [torch.rand(n_zero, 32).to(DEV), torch.rand(n_zero, 8).to(DEV)] if n_zero else []
+        assert bool(inside[(gd.cpu() <= 0)].all())                            # zero-depth rays always pass the pre-filter
+        real = torch.rand
+        try:
+            if draws:
+                torch.rand = lambda *a, **k: draws.pop(0)
+            step.iterate(ro, rd, gd, gc, t_rand=t_rand.to(DEV))
+        finally:
+            torch.rand = real
+    np.testing.assert_allclose(es.params.detach().cpu().numpy(), g["grid_s1"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(ec.params.detach().cpu().numpy(), g["grid_c1"], rtol=1e-3, atol=2e-5)
+    for k, v in dec.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["dec1__" + k.replace(".", "__")], rtol=1e-3, atol=2e-5)
+
+
+def test_mapstep_config3_shape_scannet():
+    """BASELINE configs[2]: ScanNet scene0000 tables (res 456, log2T 16/16), 8192 rays x 96 samples, uncertainty gating on, 25 % zero-depth rays"""
+    import unislam_amd as us
+    torch.manual_seed(0)
+    bound = O.load_bound([[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]])
+    assert O.get_resolution(bound, 0.02) == 456
+    ecfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16,
+            "per_level_scale": O.per_level_scale(456)}
+    es, ec = us.HashGridEncoding(3, ecfg).to(DEV), us.HashGridEncoding(3, ecfg).to(DEV)
+    assert es.desc.n_params == 1697200
+    with torch.no_grad():
+        es.params.mul_(2000); ec.params.mul_(2000)
+    dec = us.Decoders(_cfg(False, 80, 16), c_dim=32, truncation=0.06).to(DEV)
+    R = 8192
+    g = torch.Generator().manual_seed(3)
+    ro = bound.mean(1)[None].repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05
+    rd = torch.randn(R, 3, generator=g); rd = rd / rd.norm(dim=-1, keepdim=True)
+    far = O.bbox_far(ro, rd, bound)
+    gd = torch.minimum(torch.rand(R, generator=g) * 3 + 0.5, 0.9 * far); gd[::4] = 0.0
+    gc = torch.rand(R, 3, generator=g)
+    step = us.MapStep(es, ec, dec, bound, 80, 16, 0.06, W, dict(decoders=0.001, sdf_grid=0.02, color_grid=0.02), max_rays=R)
+    losses = [float(step.iterate(ro.to(DEV), rd.to(DEV), gd.to(DEV), gc.to(DEV))) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    z = step.rendered()[5]
+    assert bool((z[:, 1:] >= z[:, :-1]).all())                                # sorted samples incl. the importance-sampled zero-depth rays
+    st = step.stats.cpu().numpy()
+    assert st[8] == 3 * R and st[9] <= R * 0.75 + 1                           # colour over all rays, depth only where gt > 0 and opaque
