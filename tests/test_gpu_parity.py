@@ -527,6 +527,38 @@ def test_tcnn_layout_decoders_vs_oracle(us):
     close(raw, ref, 1e-4, 1e-5)
 
 
+def test_render_img_and_eval_points_vs_oracle(us):
+    """forward-only consumers: Renderer.render_img (Renderer.py:160-223, chunked) and Mesher.eval_points (Mesher.py:134-166)"""
+    import types
+    torch.manual_seed(2)
+    cfg = _cfg(perturb=False)
+    H, Wd, fx, fy, cx, cy = 9, 13, 9.0, 9.0, 6.0, 4.0
+    dec = us.Decoders(cfg, c_dim=32, truncation=0.06).to(DEV)
+    od = O.DecodersOracle(); od.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    rng = np.random.default_rng(1)
+    pg = rng.standard_normal(O.make_grid_desc(16, 2, 10, 16, O.per_level_scale(64)).n_params).astype(np.float32) * 0.4
+    es, ec = _grid(us, pg), _grid(us, pg[::-1].copy())
+    os_, oc_ = O.HashGridOracle(3, enc_cfg(10, 64)), O.HashGridOracle(3, enc_cfg(10, 64))
+    with torch.no_grad():
+        os_.params.copy_(T(pg)); oc_.params.copy_(T(pg[::-1].copy()))
+    c2w = O.cam_pose_to_matrix(torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]]))[0]
+    gt = torch.rand(H, Wd) * 2 + 0.4
+    r = us.Renderer(cfg, types.SimpleNamespace(bound=BOUND, device=DEV, H=H, W=Wd, fx=fx, fy=fy, cx=cx, cy=cy), ray_batch_size=50)
+    depth, color, term, unc, dunc = r.render_img(([es], [ec]), dec, c2w.to(DEV), 0.06, DEV, gt_depth=gt.to(DEV))
+    ro, rd = O.get_rays(H, Wd, fx, fy, cx, cy, c2w)
+    ref = O.render_batch_ray(([os_], [oc_]), od, rd.reshape(-1, 3), ro.reshape(-1, 3), 0.06, gt.reshape(-1), BOUND, 32, 8, False)
+    assert depth.dtype == torch.float64 and depth.shape == (H, Wd) and color.shape == (H, Wd, 3)
+    close(depth.float(), ref[2].detach().reshape(H, Wd), 1e-3, 1e-5); close(color, ref[3].detach().reshape(H, Wd, 3), 1e-3, 1e-5)
+    close(term.float(), ref[0].detach().reshape(H, Wd), 1e-3, 1e-5); close(dunc.float(), ref[6].detach().reshape(H, Wd), 2e-3, 1e-4)
+    # dense query: inside points decode, outside points get sdf -1
+    p = torch.rand(777, 3) * (BOUND[:, 1] - BOUND[:, 0]) * 1.2 + BOUND[:, 0] - 0.1 * (BOUND[:, 1] - BOUND[:, 0])
+    out = us.eval_points(p.to(DEV), ([es], [ec]), dec, BOUND, points_batch_size=200)
+    inside = ((p < BOUND[:, 1]) & (p > BOUND[:, 0])).all(-1)
+    refq = od((p - BOUND[:, 0]) / (BOUND[:, 1] - BOUND[:, 0]), ([os_], [oc_])).detach()
+    refq[~inside, 3] = -1
+    close(out, refq, 1e-4, 1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- optimiser
 def test_adam_matches_torch(us):
     import ctypes
