@@ -13,7 +13,7 @@ __global__ void k_test(LevelTable tab, const float* x, const float* dy, float* v
     float xv[3] = {x[i * 3], x[i * 3 + 1], x[i * 3 + 2]};
     float d[2] = {dy[i * 2], dy[i * 2 + 1]};
     LevelRecords<2> r;
-    level_records<2>(g, xv, d, d[0] != 0.f || d[1] != 0.f, lane, r);
+    level_records<2, false>(g, xv, d, d[0] != 0.f || d[1] != 0.f, lane, r);
     for (int c = 0; c < 8; ++c) { val[(i * 8 + c) * 2] = r.val[c][0]; val[(i * 8 + c) * 2 + 1] = r.val[c][1]; idx[i * 8 + c] = r.idx[c]; }
     tail[i] = r.tail;
 }

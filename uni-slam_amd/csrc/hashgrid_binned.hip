@@ -89,7 +89,10 @@ struct LevelRecords {
     bool tail;
 };
 
-template <int F>
+// COUNT_ONLY: the counting pass needs only WHICH lanes own a record (run tails of live samples) and the 8 entry indices;
+// it counts every corner of every live tail (an upper bound: the writing pass drops all-zero records, and the accumulate
+// kernel reads exactly what was written, [offset, cursor) per bin), so it skips the weights, products and the scan.
+template <int F, bool COUNT_ONLY>
 __device__ __forceinline__ void level_records(const LevelGeom& g, const float xv[3], const float dy[F], bool live, int lane,
                                               LevelRecords<F>& r) {
     float pos[3]; uint32_t cell[3];
@@ -105,9 +108,11 @@ __device__ __forceinline__ void level_records(const LevelGeom& g, const float xv
     if (!live || !packable) key = 0xC0000000u | (uint32_t)lane;      // bits 30..31 set: never equals a packed cell, unique per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float w = corner_weight(c, pos);
+        if (!COUNT_ONLY) {
+            const float w = corner_weight(c, pos);
 #pragma unroll
-        for (int f = 0; f < F; ++f) r.val[c][f] = live ? w * dy[f] : 0.0f;
+            for (int f = 0; f < F; ++f) r.val[c][f] = live ? w * dy[f] : 0.0f;
+        }
         r.idx[c] = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1));
     }
     // Segmented inclusive scan over aligned groups of 8 lanes (Hillis-Steele with head flags, steps 1, 2, 4).  A run is a
@@ -120,7 +125,7 @@ __device__ __forceinline__ void level_records(const LevelGeom& g, const float xv
     bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
     const bool next_is_head = (l8 == 7) | (knext != key);
 #define US_SCAN_STEP(O)                                                                                              \
-    {                                                                                                                \
+    if (!COUNT_ONLY && __ballot(!flag && (l8 >= (O))) != 0ull) {   /* wave-uniform: nothing left to merge -> skip the step */ \
         const bool take = !flag && (l8 >= (O));                                                                      \
         const bool fprev = dpp_u32<DPP_ROW_SHR(O)>(flag ? 1u : 0u) != 0u;                                            \
         _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                               \
@@ -184,14 +189,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
         uint32_t rank[8];
         bool emit[8];
         const bool wave_live = __ballot(live) != 0ull;           // a wave whose samples all have zero gradient skips the hashing
-        if (wave_live) level_records<F>(g, xv, dy, live, lane, r);
+        if (wave_live) level_records<F, !WRITE>(g, xv, dy, live, lane, r);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             emit[c] = false; rank[c] = 0;
             if (!wave_live) continue;
-            bool nz = false;
+            bool nz = !WRITE;                                     // counting pass: every corner of a live tail (upper bound)
+            if (WRITE) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) nz |= (r.val[c][f] != 0.0f);
+                for (int f = 0; f < F; ++f) nz |= (r.val[c][f] != 0.0f);
+            }
             const bool e = r.tail & nz;
             emit[c] = e;
             const unsigned long long mask = __ballot(e);
@@ -263,15 +270,15 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
 // B: one workgroup per bin
 template <int F>
 __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels,
-                                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ rec,
-                                                           float* __restrict__ grad) {
+                                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursors,
+                                                           const uint32_t* __restrict__ rec, float* __restrict__ grad) {
     __shared__ double acc[BIN_ACC_DOUBLES];
     const uint32_t b = blockIdx.x;
     uint32_t level = 0;
     while (level + 1 < n_levels && bm.first[level + 1] <= b) ++level;
     const uint32_t lg = bm.log2nb[level], bl = b - bm.first[level];
     const uint32_t hs = tab.off[level + 1] - tab.off[level];
-    const uint32_t r0 = offsets[b], r1 = offsets[b + 1];
+    const uint32_t r0 = offsets[b], r1 = cursors[b];             // what the writing pass really stored (<= the counted range)
     if (r0 == r1) return;                                        // nothing landed in this bin (wave-uniform)
     const uint32_t sh = bm.shift[level];
     const uint32_t n_local = sh ? (1u << sh) : (bl < hs ? ((hs - 1u - bl) >> lg) + 1u : 0u);   // entries owned by this bin
@@ -355,7 +362,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);         \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, (uint32_t)TB, offsets, cursors);                         \
     hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);          \
-    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), dim3(ACC_THREADS), 0, s, t, bm, L, offsets, rec, grad_params);
+    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), dim3(ACC_THREADS), 0, s, t, bm, L, offsets, cursors, rec, grad_params);
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
 #undef LAUNCH_BIN
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
