@@ -22,6 +22,6 @@ for width, nh in [(32, 2), (16, 2), (16, 1)]:
         return a.elapsed_time(b) / reps * 1e3
     full = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, L.ptr(dx), L.ptr(gp), 0, L.ptr(ws), wsb, st))
     only_dx = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, L.ptr(dx), None, 0, None, 0, st))
-    only_gp = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, None, L.ptr(gp), 0, None, 0, st))
+    only_gp = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, None, L.ptr(gp), 0, L.ptr(ws), wsb, st))
     fwd = t(lambda: lib.us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(y), 3, 0, st))
     print(f"width {width} hidden {nh}: fwd {fwd:.1f} us  bwd full {full:.1f}  only dL_din {only_dx:.1f}  only grad_params {only_gp:.1f}")

@@ -23,17 +23,21 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-#define MLP_WAVES 4
+#define MLP_WAVES 4                       // forward kernel
 #define MLP_THREADS (MLP_WAVES * 64)
 
 __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int NIN, int WIDTH, int NHID>
+// NQ_ = 16-point tiles per wave iteration, WAVES_ = waves per workgroup.  Forward: 4 tiles (2 at width 64), 4 waves.
+// Backward: 2 tiles and 8 waves (4 at width 64): the per-wave transposing scratch then fits 8 waves = 2 per SIMD, so
+// one wave's LDS round trips overlap another wave's MFMAs.
+template <int NIN, int WIDTH, int NHID, int NQ_ = ((WIDTH == 64) ? 2 : 4), int WAVES_ = MLP_WAVES>
 struct MlpCfg {
     static constexpr int N_IN = NIN, W = WIDTH, NH = NHID;
-    static constexpr int NQ = (WIDTH == 64) ? 2 : 4;  // 16-point tiles per wave iteration (register budget)
+    static constexpr int NQ = NQ_;
+    static constexpr int WAVES = WAVES_;
     static constexpr int PTS = 16 * NQ;               // points per wave iteration
     static constexpr int SCR_STRIDE = PTS + 4;        // scratch row: PTS points + 4 pad floats (16-byte aligned rows)
     static constexpr int MT = WIDTH / 16;          // 16-row tiles of a hidden layer
@@ -65,8 +69,7 @@ struct MlpCfg {
     static constexpr int SCR_ROWS_B = (WIDTH > 16 ? WIDTH : 16);
     static constexpr int L_SCR = ((L_BWD_END + 3) / 4) * 4;
     static constexpr int SCR_PER_WAVE = (SCR_ROWS_A + SCR_ROWS_B) * SCR_STRIDE;
-    static_assert(L_SCR + MLP_WAVES * SCR_PER_WAVE <= 40960, "MLP backward exceeds 160 KiB of LDS");
-    static constexpr int L_TOTAL_BWD = L_SCR + MLP_WAVES * SCR_PER_WAVE;
+    static constexpr int L_TOTAL_BWD = L_SCR + WAVES * SCR_PER_WAVE;
 };
 
 // out[q][m] = W(rows 16m..16m+15) * in + bias      (KB 16-wide K blocks; W in LDS with row stride SW)
@@ -126,23 +129,24 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
 template <typename C, bool BWD>
 __device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ params, bool has_bias) {
     constexpr int NIN = C::N_IN, WIDTH = C::W, NHID = C::NH;
-    for (int i = threadIdx.x; i < WIDTH * NIN; i += MLP_THREADS) {
+    const int nthr = blockDim.x;
+    for (int i = threadIdx.x; i < WIDTH * NIN; i += nthr) {
         const int r = i / NIN, c = i % NIN; const float v = params[C::P_W0 + i];
         lds[C::L_W0 + r * C::S_IN + c] = v;
         if (BWD) lds[C::L_W0T + c * C::S_W + r] = v;
     }
     if (NHID == 2)
-        for (int i = threadIdx.x; i < WIDTH * WIDTH; i += MLP_THREADS) {
+        for (int i = threadIdx.x; i < WIDTH * WIDTH; i += nthr) {
             const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WH + i];
             lds[C::L_WH + r * C::S_W + c] = v;
             if (BWD) lds[C::L_WHT + c * C::S_W + r] = v;
         }
-    for (int i = threadIdx.x; i < 16 * WIDTH; i += MLP_THREADS) {
+    for (int i = threadIdx.x; i < 16 * WIDTH; i += nthr) {
         const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WL + i];
         lds[C::L_WL + r * C::S_W + c] = v;
         if (BWD) lds[C::L_WLT + c * C::S_O + r] = v;
     }
-    for (int i = threadIdx.x; i < C::N_B; i += MLP_THREADS) lds[C::L_B + i] = has_bias ? params[C::P_B0 + i] : 0.0f;
+    for (int i = threadIdx.x; i < C::N_B; i += nthr) lds[C::L_B + i] = has_bias ? params[C::P_B0 + i] : 0.0f;
 }
 
 // input features of 64 points as B operands: xb[q][b][c] = in[p(q)][16b + 4g + c]
@@ -285,29 +289,44 @@ __device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT
         }
 }
 
-// sum of the per-workgroup partial rows, fixed order -> bitwise reproducible decoder gradients
-__global__ __launch_bounds__(256) void k_mlp_reduce(const float* __restrict__ partials, int n_rows, int np, float* __restrict__ grad) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= np) return;
+// sum of the per-workgroup partial rows, fixed order -> bitwise reproducible decoder gradients.
+// 64 parameters x 16 row slices per workgroup: 16 independent partial sums per parameter keep the loads short and parallel.
+__global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ partials, int n_rows, int np, float* __restrict__ grad) {
+    __shared__ float sh[16][64];
+    const int kl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     float s = 0.0f;
-    for (int r = 0; r < n_rows; ++r) s += partials[(size_t)r * np + k];
-    grad[k] += s;
+    if (k < np)
+        for (int r = sl; r < n_rows; r += 16) s += partials[(size_t)r * np + k];
+    sh[sl][kl] = s;
+    __syncthreads();
+    if (sl == 0 && k < np) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][kl];
+        grad[k] += t;
+    }
 }
 
+#define MLP_BWD_WAVES(WIDTH) ((WIDTH) == 64 ? 4 : 8)
+
 template <int NIN, int WIDTH, int NHID>
-__global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict__ params, int has_bias, int n_out,
+__global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const float* __restrict__ params, int has_bias, int n_out,
                                                          int act, const float* __restrict__ in,
                                                          const float* __restrict__ out, int64_t out_stride,
                                                          const float* __restrict__ dL_dout, int64_t dout_stride,
                                                          int64_t n, float* __restrict__ dL_din,
                                                          float* __restrict__ grad_params, int lm, float* __restrict__ partials) {
-    typedef MlpCfg<NIN, WIDTH, NHID> C;
-    constexpr int NQ = C::NQ, PTS = C::PTS;
+    typedef MlpCfg<NIN, WIDTH, NHID, 2, MLP_BWD_WAVES(WIDTH)> C;
+    static_assert(C::L_TOTAL_BWD <= 40960, "MLP backward exceeds 160 KiB of LDS");
+    constexpr int NQ = C::NQ, PTS = C::PTS, WAVES = C::WAVES, THREADS = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
     load_weights<C, true>(lds, params, has_bias != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
     const float* bias = lds + C::L_B;
+    // per-WAVE scratch: written and read by the same wave only.  LDS operations of one wave execute in order, so no
+    // workgroup barrier is needed between a wave's stores and its own loads (the waves run free of each other).
     float* bufA = lds + C::L_SCR + wave * C::SCR_PER_WAVE;         // H_{l-1}^T image  [neuron][PTS points]
     float* bufB = bufA + C::SCR_ROWS_A * C::SCR_STRIDE;            // dH_l^T image
 
@@ -325,10 +344,8 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
     gBL[0] = zero;
 
     const int64_t n_chunks = (n + PTS - 1) / PTS;
-    const int64_t n_groups = (n_chunks + MLP_WAVES - 1) / MLP_WAVES;
-    // uniform trip count for the whole workgroup (there are __syncthreads inside); idle waves run on zeros
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const int64_t base = (grp * MLP_WAVES + wave) * PTS;
+    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
+        const int64_t base = chunk * PTS;
         v4f xb[NQ][C::KB_IN];
         load_inputs<NQ, NIN>(in, base, n, row, g, xb, lm);
         v4f h0[NQ][C::MT], h1[NQ][C::MT];
@@ -353,21 +370,25 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
         }
         // ---- output layer:  dWL += dO * Hlast^T ;  dHlast = WL^T dO (.) relu'
         v4f (&hl)[NQ][C::MT] = (NHID == 2) ? h1 : h0;
-        __syncthreads();                                   // previous iteration's scratch reads are done
-        scratch_store<NQ, C::MT>(bufA, hl, row, g);
-        scratch_store<NQ, 1>(bufB, dO, row, g);
-        __syncthreads();
-        if (grad_params) { wgrad<NQ, 1, C::MT>(bufB, bufA, gWL, row, g); bias_acc<NQ, 1>(gBL, dO); }
+        if (grad_params) {
+            scratch_store<NQ, C::MT>(bufA, hl, row, g);
+            scratch_store<NQ, 1>(bufB, dO, row, g);
+            __builtin_amdgcn_wave_barrier();
+            wgrad<NQ, 1, C::MT>(bufB, bufA, gWL, row, g); bias_acc<NQ, 1>(gBL, dO);
+            __builtin_amdgcn_wave_barrier();
+        }
         v4f dh[NQ][C::MT];
         dense<NQ, 1, C::MT, C::S_O>(lds + C::L_WLT, nullptr, dO, dh, row, g);
         relu_bwd_<NQ, C::MT>(dh, hl);
         if (NHID == 2) {
             // ---- hidden layer: dWH += dH1 * H0^T ; dH0 = WH^T dH1 (.) relu'
-            __syncthreads();
-            scratch_store<NQ, C::MT>(bufA, h0, row, g);
-            scratch_store<NQ, C::MT>(bufB, dh, row, g);
-            __syncthreads();
-            if (grad_params) { wgrad<NQ, C::MT, C::MT>(bufB, bufA, gWH, row, g); bias_acc<NQ, C::MT>(gBH, dh); }
+            if (grad_params) {
+                scratch_store<NQ, C::MT>(bufA, h0, row, g);
+                scratch_store<NQ, C::MT>(bufB, dh, row, g);
+                __builtin_amdgcn_wave_barrier();
+                wgrad<NQ, C::MT, C::MT>(bufB, bufA, gWH, row, g); bias_acc<NQ, C::MT>(gBH, dh);
+                __builtin_amdgcn_wave_barrier();
+            }
             v4f dh0[NQ][C::MT];
             dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WHT, nullptr, dh, dh0, row, g);
             relu_bwd_<NQ, C::MT>(dh0, h0);
@@ -378,12 +399,12 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
         }
         // ---- input layer: dW0 += dH0 * X^T ; dX = W0^T dH0
         if (grad_params) {
-            __syncthreads();
             scratch_store<NQ, C::KB_IN>(bufA, xb, row, g);  // xb tile b, register c is feature 16b + 4g + c: same map
             scratch_store<NQ, C::MT>(bufB, dh, row, g);
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             wgrad<NQ, C::MT, C::KB_IN>(bufB, bufA, gW0, row, g);
             bias_acc<NQ, C::MT>(gB0, dh);
+            __builtin_amdgcn_wave_barrier();
         }
         if (dL_din) {
             v4f dx[NQ][C::KB_IN];
@@ -407,9 +428,9 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
     }
     if (grad_params) {
         constexpr int NP = C::N_W + C::N_B;
-        static_assert(NP <= MLP_WAVES * C::SCR_PER_WAVE, "staging area");
+        static_assert(NP <= WAVES * C::SCR_PER_WAVE, "staging area");
         float* stage = lds + C::L_SCR;                            // the scratch images are dead now
-        for (int w = 0; w < MLP_WAVES; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             __syncthreads();
             if (wave == w) {
                 const bool first = (w == 0);
@@ -424,9 +445,9 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_bwd(const float* __restrict
         __syncthreads();
         const int np = has_bias ? NP : C::N_W;
         if (partials) {
-            for (int k = threadIdx.x; k < np; k += MLP_THREADS) partials[(size_t)blockIdx.x * np + k] = stage[k];
+            for (int k = threadIdx.x; k < np; k += THREADS) partials[(size_t)blockIdx.x * np + k] = stage[k];
         } else {
-            for (int k = threadIdx.x; k < np; k += MLP_THREADS) { const float v = stage[k]; if (v != 0.0f) atomicAdd(grad_params + k, v); }
+            for (int k = threadIdx.x; k < np; k += THREADS) { const float v = stage[k]; if (v != 0.0f) atomicAdd(grad_params + k, v); }
         }
     }
 }
@@ -497,9 +518,9 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
     if (!dL_din && !grad_params) return US_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int pts = d->width == 64 ? 32 : 64;
-    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;      // one workgroup per CU
-    dim3 grid((unsigned)nb), block(MLP_THREADS);
+    const int waves = MLP_BWD_WAVES(d->width);
+    int64_t nb = us_cdiv(n, 32 * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;          // one workgroup per CU
+    dim3 grid((unsigned)nb), block(waves * 64);
     float* partials = nullptr;
     if (grad_params && workspace) {
         US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(d), US_ERR_WORKSPACE, "us_mlp_bwd: workspace %zu B < %zu B",
@@ -511,7 +532,7 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     US_CHECK_LAUNCH("us_mlp_bwd");
     if (partials) {
         const int np = (int)us_mlp_n_params(d);
-        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 256)), dim3(256), 0, s, partials, (int)nb, np, grad_params);
+        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, s, partials, (int)nb, np, grad_params);
         US_CHECK_LAUNCH("us_mlp_bwd(reduce)");
     }
     return US_OK;
