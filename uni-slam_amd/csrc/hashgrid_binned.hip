@@ -25,6 +25,7 @@
 #define BIN_MAX_TOTAL 4096               // bins over all levels (LDS counters: 2 x 16 KiB)
 #define BIN_ACC_DOUBLES 4096             // 32 KiB of f64 accumulators per bin -> ~5 accumulate workgroups per CU
 #define ACC_THREADS 256
+#define BIN_GROUP_BYTES (1ull << 40)      // record bytes per level group: effectively ONE group (see us_hashgrid_bwd_binned)
 #define ACC_UNROLL 8                     // record loads in flight per thread (the accumulate kernel is a latency-bound stream)
 
 struct BinMap {
@@ -40,6 +41,11 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t e, uint32_t lg, uint32_t sh)
 __device__ __forceinline__ uint32_t local_of(uint32_t e, uint32_t lg, uint32_t sh) { return sh ? (e & ((1u << sh) - 1u)) : (e >> lg); }
 
 static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
+
+// records are {local entry, F values} = 1+F dwords.  Measured: the scatter pass's stores run at HBM write speed (padding the
+// F = 2 record to 16 bytes for single vector stores made the whole pass slower: bytes matter, not store instructions)
+template <int F> struct RecW { static constexpr int DW = 1 + F; };
+static inline uint32_t rec_dwords(uint32_t F) { return 1u + F; }
 
 // bins per level: enough for the f64 slice to fit the LDS budget (capacity) AND enough to keep every bin near
 // BIN_TARGET_RECORDS records whatever the level's size (a 4096-entry level receives as many records as a 4 MiB one)
@@ -146,13 +152,14 @@ __device__ __forceinline__ void level_records(const LevelGeom& g, const float xv
 // A1 (WRITE = true) : per level: count in LDS -> reserve the workgroup's share of every bin from the global cursors
 //                     (initialised to the scan) -> store the records, which stayed in registers meanwhile.
 template <int F, bool WRITE>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, uint32_t n_levels, const float* __restrict__ x,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, uint32_t n_levels, uint32_t l0, uint32_t l1,
+                                                     const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                      uint32_t* __restrict__ rec) {
     __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
-    const uint32_t TB = bm.first[n_levels];
-    for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0;
+    const uint32_t TB0 = bm.first[l0], TB1 = bm.first[l1];       // this launch handles levels [l0, l1) = bins [TB0, TB1)
+    for (uint32_t t = TB0 + threadIdx.x; t < TB1; t += BIN_THREADS) lcnt[t] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
@@ -166,13 +173,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
     // all levels' gradients of this point are fetched up front (one memory round trip instead of one per level)
     constexpr int LCH = 16;
     float dyv[LCH][F];
-    for (uint32_t level = 0; level < n_levels; ++level) {
-        if ((level % LCH) == 0) {
+    for (uint32_t level = l0; level < l1; ++level) {
+        if (level == l0 || (level % LCH) == 0) {
+            const uint32_t lb = level - (level % LCH);
 #pragma unroll
             for (int q = 0; q < LCH; ++q)
 #pragma unroll
                 for (int f = 0; f < F; ++f)
-                    dyv[q][f] = (in && level + q < n_levels) ? dL_dy[feat_index(lm, i, n, level + q, C, F) + f] : 0.0f;
+                    dyv[q][f] = (in && lb + q >= l0 && lb + q < l1) ? dL_dy[feat_index(lm, i, n, lb + q, C, F) + f] : 0.0f;
         }
         const LevelGeom g = level_geom(tab, level);
         const uint32_t nb = 1u << bm.log2nb[level], lg = bm.log2nb[level], first = bm.first[level], sh = bm.shift[level];
@@ -204,16 +212,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
             const unsigned long long mask = __ballot(e);
             if (mask == 0ull) continue;
             const uint32_t b = first + bin_of(r.idx[c], lg, sh);
-            // rank inside the workgroup's share of the bin.  Fast path: every emitting lane of the wave hits the same
-            // bin: one LDS atomic for the wave instead of <= 64 serialised ones.
-            const int lead = __ffsll((long long)mask) - 1;
-            const uint32_t b0 = __builtin_amdgcn_readlane(b, lead);
-            if (__ballot(e && b == b0) == mask) {
-                uint32_t base = 0;
-                const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
-                base = __builtin_amdgcn_readlane(base, lead);
-                rank[c] = base + mb;
+            // rank inside the workgroup's share of the bin.  With few bins (small batches) every emitting lane of the wave
+            // tends to hit the same bin: one LDS atomic for the wave instead of <= 64 serialised ones.  With hundreds of
+            // bins per level the lanes scatter and plain LDS integer atomics (7 cycles per wave instruction) are cheapest.
+            if (lg <= 1) {                                       // wave-uniform
+                const int lead = __ffsll((long long)mask) - 1;
+                const uint32_t b0 = __builtin_amdgcn_readlane(b, lead);
+                if (__ballot(e && b == b0) == mask) {
+                    uint32_t base = 0;
+                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
+                    base = __builtin_amdgcn_readlane(base, lead);
+                    rank[c] = base + mb;
+                } else if (e) {
+                    rank[c] = atomicAdd(&lcnt[b], 1u);
+                }
             } else if (e) {
                 rank[c] = atomicAdd(&lcnt[b], 1u);
             }
@@ -228,8 +241,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (emit[c]) {
-                    uint32_t* dst = rec + (size_t)(lcnt[first + bin_of(r.idx[c], lg, sh)] + rank[c]) * (1 + F);
-                    dst[0] = local_of(r.idx[c], lg, sh);
+                    uint32_t* dst = rec + (size_t)(lcnt[first + bin_of(r.idx[c], lg, sh)] + rank[c]) * RecW<F>::DW;
+                    const uint32_t loc = local_of(r.idx[c], lg, sh);
+#ifdef US_EXP_A_NOSTORE
+                    if (loc == 0xFFFFFFF0u)
+#endif
+                    dst[0] = loc;
 #pragma unroll
                     for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(r.val[c][f]);
                 }
@@ -238,13 +255,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
     }
     if (!WRITE) {
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) { const uint32_t c = lcnt[t]; if (c) atomicAdd(&counts[t], c); }
+        for (uint32_t t = TB0 + threadIdx.x; t < TB1; t += BIN_THREADS) { const uint32_t c = lcnt[t]; if (c) atomicAdd(&counts[t], c); }
     }
 }
 
 // exclusive scan of counts[0..TB) -> offsets[0..TB], cursors[t] = offsets[t]   (TB <= 4096: 4 elements per thread)
-__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ cursors) {
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts_all, uint32_t TB0, uint32_t TB, uint32_t* __restrict__ offsets_all,
+                                                   uint32_t* __restrict__ cursors_all) {
+    const uint32_t* counts = counts_all + TB0; uint32_t* offsets = offsets_all + TB0; uint32_t* cursors = cursors_all + TB0;
     __shared__ uint32_t sh[1024];
     const uint32_t t = threadIdx.x;
     uint32_t c[4], s4 = 0;
@@ -269,11 +287,11 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
 
 // B: one workgroup per bin
 template <int F>
-__global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels,
+__global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels, uint32_t bin0,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursors,
                                                            const uint32_t* __restrict__ rec, float* __restrict__ grad) {
     __shared__ double acc[BIN_ACC_DOUBLES];
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = bin0 + blockIdx.x;
     uint32_t level = 0;
     while (level + 1 < n_levels && bm.first[level + 1] <= b) ++level;
     const uint32_t lg = bm.log2nb[level], bl = b - bm.first[level];
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
             loc[u] = 0xFFFFFFFFu;
             if (r < r1) {
-                const uint32_t* src = rec + (size_t)r * (1 + F);
+                const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
                 loc[u] = src[0];
 #pragma unroll
                 for (int f = 0; f < F; ++f) v[u][f] = __uint_as_float(src[1 + f]);
@@ -327,11 +345,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
-static size_t header_bytes() { return (size_t)(3 * (BIN_MAX_TOTAL + 64)) * sizeof(uint32_t); }
+static size_t header_bytes() { return (size_t)(3 * (BIN_MAX_TOTAL + 64)) * sizeof(uint32_t); }   // multiple of 16 bytes
 
 extern "C" size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* d, int64_t n) {
     if (!d || n <= 0) return 0;
-    return header_bytes() + (size_t)n * 8u * d->n_levels * (1u + d->n_features) * sizeof(uint32_t);
+    return header_bytes() + (size_t)n * 8u * d->n_levels * rec_dwords(d->n_features) * sizeof(uint32_t);
 }
 
 extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
@@ -358,11 +376,22 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     if (e != hipSuccess) { us_set_error("us_hashgrid_bwd_binned: memset: %s", hipGetErrorString(e)); return (int)e; }
     dim3 gridA((unsigned)us_cdiv(n, BIN_THREADS)), block(BIN_THREADS);
     const uint32_t L = d->n_levels;
+    // Level groups (count -> scan -> scatter -> accumulate per group, record buffer reused from offset 0).  Tried with
+    // ~100 MB groups so that the accumulate pass would read the records from the Infinity Cache: measured SLOWER (0.46 vs
+    // 0.36 ms per grid; the per-launch fixed costs of four passes outweigh the cache hits), so one group is the default.
+    const uint64_t per_level = (uint64_t)n * 8ull * rec_dwords(d->n_features) * sizeof(uint32_t);
+    uint32_t lg_levels = (uint32_t)(BIN_GROUP_BYTES / (per_level ? per_level : 1));
+    if (lg_levels < 1) lg_levels = 1;
+    if (lg_levels > L) lg_levels = L;
 #define LAUNCH_BIN(F)                                                                                                          \
-    hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);         \
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, (uint32_t)TB, offsets, cursors);                         \
-    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, counts, cursors, rec);          \
-    hipLaunchKernelGGL((k_bin_accum<F>), dim3((unsigned)TB), dim3(ACC_THREADS), 0, s, t, bm, L, offsets, cursors, rec, grad_params);
+    for (uint32_t l0 = 0; l0 < L; l0 += lg_levels) {                                                                           \
+        const uint32_t l1 = (l0 + lg_levels < L) ? l0 + lg_levels : L;                                                         \
+        const uint32_t b0 = bm.first[l0], nbins = bm.first[l1] - bm.first[l0];                                                 \
+        hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, l0, l1, x, dL_dy, n, clamp, lm, counts, cursors, rec); \
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, b0, nbins, offsets, cursors);                        \
+        hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, l0, l1, x, dL_dy, n, clamp, lm, counts, cursors, rec);  \
+        hipLaunchKernelGGL((k_bin_accum<F>), dim3(nbins), dim3(ACC_THREADS), 0, s, t, bm, L, b0, offsets, cursors, rec, grad_params); \
+    }
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
 #undef LAUNCH_BIN
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
