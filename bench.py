@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--hidden", type=int, default=32, help="MLP width (32 = BASELINE '2x32'; 16 = reference decoders.py default)")
     ap.add_argument("--bwd-mode", type=int, default=-1)
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="MFMA operand type of the decoders; the headline (parity-tested to 1e-3) is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
@@ -193,13 +195,19 @@ def main():
     res = int((bound[:, 1] - bound[:, 0]).max() / 0.01)                                  # 816 (src/UNISLAM.py:192-199)
     pls = per_level_scale(res)
     torch.manual_seed(0)
-    cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}}
-    dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
     mk = lambda l2: us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
                                             "log2_hashmap_size": l2, "base_resolution": 16, "per_level_scale": pls}).to(dev)
-    es, ec = mk(16), mk(19)                                                              # replica.yaml:29-30
-    step = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
-                      group=True if world > 1 else None, bwd_mode=args.bwd_mode)
+
+    def build_step(prec):
+        torch.manual_seed(0)
+        cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
+        dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
+        es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
+        st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
+                        group=True if world > 1 else None, bwd_mode=args.bwd_mode)
+        return st, es, ec, dec
+
+    step, es, ec, dec = build_step(args.mlp_precision)
     if world > 1:
         broadcast_parameters(step.flat)
     ro, rd, gd, gc = synthetic_rays(args.rays, bound, 1000 + rank, dev)                   # one synthetic frame per rank
@@ -231,7 +239,8 @@ def main():
         rec = {"metric": "rays/s (64 samples, L=16 hash, 2x32 MLP), Replica room0 mapping iteration",
                "value": world * args.rays / (ms / 1e3), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32" if args.mlp_precision == "fp32" else "f32 tables/accumulation, bf16 MFMA operands in the decoders",
+               "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: Replica room0, 4096 rays x 64 samples (48 stratified + 16 surface), "
                                       "L=16 F=2 hash grids log2T 16 (sdf) / 19 (colour) res 816, 2 hidden x %d MLP decoders with bias, "
                                       "mapping iteration = sample+encode+decode+composite+loss+backward+dense Adam" % args.hidden,
@@ -253,6 +262,18 @@ def main():
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
                                "avg_launch_ms": kern[dom]}
+        if world == 1 and args.mlp_precision == "fp32" and not args.no_probe:
+            # the same iteration with bf16 MFMA operands in the two decoders (v_mfma_f32_16x16x32_bf16); not the headline
+            st2 = build_step("bf16")[0]
+            for _ in range(args.warmup):
+                st2.iterate(ro, rd, gd, gc, has_zero_depth=False)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l2 = st2.iterate(ro, rd, gd, gc, has_zero_depth=False)
+            torch.cuda.synchronize()
+            ms2 = 1e3 * (time.perf_counter() - t1) / args.steps
+            rec["bf16_decoders"] = {"ms_per_step": ms2, "rays_per_s": args.rays / (ms2 / 1e3), "final_loss": float(l2)}
+            del st2
         if world == 1 and not args.no_tracking:
             rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -372,3 +372,35 @@ def test_mapstep_config3_shape_scannet():
     assert bool((z[:, 1:] >= z[:, :-1]).all())                                # sorted samples incl. the importance-sampled zero-depth rays
     st = step.stats.cpu().numpy()
     assert st[8] == 3 * R and st[9] <= R * 0.75 + 1                           # colour over all rays, depth only where gt > 0 and opaque
+
+
+@pytest.mark.parametrize("tcnn,hidden", [(False, 32), (True, 16)])
+def test_mapstep_bf16_decoders_track_fp32(tcnn, hidden):
+    """mlp_precision = bf16 (MFMA bf16 operands, fp32 accumulation and parameters): same rays and draws as the fp32 step.
+    Rendered depth / colour stay within 1e-2 relative (norm-wise) of the fp32 path and the optimisation behaves the same."""
+    import unislam_amd as us
+    R, S = 1024, 64
+    ro, rd, gd, gc = _rays(R, seed=5)
+    t_rand = torch.rand(R, S, device=DEV)
+    outs, losses = {}, {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        cfg = dict(_cfg(tcnn, 48, 16), model={"mlp_precision": prec})
+        dec = us.Decoders(cfg, c_dim=32, hidden_size=hidden, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=R)
+        assert step.desc_s.precision == (1 if prec == "bf16" else 0)
+        l0 = float(step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False))
+        outs[prec] = [t.clone() for t in step.rendered()[:4]] + [es.params.grad.clone(), ec.params.grad.clone()]
+        step.adam_step()
+        ls = [l0] + [float(step.iterate(ro, rd, gd, gc, has_zero_depth=False)) for _ in range(25)]
+        losses[prec] = ls
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    term_b, unc_b, depth_b, rgb_b, gs_b, gc_b = outs["bf16"]
+    term_f, unc_f, depth_f, rgb_f, gs_f, gc_f = outs["fp32"]
+    assert rel(depth_b, depth_f) < 1e-2 and rel(rgb_b, rgb_f) < 1e-2, (rel(depth_b, depth_f), rel(rgb_b, rgb_f))
+    assert rel(gs_b, gs_f) < 0.15 and rel(gc_b, gc_f) < 0.15, (rel(gs_b, gs_f), rel(gc_b, gc_f))
+    assert abs(losses["bf16"][0] - losses["fp32"][0]) < 2e-2 * abs(losses["fp32"][0])
+    assert losses["bf16"][-1] < losses["bf16"][0] and abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * abs(losses["fp32"][-1])

@@ -5,8 +5,8 @@ import unislam_amd as us
 from unislam_amd import _lib as L
 DEV = "cuda:0"
 n = 262144
-for width, nh in [(32, 2), (16, 2), (16, 1)]:
-    desc = us.make_mlp_desc(32, width, nh, 3, "sigmoid", True)
+for width, nh, prec in [(w, h, pr) for (w, h) in [(32, 2), (16, 2), (16, 1), (64, 2)] for pr in ("fp32", "bf16")]:
+    desc = us.make_mlp_desc(32, width, nh, 3, "sigmoid", True, prec)
     p = torch.randn(us.network.mlp_n_params(desc), device=DEV) * 0.3
     x = torch.randn(n, 32, device=DEV); y = torch.empty(n, 3, device=DEV); dy = torch.randn(n, 3, device=DEV)
     dx = torch.empty(n, 32, device=DEV); gp = torch.zeros_like(p)
@@ -24,4 +24,4 @@ for width, nh in [(32, 2), (16, 2), (16, 1)]:
     only_dx = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, L.ptr(dx), None, 0, None, 0, st))
     only_gp = t(lambda: lib.us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(y), 3, L.ptr(dy), 3, n, None, L.ptr(gp), 0, L.ptr(ws), wsb, st))
     fwd = t(lambda: lib.us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(y), 3, 0, st))
-    print(f"width {width} hidden {nh}: fwd {fwd:.1f} us  bwd full {full:.1f}  only dL_din {only_dx:.1f}  only grad_params {only_gp:.1f}")
+    print(f"{prec} width {width} hidden {nh}: fwd {fwd:.1f} us  bwd full {full:.1f}  only dL_din {only_dx:.1f}  only grad_params {only_gp:.1f}")

@@ -24,13 +24,15 @@ class Decoders(nn.Module):
         self.n_blocks = n_blocks
         self.hidden_size = hidden_size
         self.tcnn_network = self.cfg['grid']['tcnn_network']
+        # extension over the reference's yaml: MFMA operand type of the decoder MLPs ("fp32" | "bf16")
+        self.mlp_precision = self.cfg.get('model', {}).get('mlp_precision', 'fp32') if hasattr(self.cfg, 'get') else 'fp32'
         if cfg['grid_mode'] != 'hash_grid':
             raise ValueError("Decoders: only grid_mode == 'hash_grid' exists in Uni-SLAM (decoders.py:116-120)")
         input_channels = c_dim
         if self.tcnn_network:
             mk = lambda n_out, act: FusedMLP(input_channels, n_out, {
                 "otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act,
-                "n_neurons": hidden_size, "n_hidden_layers": n_blocks - 1})
+                "n_neurons": hidden_size, "n_hidden_layers": n_blocks - 1, "precision": self.mlp_precision})
             self.sdf_decoder = mk(1, "Tanh")
             self.color_decoder = mk(3, "Sigmoid")
         else:
@@ -42,8 +44,7 @@ class Decoders(nn.Module):
             self.c_output_linear = nn.Linear(hidden_size, 3)
             if n_blocks not in (1, 2):
                 raise ValueError("Decoders: the fused kernel covers n_blocks in {1, 2}")
-            self._desc_sdf = make_mlp_desc(input_channels, hidden_size, n_blocks, 1, "tanh", True)
-            self._desc_rgb = make_mlp_desc(input_channels, hidden_size, n_blocks, 3, "sigmoid", True)
+            self._desc_sdf, self._desc_rgb = self.mlp_descs()
         if learnable_beta:
             self.beta = nn.Parameter(10 * torch.ones(1))
         else:
@@ -57,9 +58,16 @@ class Decoders(nn.Module):
 
     def __setstate__(self, s):
         self.__dict__.update(s)
+        self.__dict__.setdefault("mlp_precision", "fp32")
         if not self.tcnn_network:
-            self._desc_sdf = make_mlp_desc(self.c_dim, self.hidden_size, self.n_blocks, 1, "tanh", True)
-            self._desc_rgb = make_mlp_desc(self.c_dim, self.hidden_size, self.n_blocks, 3, "sigmoid", True)
+            self._desc_sdf, self._desc_rgb = self.mlp_descs()
+
+    def mlp_descs(self):
+        """(sdf, colour) us_mlp_desc of the two decoders"""
+        if self.tcnn_network:
+            return self.sdf_decoder.desc, self.color_decoder.desc
+        return (make_mlp_desc(self.c_dim, self.hidden_size, self.n_blocks, 1, "tanh", True, self.mlp_precision),
+                make_mlp_desc(self.c_dim, self.hidden_size, self.n_blocks, 3, "sigmoid", True, self.mlp_precision))
 
     def __deepcopy__(self, memo):
         new = Decoders(self.cfg, self.c_dim, self.hidden_size, self.truncation, self.n_blocks,

@@ -18,11 +18,13 @@ import torch.nn as nn
 from . import _lib as L
 
 ACT = {"none": 0, "None": 0, "tanh": 1, "Tanh": 1, "sigmoid": 2, "Sigmoid": 2}
+# MFMA operand type (us_mlp_desc.precision): parameters, gradients and accumulation are fp32 in both
+PREC = {"fp32": 0, "f32": 0, "float": 0, "bf16": 1, "bfloat16": 1}
 
 
 def make_mlp_desc(n_in, width, n_hidden, n_out, out_act, has_bias, precision=0):
     d = L.MlpDesc(n_in, width, n_hidden, n_out, ACT[out_act] if isinstance(out_act, str) else int(out_act),
-                  1 if has_bias else 0, precision)
+                  1 if has_bias else 0, PREC[precision] if isinstance(precision, str) else int(precision))
     return d
 
 
@@ -79,7 +81,7 @@ class FusedMLP(nn.Module):
         self.n_hidden = int(c.get("n_hidden_layers", 1))
         self.bias = bool(bias)
         self.desc = make_mlp_desc(n_input_dims, self.width, self.n_hidden, n_output_dims,
-                                  c.get("output_activation", "None"), self.bias)
+                                  c.get("output_activation", "None"), self.bias, c.get("precision", "fp32"))
         n = mlp_n_params(self.desc)
         g = torch.Generator().manual_seed(seed)
         # xavier-uniform per matrix like tcnn's FullyFusedMLP::initialize_params; biases (if any) start at zero
@@ -103,7 +105,8 @@ class FusedMLP(nn.Module):
     def __setstate__(self, s):
         self.__dict__.update(s)
         self.desc = make_mlp_desc(self.n_input_dims, self.width, self.n_hidden, self.n_output_dims,
-                                  self.network_config.get("output_activation", "None"), self.bias)
+                                  self.network_config.get("output_activation", "None"), self.bias,
+                                  self.network_config.get("precision", "fp32"))
 
     def __deepcopy__(self, memo):
         new = FusedMLP(self.n_input_dims, self.n_output_dims, self.network_config, self.bias)

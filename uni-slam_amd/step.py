@@ -70,11 +70,7 @@ class MapStep:
     # ------------------------------------------------------------------------------------------ parameters
     def _adopt_parameters(self):
         dec, dev = self.dec, self.device
-        if dec.tcnn_network:
-            self.desc_s, self.desc_c = dec.sdf_decoder.desc, dec.color_decoder.desc
-        else:
-            self.desc_s = make_mlp_desc(dec.c_dim, dec.hidden_size, dec.n_blocks, 1, "tanh", True)
-            self.desc_c = make_mlp_desc(dec.c_dim, dec.hidden_size, dec.n_blocks, 3, "sigmoid", True)
+        self.desc_s, self.desc_c = dec.mlp_descs()
         n_s, n_c = mlp_n_params(self.desc_s), mlp_n_params(self.desc_c)
         self.has_beta = isinstance(dec.beta, nn.Parameter)
         self.o_dec_s, self.o_dec_c, self.o_beta = 0, n_s, n_s + n_c
@@ -300,11 +296,7 @@ class TrackStep:
         self.bhost = bound_host(bound)
         self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
         self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
-        if decoders.tcnn_network:
-            self.desc_s, self.desc_c = decoders.sdf_decoder.desc, decoders.color_decoder.desc
-        else:
-            self.desc_s = make_mlp_desc(decoders.c_dim, decoders.hidden_size, decoders.n_blocks, 1, "tanh", True)
-            self.desc_c = make_mlp_desc(decoders.c_dim, decoders.hidden_size, decoders.n_blocks, 3, "sigmoid", True)
+        self.desc_s, self.desc_c = decoders.mlp_descs()
         self._alloc(max_rays)
 
     def _alloc(self, R):
