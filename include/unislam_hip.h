@@ -68,6 +68,10 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
 /* US_GRID_LEVEL_MAJOR: `out` of us_hashgrid_fwd / `dL_dy` of us_hashgrid_bwd_params are laid out [L][N][F] (each level's
  * plane contiguous) instead of the torch view [N][L*F]; dy_dx is not affected */
 #define US_GRID_LEVEL_MAJOR 2
+/* US_GRID_BWD_OVERWRITE (us_hashgrid_bwd_binned only): every entry of grad_params is WRITTEN (zero where no sample
+ * contributed) instead of added to, so the caller need not clear the table gradient beforehand (what optimizer.zero_grad()
+ * does at src/Mapper.py:443 before loss.backward()). */
+#define US_GRID_BWD_OVERWRITE 4
 
 /* out[N][C] = encode(x[N][3]);  dy_dx[N][C][3] optional (NULL when positions need no gradient) */
 int us_hashgrid_fwd(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n,

@@ -102,6 +102,39 @@ def test_hashgrid_backward(us, mode, log2T, n):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), O.hashgrid_bwd_input(dy, dydx), rtol=2e-4, atol=1e-3)
 
 
+def test_binned_backward_overwrite_and_split_bins(us):
+    """us_hashgrid_bwd_binned: US_GRID_BWD_OVERWRITE writes every entry (grad buffer pre-filled with garbage), the default
+    adds to what is there; 60000 points inside one coarse cell make bins of > ACC_CHUNK records, which several workgroups
+    accumulate (float atomics into entries cleared by the scan pass)."""
+    import ctypes
+    from unislam_amd import _lib as L
+    rng = np.random.default_rng(11)
+    n = 60000
+    x = (0.41 + 0.02 * rng.random((n, 3))).astype(np.float32)
+    x[:5000] = rng.random((5000, 3), dtype=np.float32)
+    dy = rng.standard_normal((n, 32)).astype(np.float32)
+    for log2T in (14, 19):
+        d = O.make_grid_desc(16, 2, log2T, 16, PLS816)
+        enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+        gp = O.hashgrid_bwd_params(d, x, dy)
+        scale = np.abs(gp).max()
+        xd, dyd = T(x).to(DEV), T(dy).to(DEV)
+        nbytes = int(L.lib().us_hashgrid_bwd_workspace_bytes(ctypes.byref(enc.desc), n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        g = torch.full((d.n_params,), 123.0, device=DEV)
+        L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(enc.desc), L.ptr(xd), L.ptr(dyd), n, L.ptr(g), L.US_GRID_BWD_OVERWRITE,
+                                               L.ptr(ws), nbytes, L.stream()), "binned")
+        np.testing.assert_allclose(g.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * scale)
+        base = torch.randn(d.n_params, device=DEV)
+        g2 = base.clone()
+        L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(enc.desc), L.ptr(xd), L.ptr(dyd), n, L.ptr(g2), 0, L.ptr(ws), nbytes,
+                                               L.stream()), "binned")
+        np.testing.assert_allclose((g2 - base).cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * scale + 1e-6)
+        # n == 0 with OVERWRITE clears the gradient
+        L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(enc.desc), None, None, 0, L.ptr(g), L.US_GRID_BWD_OVERWRITE, None, 0, L.stream()), "binned")
+        assert float(g.abs().max()) == 0.0
+
+
 def test_level_major_layout_matches_row_major(us):
     """the fused path's [L][N][F] planes (US_GRID_LEVEL_MAJOR / US_MLP_LEVEL_MAJOR) against the torch-view layout"""
     import ctypes

@@ -44,8 +44,8 @@ int main(int argc, char** argv) {
                 for (int r = 0; r < 3; ++r) us_hashgrid_bwd_binned(&d, x, dy, n, g, lm, ws, wsb, 0);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b);
-                std::vector<uint32_t> hdr(3 * (4096 + 64)); hipMemcpy(hdr.data(), ws, hdr.size() * 4, hipMemcpyDeviceToHost);
-                uint32_t tot = 0, mx = 0, nz = 0; for (int q = 0; q < 4096; ++q) { tot += hdr[q]; if (hdr[q] > mx) mx = hdr[q]; nz += hdr[q] != 0; }
+                std::vector<uint32_t> hdr(2 * (BIN_MAX_TOTAL + 64)); hipMemcpy(hdr.data(), ws, hdr.size() * 4, hipMemcpyDeviceToHost);
+                uint32_t tot = 0, mx = 0, nz = 0; for (int q = 0; q < BIN_MAX_TOTAL; ++q) { tot += hdr[q]; if (hdr[q] > mx) mx = hdr[q]; nz += hdr[q] != 0; }   // bin totals
                 printf("log2T %2u  n %ld  BINNED  layout %s : %8.3f ms   (workspace %.0f MB, records %u of %ld, bins used %u, largest bin %u)\n", log2T, (long)n, lm ? "level-major" : "row-major", ms / 3, wsb / 1e6, tot, (long)n * 128, nz, mx);
             }
             hipFree(ws);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libunislam_hip.so")
 US_MAX_LEVELS = 32
 US_GRID_CLAMP01 = 1
 US_GRID_LEVEL_MAJOR = 2
+US_GRID_BWD_OVERWRITE = 4
 US_MLP_LEVEL_MAJOR = 1
 
 c_f = ctypes.c_void_p          # device pointers travel as void*

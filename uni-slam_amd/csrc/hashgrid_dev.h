@@ -86,3 +86,8 @@ template <> __device__ __forceinline__ void feat_to_array<1>(const float& v, flo
 template <> __device__ __forceinline__ void feat_to_array<2>(const float2& v, float* a) { a[0] = v.x; a[1] = v.y; }
 template <> __device__ __forceinline__ void feat_to_array<4>(const float4& v, float* a) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
 
+
+template <int F> __device__ __forceinline__ void array_to_feat(const float* a, typename Feat<F>::T& v);
+template <> __device__ __forceinline__ void array_to_feat<1>(const float* a, float& v) { v = a[0]; }
+template <> __device__ __forceinline__ void array_to_feat<2>(const float* a, float2& v) { v.x = a[0]; v.y = a[1]; }
+template <> __device__ __forceinline__ void array_to_feat<4>(const float* a, float4& v) { v.x = a[0]; v.y = a[1]; v.z = a[2]; v.w = a[3]; }

@@ -62,14 +62,16 @@ class _HashGridFn(torch.autograd.Function):
             L.check(L.lib().us_hashgrid_bwd_input(L.ptr(dy), L.ptr(dydx), n, desc.n_levels * desc.n_features,
                                                   L.ptr(gx), L.stream()), "us_hashgrid_bwd_input")
         if ctx.needs_input_grad[1]:
-            gp = torch.zeros(desc.n_params, dtype=torch.float32, device=x.device)
             mode = ctx.bwd_mode
-            if mode == 3 or (mode == -1 and n >= 16384):
+            binned = mode == 3 or (mode == -1 and n >= 16384)
+            gp = (torch.empty if binned else torch.zeros)(desc.n_params, dtype=torch.float32, device=x.device)
+            if binned:
                 # bin once, accumulate in f64 (csrc/hashgrid_binned.hip); scratch comes from torch's caching allocator
                 nbytes = int(L.lib().us_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), n))
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-                L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp), ctx.flags, L.ptr(ws),
-                                                       nbytes, L.stream()), "us_hashgrid_bwd_binned")
+                L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp),
+                                                       ctx.flags | L.US_GRID_BWD_OVERWRITE, L.ptr(ws), nbytes, L.stream()),
+                        "us_hashgrid_bwd_binned")
             else:
                 # the sliced kernel streams one level at a time: hand it level-major planes [L][N][F]
                 dy_lm = dy.view(n, desc.n_levels, desc.n_features).permute(1, 0, 2).contiguous()

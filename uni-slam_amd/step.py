@@ -215,7 +215,8 @@ class MapStep:
         L.check(lib.us_loss_grad(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
                                  P(self.rgb), P(self.unc), None, R, S, self.truncation, self.w5, P(self.stats), P(self.g_sdf),
                                  P(self.g_depth), P(self.g_rgb), P(self.loss), st), "us_loss_grad")
-        self.grad.zero_()
+        # the binned table backward writes every table entry (US_GRID_BWD_OVERWRITE): only the decoder segment is cleared
+        (self.grad[:self.o_tab_s] if self.bwd_mode in (-1, 3) else self.grad).zero_()
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
@@ -224,7 +225,7 @@ class MapStep:
         binned = self.ws is not None
         if binned:
             self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                3, P(self.ws), self.ws_bytes, st))
+                                                                                3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, st))
         else:
             self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                 off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
@@ -235,7 +236,7 @@ class MapStep:
                                                           P(self.mlp_ws), self.mlp_ws_bytes, st))
         if binned:
             self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                              3, P(self.ws), self.ws_bytes, st))
+                                                                              3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, st))
         else:
             self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
                                                                               off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
