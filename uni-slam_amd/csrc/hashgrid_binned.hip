@@ -80,6 +80,7 @@ static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
     const uint32_t be = bin_entries(d->n_features);
     uint32_t want = 0;
     while (((int64_t)BIN_TARGET_RECORDS << want) < n * 8 && want < BIN_WANT_MAX) ++want;
+    if (want < 4) want = 4;                                      // >= 16 bins per level: keeps the LDS counters of a wave apart
     for (uint32_t l = 0; l < US_MAX_LEVELS; ++l) {
         bm->first[l] = total; bm->log2nb[l] = 0;
         if (l >= d->n_levels) continue;
@@ -108,144 +109,235 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
 #define DPP_ROW_SHL1 0x101
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
-// one level of one point: corner records after run-combining.  emit[c] says whether this lane owns a record for corner c.
-template <int F>
-struct LevelRecords {
-    float val[8][F];
-    uint32_t idx[8];
-    bool tail;
+// Per-level constants of the binning passes, precomputed on the host: one s_load_dwordx8 per level.
+struct BinLevel {
+    float    scale;
+    uint32_t res, res2;      // dense levels: entry = x + y*res + z*res2 (wrapped once at hs)
+    uint32_t hs;             // entries of the level
+    uint32_t hashed;         // 1: coherent prime hash & (hs-1)
+    uint32_t lg;             // log2(bins of this level)
+    uint32_t first;          // first bin of this level
+    uint32_t packable;       // cell coordinates fit 10 bits each -> run-combining possible
 };
+struct BinLevels { BinLevel l[US_MAX_LEVELS]; };
 
-// COUNT_ONLY: the counting pass needs only WHICH lanes own a record (run tails of live samples) and the 8 entry indices;
-// it counts every corner of every live tail (exactly what the writing pass emits), so it skips the weights, products and scan.
-template <int F, bool COUNT_ONLY>
-__device__ __forceinline__ void level_records(const LevelGeom& g, const float xv[3], const float dy[F], bool live, int lane,
-                                              LevelRecords<F>& r) {
-    float pos[3]; uint32_t cell[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pos_fract(xv[k], g.scale, pos[k], cell[k]);
-    // run key: the cell (resolutions <= 1023 per axis; larger grids get unique keys = no combining)
+static BinLevels make_bin_levels(const us_grid_desc* d, const BinMap& bm) {
+    BinLevels r;
+    memset(&r, 0, sizeof(r));
+    for (uint32_t l = 0; l < d->n_levels; ++l) {
+        BinLevel& q = r.l[l];
+        q.scale = d->scale[l]; q.res = d->resolution[l]; q.res2 = q.res * q.res; q.hs = d->offset[l + 1] - d->offset[l];
+        uint32_t stride = 1; bool early = false;                 // as level_geom() in hashgrid_dev.h
+        for (int dim = 0; dim < 3; ++dim) { if (stride <= q.hs) stride *= q.res; else early = true; }
+        q.hashed = (early || q.hs < stride) ? 1u : 0u;
+        q.lg = bm.log2nb[l]; q.first = bm.first[l];
 #ifdef US_EXP_NO_COMBINE
-    const bool packable = false;
+        q.packable = 0;
 #else
-    const bool packable = g.res <= 1023u;
+        q.packable = q.res <= 1023u ? 1u : 0u;
 #endif
-    uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
-    if (!live || !packable) key = 0xC0000000u | (uint32_t)lane;      // bits 30..31 set: never equals a packed cell, unique per lane
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        if (!COUNT_ONLY) {
-            const float w = corner_weight(c, pos);
-#pragma unroll
-            for (int f = 0; f < F; ++f) r.val[c][f] = live ? w * dy[f] : 0.0f;
-        }
-        r.idx[c] = grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1));
     }
-    // Segmented inclusive scan over aligned groups of 8 lanes (Hillis-Steele with head flags, steps 1, 2, 4).  A run is a
-    // maximal stretch of ADJACENT lanes in the same cell; equal cells that are not adjacent (arbitrary point order) stay
-    // separate runs, so the scan is exact for any input, and simply finds nothing to merge on unordered points.
-    const int l8 = lane & 7;
-    // NB: every DPP move must execute with the whole wave active (a lane disabled by EXEC reads as 0 to its neighbours):
-    // hoist them out of any short-circuit / divergent expression.
-    const uint32_t kprev = dpp_u32<DPP_ROW_SHR(1)>(key), knext = dpp_u32<DPP_ROW_SHL1>(key);
-    bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
-    const bool next_is_head = (l8 == 7) | (knext != key);
-#define US_SCAN_STEP(O)                                                                                              \
-    if (!COUNT_ONLY && __ballot(!flag && (l8 >= (O))) != 0ull) {   /* wave-uniform: nothing left to merge -> skip the step */ \
-        const bool take = !flag && (l8 >= (O));                                                                      \
-        const bool fprev = dpp_u32<DPP_ROW_SHR(O)>(flag ? 1u : 0u) != 0u;                                            \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                               \
-            _Pragma("unroll") for (int f = 0; f < F; ++f) {                                                         \
-                const float t = dpp_f32<DPP_ROW_SHR(O)>(r.val[c][f]);                                                \
-                r.val[c][f] += take ? t : 0.0f;                                                                      \
-            }                                                                                                        \
-        flag = flag | ((l8 >= (O)) & fprev);                                                                         \
-    }
-    US_SCAN_STEP(1)
-    US_SCAN_STEP(2)
-    US_SCAN_STEP(4)
-#undef US_SCAN_STEP
-    r.tail = live & next_is_head;
+    return r;
 }
 
-// A0 (WRITE = false): wg_counts[workgroup][bin] = records this workgroup will emit (every corner of every live run tail).
-// A1 (WRITE = true) : LDS counters start at the workgroup's range starts (bin offset + column prefix); the LDS atomic of
-//                     each record returns its final slot, and the record is stored at once.
+// Binning passes.  Every workgroup takes 1024 consecutive points through all levels.  Per level and point:
+//   cell, fractional position, the 8 entry indices (hash: two 32-bit multiplies, the +1 vertices by adding the primes;
+//   dense: two 24-bit mads, the wrap-around at hs as one unsigned min);
+//   RUN-COMBINING: lanes of an aligned group of 8 (= 8 consecutive samples of a ray) that sit in the same cell form runs;
+//   a segmented inclusive scan (Hillis-Steele, DPP row_shr 1/2/4 fused into v_fmac) sums the 8 x F corner products of a
+//   run into its last lane, which alone emits records.  Equal cells that are not adjacent stay separate runs: exact for
+//   any point order.  NB every DPP move executes with the whole wave active (a disabled lane reads as 0).
+//   A0 (WRITE = false): wg_counts[workgroup][bin] = records this workgroup will emit (every corner of every live run tail).
+//   A1 (WRITE = true) : the LDS counters start at the workgroup's range starts (bin offset + column prefix), so the
+//                       returning LDS atomic IS the record's final slot; the 12-byte record is stored at once.
+#define BIN_STAGE_RECORDS (BIN_THREADS * 8)   // records one workgroup emits per level at most
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (s_waitcnt vmcnt(0)), which would drain the record stores of the previous level twice per level; the stage protocol
+// below needs only the LDS reads/writes of all waves to have completed.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int F, bool WRITE>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, uint32_t n_levels, const float* __restrict__ x,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_levels, uint32_t TB, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
-                                                     uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ rec) {
+                                                     uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ wg_prefix,
+                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec) {
+    // lcnt: COUNT pass: records per bin.  WRITE pass: cursor into the workgroup's LDS stage, where the records of one level
+    // are collected sorted by bin (counting sort: the exclusive scan of this workgroup's own counts gives every bin's place).
+    // (F = 4 records do not fit a stage beside the counters: that instantiation stores every record straight from the
+    //  lane that owns it, lcnt being the global cursor.)
+    constexpr bool STAGED = WRITE && F <= 2;
     __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
-    const uint32_t TB = bm.first[n_levels];
+    __shared__ uint32_t gpos[STAGED ? BIN_MAX_TOTAL : 1];                      // first global record slot of (workgroup, bin)
+    __shared__ uint32_t st_loc[STAGED ? BIN_STAGE_RECORDS : 1];
+    __shared__ float    st_val[STAGED ? F : 1][STAGED ? BIN_STAGE_RECORDS : 1];
     uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL;
-    for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = WRITE ? offsets[t] + row[t] : 0u;
+    if (WRITE && !STAGED) {
+        const uint32_t* pre = wg_prefix + (size_t)blockIdx.x * BIN_MAX_TOTAL;
+        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = offsets[t] + pre[t];
+    } else if (WRITE) {
+        uint32_t* sc = st_loc;                                   // scan scratch (the stage is not in use yet)
+        uint32_t c4[4], s4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c4[k] = (4 * threadIdx.x + k < TB) ? row[4 * threadIdx.x + k] : 0u; s4 += c4[k]; }
+        sc[threadIdx.x] = s4;
+        __syncthreads();
+        for (uint32_t o = 1; o < BIN_THREADS; o <<= 1) {
+            const uint32_t v = (threadIdx.x >= o) ? sc[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = sc[threadIdx.x] - s4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (4 * threadIdx.x + k < TB) lcnt[4 * threadIdx.x + k] = run; run += c4[k]; }
+        const uint32_t* pre = wg_prefix + (size_t)blockIdx.x * BIN_MAX_TOTAL;
+        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) gpos[t] = offsets[t] + pre[t];
+    } else {
+        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0u;
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, l8 = lane & 7;
     const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
     const bool in = i < n;
-    const uint32_t C = n_levels * F;
     float xv[3] = {0.f, 0.f, 0.f};
     if (in) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) xv[k] = load_x(x, i, k, clamp);
     }
-    // all levels' gradients of this point are fetched up front (one memory round trip instead of one per level)
-    constexpr int LCH = 16;
-    float dyv[LCH][F];
+    typedef typename Feat<F>::T FT;
+    // The gradients of all levels of this point are fetched up front ([L][N][F] planes or rows of [N][L*F]) and held in
+    // registers, indexed by the wave-uniform level: the level loop of the writing pass must not wait on loads, because on
+    // gfx9 a wait for a load also waits for every record store issued before it (one vmcnt for both).
+    const int64_t dy_base = lm ? i * F : i * (int64_t)(n_levels * F), dy_step = lm ? n * F : (int64_t)F;
+    float dyv[US_MAX_LEVELS * F];
+#pragma unroll
+    for (int l = 0; l < US_MAX_LEVELS; ++l) {
+        float t[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) t[f] = 0.0f;
+        if (in && (uint32_t)l < n_levels) feat_to_array<F>(*reinterpret_cast<const FT*>(dL_dy + dy_base + (int64_t)l * dy_step), t);
+#pragma unroll
+        for (int f = 0; f < F; ++f) dyv[l * F + f] = t[f];
+    }
     for (uint32_t level = 0; level < n_levels; ++level) {
-        if ((level % LCH) == 0) {
-#pragma unroll
-            for (int q = 0; q < LCH; ++q)
-#pragma unroll
-                for (int f = 0; f < F; ++f)
-                    dyv[q][f] = (in && level + q < n_levels) ? dL_dy[feat_index(lm, i, n, level + q, C, F) + f] : 0.0f;
-        }
-        const LevelGeom g = level_geom(tab, level);
-        const uint32_t lg = bm.log2nb[level], first = bm.first[level];
-        float dy[F]; bool live = false;
+        const BinLevel q = lv.l[level];
+        float dy[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) dy[f] = 0.0f;
+        // static register indexing behind a scalar jump: the empty asm keeps the compiler from turning the (wave-uniform)
+        // switch into a chain of 32 x F selects, and from moving the array to scratch memory
+#define US_DY_CASE(Q) case Q: { asm volatile("" ::: "memory"); _Pragma("unroll") for (int f = 0; f < F; ++f) dy[f] = dyv[(Q) * F + f]; } break;
+        switch (level) {
+            US_DY_CASE(0) US_DY_CASE(1) US_DY_CASE(2) US_DY_CASE(3) US_DY_CASE(4) US_DY_CASE(5) US_DY_CASE(6) US_DY_CASE(7)
+            US_DY_CASE(8) US_DY_CASE(9) US_DY_CASE(10) US_DY_CASE(11) US_DY_CASE(12) US_DY_CASE(13) US_DY_CASE(14) US_DY_CASE(15)
+            US_DY_CASE(16) US_DY_CASE(17) US_DY_CASE(18) US_DY_CASE(19) US_DY_CASE(20) US_DY_CASE(21) US_DY_CASE(22) US_DY_CASE(23)
+            US_DY_CASE(24) US_DY_CASE(25) US_DY_CASE(26) US_DY_CASE(27) US_DY_CASE(28) US_DY_CASE(29) US_DY_CASE(30) US_DY_CASE(31)
+            default: break;
+        }
+#undef US_DY_CASE
+        bool live = false;
 #pragma unroll
-        for (int q = 0; q < LCH; ++q)                           // static register indexing (level % LCH is wave-uniform)
-            if ((int)(level % LCH) == q) {
+        for (int f = 0; f < F; ++f) live |= (dy[f] != 0.0f);
+        const uint32_t lbase = STAGED ? lcnt[q.first] : 0u;      // stage slot 0 of this level, read before anyone adds to it;
+        if (STAGED) lds_barrier();                               // the barrier also ends the previous level's copy-out
+        if (__ballot(live) != 0ull) {                            // a wave whose samples all have zero gradient skips the level
+        // ---- cell and position
+        float pos[3]; uint32_t cell[3];
 #pragma unroll
-                for (int f = 0; f < F; ++f) { dy[f] = dyv[q][f]; live |= (dy[f] != 0.0f); }
+        for (int k = 0; k < 3; ++k) pos_fract(xv[k], q.scale, pos[k], cell[k]);
+        // ---- runs
+        uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
+        if (!live || !q.packable) key = 0xC0000000u | (uint32_t)lane;   // never equals a packed cell, unique per lane
+        const uint32_t kprev = dpp_u32<DPP_ROW_SHR(1)>(key), knext = dpp_u32<DPP_ROW_SHL1>(key);
+        bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
+        const bool tail = live & ((l8 == 7) | (knext != key));
+        // ---- entry indices
+        uint32_t idx[8];
+        if (q.hashed) {                                          // wave-uniform
+            const uint32_t hx[2] = {cell[0], cell[0] + 1u};
+            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
+            const uint32_t hy[2] = {hy0, hy0 + 2654435761u}, hz[2] = {hz0, hz0 + 805459861u};
+            const uint32_t mask = q.hs - 1u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) idx[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask;
+        } else {
+            const uint32_t base = cell[0] + __umul24(cell[1], q.res) + __umul24(cell[2], q.res2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t e = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? q.res : 0u) + ((c & 4) ? q.res2 : 0u);
+                idx[c] = min(e, e - q.hs);                       // e < 2*hs: one conditional subtraction == e % hs
             }
-        if (__ballot(live) == 0ull) continue;                    // a wave whose samples all have zero gradient skips the level
-        LevelRecords<F> r;
-        level_records<F, !WRITE>(g, xv, dy, live, lane, r);
-        // Both passes emit EVERY corner of every live run tail (a corner whose weight is exactly 0 becomes a zero record),
-        // so the counted ranges are exact.
-        const bool e = r.tail;
-        const unsigned long long mask = __ballot(e);
-        if (mask == 0ull) continue;
+        }
+        // ---- corner products and their segmented scan (only the writing pass needs the values)
+        float val[8][F];
+        if (WRITE) {
+            const float a0[2] = {1.0f - pos[0], pos[0]}, a1[2] = {1.0f - pos[1], pos[1]}, a2[2] = {1.0f - pos[2], pos[2]};
+            float wxy[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t b = first + bin_of(r.idx[c], lg);
-            uint32_t slot = 0;
-            // With few bins (small batches) every emitting lane of the wave tends to hit the same bin: one LDS atomic for the
-            // wave instead of <= 64 serialised ones.  With hundreds of bins per level the lanes scatter and plain LDS integer
-            // atomics (7 cycles per wave instruction) are cheapest.
-            bool done = false;
-            if (lg <= 1) {                                       // wave-uniform
-                const int lead = __ffsll((long long)mask) - 1;
-                const uint32_t b0 = __builtin_amdgcn_readlane(b, lead);
-                if (__ballot(e && b == b0) == mask) {
-                    uint32_t base = 0;
-                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (e && mb == 0) base = atomicAdd(&lcnt[b0], (uint32_t)__popcll(mask));
-                    base = __builtin_amdgcn_readlane(base, lead);
-                    slot = base + mb;
-                    done = true;
+            for (int c = 0; c < 4; ++c) wxy[c] = a0[c & 1] * a1[c >> 1];              // tcnn's order: ((1*a0)*a1)*a2
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = wxy[c & 3] * a2[c >> 2];
+#pragma unroll
+                for (int f = 0; f < F; ++f) val[c][f] = w * dy[f];                     // dy == 0 on dead lanes
+            }
+#define US_SCAN_STEP(O)                                                                                              \
+            if (__ballot(!flag && (l8 >= (O))) != 0ull) {        /* wave-uniform: nothing left to merge -> skip the step */ \
+                const float takef = (!flag && (l8 >= (O))) ? 1.0f : 0.0f;                                            \
+                const bool fprev = dpp_u32<DPP_ROW_SHR(O)>(flag ? 1u : 0u) != 0u;                                    \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                       \
+                    _Pragma("unroll") for (int f = 0; f < F; ++f)                                                   \
+                        val[c][f] = fmaf(dpp_f32<DPP_ROW_SHR(O)>(val[c][f]), takef, val[c][f]);   /* t*1+v == t+v */  \
+                flag = flag | ((l8 >= (O)) & fprev);                                                                 \
+            }
+            US_SCAN_STEP(1)
+            US_SCAN_STEP(2)
+            US_SCAN_STEP(4)
+#undef US_SCAN_STEP
+        }
+        // ---- emit: every corner of every live run tail (a corner whose weight is exactly 0 becomes a zero record, so the
+        //      counted ranges are exact)
+        if (tail) {
+            const uint32_t nbm = (1u << q.lg) - 1u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
+                if (STAGED) {
+                    const uint32_t slot = atomicAdd(&lcnt[b], 1u) - lbase;
+                    st_loc[slot] = local_of(idx[c], q.lg);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) st_val[f][slot] = val[c][f];
+                } else if (WRITE) {
+                    const uint32_t slot = atomicAdd(&lcnt[b], 1u);
+                    uint32_t* dst = rec + (size_t)slot * RecW<F>::DW;
+                    dst[0] = local_of(idx[c], q.lg);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(val[c][f]);
+                } else {
+                    atomicAdd(&lcnt[b], 1u);
                 }
             }
-            if (!done && e) slot = atomicAdd(&lcnt[b], 1u);
-            if (WRITE && e) {
-                uint32_t* dst = rec + (size_t)slot * RecW<F>::DW;
-                dst[0] = local_of(r.idx[c], lg);
+        }
+        }   // wave has live samples
+        if (STAGED) {
+            // ---- copy the level's records out: the stage holds them sorted by bin, bin t at [lcnt[t-1], lcnt[t]) - lbase;
+            //      16 lanes per bin write its records as one contiguous run
+            lds_barrier();
+            const uint32_t nb = 1u << q.lg, grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+            for (uint32_t bl = grp; bl < nb; bl += BIN_THREADS / 16) {
+                const uint32_t t = q.first + bl;
+                const uint32_t e0 = (bl == 0 ? lbase : lcnt[t - 1]) - lbase, e1 = lcnt[t] - lbase;
+                const uint32_t g0 = gpos[t];
+                for (uint32_t k = e0 + l16; k < e1; k += 16) {
+                    struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
+                    RecT r;
+                    r.w[0] = st_loc[k];
 #pragma unroll
-                for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(r.val[c][f]);
+                    for (int f = 0; f < F; ++f) r.w[1 + f] = __float_as_uint(st_val[f][k]);
+                    const uint32_t slot = g0 + (k - e0);
+                    const uint32_t byte_off = RecW<F>::DW == 3 ? (slot << 3) + (slot << 2) : slot * (uint32_t)(RecW<F>::DW * 4);   // < 2^32 (host check)
+                    *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;
+                }
             }
         }
     }
@@ -255,26 +347,30 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(LevelTable tab, BinMap bm, 
     }
 }
 
-// column scan: wg_counts[w][b] <- sum of wg_counts[w'][b] over w' < w ; totals[b] = column sum.
+// column scan: wg_prefix[w][b] = sum of wg_counts[w'][b] over the workgroups w' ordered before w ; totals[b] = column sum.
 // In OVERWRITE mode the bins that will be split over several accumulate workgroups (total > ACC_CHUNK, added with float
 // atomics) get their gradient entries cleared here, two kernels ahead of the first add.
 #define COLSCAN_THREADS 64
 template <int F>
-__global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab, BinMap bm, uint32_t n_levels, uint32_t* __restrict__ wg_counts,
-                                                                 uint32_t n_wg, uint32_t TB, uint32_t* __restrict__ totals,
+__global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab, BinMap bm, uint32_t n_levels, const uint32_t* __restrict__ wg_counts,
+                                                                 uint32_t* __restrict__ wg_prefix, uint32_t n_wg, uint32_t TB, uint32_t* __restrict__ totals,
                                                                  float* __restrict__ grad, int overwrite) {
     const uint32_t b = blockIdx.x * COLSCAN_THREADS + threadIdx.x;
     uint32_t run = 0;
     if (b < TB) {
-        uint32_t w = 0;
-        for (; w + 8 <= n_wg; w += 8) {
-            uint32_t v[8];
+        // Order of the workgroups' segments inside a bin: by XCD first (workgroup w runs on XCD w % 8), so that the ~300-byte
+        // segments written through one XCD's L2 are neighbours and their cache lines leave that L2 completely written.
+        for (uint32_t xcd = 0; xcd < 8; ++xcd) {
+            uint32_t w = xcd;
+            for (; w + 56 < n_wg; w += 64) {
+                uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = wg_counts[(size_t)(w + k) * BIN_MAX_TOTAL + b];
+                for (int k = 0; k < 8; ++k) v[k] = wg_counts[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { wg_counts[(size_t)(w + k) * BIN_MAX_TOTAL + b] = run; run += v[k]; }
+                for (int k = 0; k < 8; ++k) { wg_prefix[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b] = run; run += v[k]; }
+            }
+            for (; w < n_wg; w += 8) { const uint32_t v = wg_counts[(size_t)w * BIN_MAX_TOTAL + b]; wg_prefix[(size_t)w * BIN_MAX_TOTAL + b] = run; run += v; }
         }
-        for (; w < n_wg; ++w) { const uint32_t v = wg_counts[(size_t)w * BIN_MAX_TOTAL + b]; wg_counts[(size_t)w * BIN_MAX_TOTAL + b] = run; run += v; }
         totals[b] = run;
     }
     if (!overwrite) return;
@@ -419,11 +515,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 // workspace: totals | offsets (2 x (BIN_MAX_TOTAL + 64) u32) | n_extra (16 u32) | extra[e_max] | per-workgroup count rows
-// [n_wg][BIN_MAX_TOTAL] | records
+// [n_wg][BIN_MAX_TOTAL] | their column prefixes [n_wg][BIN_MAX_TOTAL] | records
 static uint32_t extra_max(const us_grid_desc* d, int64_t n) { return (uint32_t)(((uint64_t)n * 8ull * d->n_levels) / ACC_CHUNK) + 1u; }
 static size_t header_bytes(const us_grid_desc* d, int64_t n) {
     const size_t em = ((size_t)extra_max(d, n) + 15u) & ~(size_t)15u;
-    return (size_t)(2 * (BIN_MAX_TOTAL + 64) + 16 + em) * sizeof(uint32_t) + (size_t)us_cdiv(n, BIN_THREADS) * BIN_MAX_TOTAL * sizeof(uint32_t);
+    return (size_t)(2 * (BIN_MAX_TOTAL + 64) + 16 + em) * sizeof(uint32_t) + 2 * (size_t)us_cdiv(n, BIN_THREADS) * BIN_MAX_TOTAL * sizeof(uint32_t);
 }
 
 extern "C" size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* d, int64_t n) {
@@ -453,7 +549,10 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     BinMap bm;
     const int TB = make_binmap(d, n, &bm);
     US_REQUIRE(TB > 0 && TB <= BIN_MAX_TOTAL, US_ERR_CONFIG, "us_hashgrid_bwd_binned: %d bins > %d (table too large for this path)", TB, BIN_MAX_TOTAL);
+    US_REQUIRE((uint64_t)n * 8ull * d->n_levels * rec_dwords(d->n_features) * 4ull <= 0xFFFFFFFFull, US_ERR_SHAPE,
+               "us_hashgrid_bwd_binned: n = %lld too large for 32-bit record offsets (split the batch)", (long long)n);
     const LevelTable t = make_table(d);
+    const BinLevels lv = make_bin_levels(d, bm);
     hipStream_t s = (hipStream_t)stream;
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
     const uint32_t e_max = extra_max(d, n);
@@ -464,17 +563,18 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     uint32_t* wg_counts = extra + (((size_t)e_max + 15u) & ~(size_t)15u);
     uint32_t* rec = (uint32_t*)((char*)workspace + header_bytes(d, n));
     const uint32_t n_wg = (uint32_t)us_cdiv(n, BIN_THREADS);
+    uint32_t* wg_prefix = wg_counts + (size_t)n_wg * BIN_MAX_TOTAL;
     dim3 gridA(n_wg), block(BIN_THREADS);
     const uint32_t L = d->n_levels;
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0;
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #define LAUNCH_BIN(F)                                                                                                          \
-    hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, wg_counts, offsets, rec);      \
-    hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_THREADS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, n_wg, \
+    hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
+    hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_THREADS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
                        (uint32_t)TB, totals, grad_params, overwrite);                                                          \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
-    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, t, bm, L, x, dL_dy, n, clamp, lm, wg_counts, offsets, rec);       \
+    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
     hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
                        grad_params, overwrite);
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
