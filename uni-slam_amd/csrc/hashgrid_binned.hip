@@ -348,37 +348,55 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
 }
 
 // column scan: wg_prefix[w][b] = sum of wg_counts[w'][b] over the workgroups w' ordered before w ; totals[b] = column sum.
+// Order of the workgroups' segments inside a bin: by XCD first (workgroup w runs on XCD w % 8), so that the ~300-byte
+// segments written through one XCD's L2 are neighbours.  8 lanes per bin, one per XCD class: each sums its class (pass 1),
+// the classes are scanned across the 8 lanes, and pass 2 writes the prefixes.
 // In OVERWRITE mode the bins that will be split over several accumulate workgroups (total > ACC_CHUNK, added with float
 // atomics) get their gradient entries cleared here, two kernels ahead of the first add.
 #define COLSCAN_THREADS 64
+#define COLSCAN_BINS (COLSCAN_THREADS / 8)
 template <int F>
 __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab, BinMap bm, uint32_t n_levels, const uint32_t* __restrict__ wg_counts,
-                                                                 uint32_t* __restrict__ wg_prefix, uint32_t n_wg, uint32_t TB, uint32_t* __restrict__ totals,
-                                                                 float* __restrict__ grad, int overwrite) {
-    const uint32_t b = blockIdx.x * COLSCAN_THREADS + threadIdx.x;
-    uint32_t run = 0;
-    if (b < TB) {
-        // Order of the workgroups' segments inside a bin: by XCD first (workgroup w runs on XCD w % 8), so that the ~300-byte
-        // segments written through one XCD's L2 are neighbours and their cache lines leave that L2 completely written.
-        for (uint32_t xcd = 0; xcd < 8; ++xcd) {
-            uint32_t w = xcd;
-            for (; w + 56 < n_wg; w += 64) {
-                uint32_t v[8];
+                                                                 uint32_t* __restrict__ wg_prefix, uint32_t n_wg, uint32_t TB,
+                                                                 uint32_t* __restrict__ totals, float* __restrict__ grad, int overwrite) {
+    const uint32_t xcd = threadIdx.x & 7u;
+    const uint32_t b = blockIdx.x * COLSCAN_BINS + (threadIdx.x >> 3);
+    const bool ok = b < TB;
+    uint32_t sum = 0;
+    if (ok) {
+        uint32_t w = xcd;
+        for (; w + 56 < n_wg; w += 64) {
+            uint32_t v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = wg_counts[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b];
+            for (int k = 0; k < 8; ++k) v[k] = wg_counts[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { wg_prefix[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b] = run; run += v[k]; }
-            }
-            for (; w < n_wg; w += 8) { const uint32_t v = wg_counts[(size_t)w * BIN_MAX_TOTAL + b]; wg_prefix[(size_t)w * BIN_MAX_TOTAL + b] = run; run += v; }
+            for (int k = 0; k < 8; ++k) sum += v[k];
         }
-        totals[b] = run;
+        for (; w < n_wg; w += 8) sum += wg_counts[(size_t)w * BIN_MAX_TOTAL + b];
+    }
+    uint32_t incl = sum;                                         // inclusive scan over the 8 XCD classes of the bin
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 8); if ((int)xcd >= o) incl += t; }
+    const uint32_t total = __shfl(incl, 7, 8);
+    if (ok) {
+        uint32_t run = incl - sum;
+        uint32_t w = xcd;
+        for (; w + 56 < n_wg; w += 64) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = wg_counts[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { wg_prefix[(size_t)(w + 8 * k) * BIN_MAX_TOTAL + b] = run; run += v[k]; }
+        }
+        for (; w < n_wg; w += 8) { const uint32_t v = wg_counts[(size_t)w * BIN_MAX_TOTAL + b]; wg_prefix[(size_t)w * BIN_MAX_TOTAL + b] = run; run += v; }
+        if (xcd == 0) totals[b] = total;
     }
     if (!overwrite) return;
-    unsigned long long hot = __ballot(b < TB && run > ACC_CHUNK);
+    unsigned long long hot = __ballot(ok && xcd == 0 && total > ACC_CHUNK);
     while (hot) {                                                // wave-uniform loop (one wave per workgroup)
         const int src = __ffsll((long long)hot) - 1;
         hot &= hot - 1ull;
-        const uint32_t hb = blockIdx.x * COLSCAN_THREADS + (uint32_t)src;
+        const uint32_t hb = blockIdx.x * COLSCAN_BINS + ((uint32_t)src >> 3);
         uint32_t level = 0;
         for (uint32_t l = 1; l < n_levels; ++l) level += (bm.first[l] <= hb) ? 1u : 0u;
         const uint32_t lg = bm.log2nb[level], bl = hb - bm.first[level], hs = tab.off[level + 1] - tab.off[level];
@@ -571,7 +589,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #define LAUNCH_BIN(F)                                                                                                          \
     hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
-    hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_THREADS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
+    hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
                        (uint32_t)TB, totals, grad_params, overwrite);                                                          \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
     hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
