@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--bwd-mode", type=int, default=-1)
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
                     help="MFMA operand type of the decoders; the headline (parity-tested to 1e-3) is fp32")
+    ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
@@ -204,7 +205,7 @@ def main():
         dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
-                        group=True if world > 1 else None, bwd_mode=args.bwd_mode)
+                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=not args.no_overlap)
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)
@@ -220,7 +221,9 @@ def main():
     for _ in range(args.warmup):
         step.iterate(ro, rd, gd, gc, has_zero_depth=False)
     if not args.no_probe:
-        step.probe = {}
+        step.probe = {}                 # every 10th timed step carries HIP events around the hot kernels (and runs its two
+        step.probe_every = 10 if args.steps >= 50 else max(1, args.steps // 5)   # branches on one stream: the kernels' own durations)
+        step._it = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

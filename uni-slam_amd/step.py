@@ -35,16 +35,18 @@ def _align(n, a=64):
 
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1):
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=True):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
         lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
         group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
+        overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch.
         """
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
+        self.overlap, self.side = bool(overlap), None
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
             raise L.UniSlamHipError("MapStep needs the model on the GPU")
@@ -63,6 +65,8 @@ class MapStep:
         self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
         self.lr = dict(lr)
         self.probe = None               # dict name -> [(start_event, end_event)]: per-kernel HIP-event timing (bench.py)
+        self.probe_every = 1            # with self.probe set: every k-th iteration is a probing one (events around the
+        self._it, self._probing = 0, False   # launches, both branches on ONE stream so that durations are the kernels' own)
         self._adopt_parameters()
         self._alloc(max_rays)
         self.reset_optimizer(1.0)
@@ -135,14 +139,50 @@ class MapStep:
         lib = L.lib()
         self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
-        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
+        # one scratch set per branch (sdf / colour): the two branches run on two streams
+        mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
+        self.ws, self.ws_s = mk_ws(), (mk_ws() if self.overlap else None)
         self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
                                 int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
+        self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev) if self.overlap else self.mlp_ws
+        if self.ws_s is None:
+            self.ws_s = self.ws
+
+    class _Branch:
+        """`with step._branch() as st2:` -- the launches inside go to the side stream (st2 = its handle), which first waits
+        for everything queued on the main stream; _join() makes the main stream wait for the side stream.  Without overlap
+        the block simply runs on the main stream."""
+        def __init__(self, step):
+            self.step = step
+
+        def __enter__(self):
+            s = self.step
+            self.on = s.overlap and not s._probing
+            if not self.on:
+                return L.stream()
+            if s.side is None:
+                s.side = torch.cuda.Stream(device=s.device)
+            s.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(s.side)
+            self.ctx.__enter__()
+            return L.stream()
+
+        def __exit__(self, *a):
+            if self.on:
+                self.ctx.__exit__(*a)
+            return False
+
+    def _branch(self):
+        return MapStep._Branch(self)
+
+    def _join(self):
+        if self.overlap and not self._probing and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _timed(self, name, rc_fn):
         """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
-        if self.probe is None:
+        if not self._probing:
             L.check(rc_fn(), name)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -160,6 +200,8 @@ class MapStep:
         importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
         """
         lib, st = L.lib(), L.stream()
+        self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
+        self._it += 1
         o, d, gd, gc = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()), L.f32(gt_color.detach())
         R, S = o.shape[0], self.S
         if R > self.max_rays:
@@ -184,10 +226,13 @@ class MapStep:
         fl = self.flat
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st))
+        # the sdf and the colour branch are independent between the sample points and the compositing: two streams
+        with self._branch() as st2:
+            self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
+            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
         self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
-        self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
         self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
+        self._join()
         beta = off(fl, self.o_beta)
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), beta, R, S, P(self.term), P(self.unc), P(self.depth), P(self.rgb),
                                      P(self.dunc), None, st), "us_composite_fwd")
@@ -220,9 +265,19 @@ class MapStep:
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
+        binned = self.ws is not None
+        with self._branch() as st2:                              # sdf branch on the side stream
+            self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
+                                                              off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                              P(self.mlp_ws_s), self.mlp_ws_bytes, st2))
+            if binned:
+                self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE, P(self.ws_s), self.ws_bytes, st2))
+            else:
+                self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
+                                                                                  off(self.grad, self.o_tab_s), self.bwd_mode, 3, st2))
         self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                             N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
-        binned = self.ws is not None
         if binned:
             self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
                                                                                 3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, st))
@@ -231,15 +286,7 @@ class MapStep:
                                                                                 off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
         if on_ready is not None:
             on_ready(self.grad[self.o_tab_c:])
-        self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                          off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
-                                                          P(self.mlp_ws), self.mlp_ws_bytes, st))
-        if binned:
-            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                              3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, st))
-        else:
-            self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
-                                                                              off(self.grad, self.o_tab_s), self.bwd_mode, 3, st))
+        self._join()
         if on_ready is not None:
             on_ready(self.grad[:self.o_tab_c])
         self.n_rays = R
