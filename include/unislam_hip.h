@@ -158,6 +158,15 @@ int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals,
 int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
                       int n_samples, float* dL_do, float* dL_dd, void* stream);
 
+/* us_bbox_filter + us_sample_z + us_ray_points in ONE launch, value for value (the iteration of src/Mapper.py:396-406 +
+ * src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  perturb != 0: jitter with t_rand[R][S], or,
+ * when t_rand is NULL, with an in-kernel counter-based uniform generator seeded by rng_seed (the reference draws
+ * torch.rand there, Renderer.py:54; any iid U[0,1) stream serves).  valid may be NULL. */
+int us_sample_points(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
+                     int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf, int n_imp, float c_free,
+                     float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, int perturb,
+                     int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream);
+
 /* bounding-box pre-filter (Mapper.py:396-402, Tracker.py:177-184): far = min_dim max((lo-o)/d, (hi-o)/d);
  * valid[i] = far >= gt_depth[i] (&& gt_depth[i] > 0 when require_depth); far_out[R] optional (Renderer.py:108-113) */
 int us_bbox_filter(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
@@ -213,6 +222,13 @@ int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* 
 /* torch.optim.Adam semantics (amsgrad off, weight_decay 0); step = 1-based step count after increment */
 int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);
+
+/* the same over n_seg (<= 8) segments [seg_off[k], seg_off[k] + seg_n[k]) of one flat buffer in ONE launch, each segment with
+ * its own learning rate -- the optimizer's param_groups (src/Mapper.py:118-126: decoders, sdf tables, colour tables);
+ * seg_off / seg_n / seg_lr are HOST arrays */
+int us_adam_step_segments(float* p, const float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+                          const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
+                          void* stream);
 
 /* the same with the 1-based step count in device memory (float[1]): nothing step-dependent is baked into the launch, so the
  * call can sit inside a captured hipGraph (torch.optim.Adam(capturable=True) arithmetic: bias corrections in fp32) */

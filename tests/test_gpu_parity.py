@@ -658,3 +658,67 @@ def test_adam_matches_torch(us):
         pt.grad = gr.clone(); opt.step()
         L.check(L.lib().us_adam_step(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), n, 0.05, 0.9, 0.999, 1e-8, step, L.stream()), "adam")
     close(p, pt.detach(), 2e-5, 2e-6)
+
+
+def test_sample_points_equals_the_three_kernels(us):
+    """us_sample_points (filter + z + points in one launch) against us_bbox_filter / us_sample_z / us_ray_points, bit for bit;
+    the in-kernel jitter generator yields iid-looking U[0,1) draws (mean, variance, range) and depends on the seed."""
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    R, ns, ni = 1003, 48, 16
+    S = ns + ni
+    bound = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+    bh = us.common.bound_host(bound)
+    o = (torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05).to(DEV)
+    d = torch.randn(R, 3, generator=g); d = (d / d.norm(dim=-1, keepdim=True)).to(DEV)
+    gd = (torch.rand(R, generator=g) * 6 + 0.2).to(DEV)                      # some beyond the box -> invalid
+    tr = torch.rand(R, S, generator=g).to(DEV)
+    tu, ts = torch.linspace(0., 1., ns).to(DEV), torch.linspace(0., 1., ni).to(DEV)
+    cf, so, sp = ctypes.c_float(1.2), ctypes.c_float(1.5 * 0.06), ctypes.c_float(3 * 0.06)
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    v0 = torch.empty(R, dtype=torch.uint8, device=DEV); z0 = torch.empty(R, S, device=DEV); p0 = torch.empty(R, S, 3, device=DEV)
+    L.check(lib.us_bbox_filter(P(o), P(d), P(gd), bh, R, 0, P(v0), None, st), "f")
+    L.check(lib.us_sample_z(P(gd), R, P(tu), ns, P(ts), ni, cf, so, sp, P(tr), P(z0), st), "z")
+    L.check(lib.us_ray_points(P(o), P(d), P(z0), bh, R, S, P(p0), st), "p")
+    v1 = torch.empty_like(v0); z1 = torch.empty_like(z0); p1 = torch.empty_like(p0)
+    L.check(lib.us_sample_points(P(o), P(d), P(gd), bh, R, P(tu), ns, P(ts), ni, cf, so, sp, P(tr), 0, 1, 0, P(v1), P(z1), P(p1), st), "sp")
+    assert torch.equal(v0, v1) and torch.equal(z0, z1) and torch.equal(p0, p1)
+    assert 0 < int(v1.sum()) < R
+    # unperturbed
+    L.check(lib.us_sample_z(P(gd), R, P(tu), ns, P(ts), ni, cf, so, sp, None, P(z0), st), "z")
+    L.check(lib.us_sample_points(P(o), P(d), P(gd), bh, R, P(tu), ns, P(ts), ni, cf, so, sp, None, 0, 0, 0, P(v1), P(z1), P(p1), st), "sp")
+    assert torch.equal(z0, z1)
+    # in-kernel generator: recover u from z = lower + (upper - lower) * u
+    mids = 0.5 * (z0[:, 1:] + z0[:, :-1])
+    lower = torch.cat([z0[:, :1], mids], -1); upper = torch.cat([mids, z0[:, -1:]], -1)
+    us_ = []
+    for seed in (1, 2):
+        L.check(lib.us_sample_points(P(o), P(d), P(gd), bh, R, P(tu), ns, P(ts), ni, cf, so, sp, None, seed, 1, 0, P(v1), P(z1), P(p1), st), "sp")
+        ok = (upper - lower) > 1e-4
+        u = ((z1 - lower) / (upper - lower))[ok]
+        assert float(u.min()) >= -1e-3 and float(u.max()) <= 1 + 1e-3
+        assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 3e-3
+        us_.append(z1.clone())
+    assert not torch.equal(us_[0], us_[1])
+
+
+def test_adam_segments_equals_adam_per_segment(us):
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    n = 100000
+    p0 = torch.randn(n, generator=g).to(DEV); gr = torch.randn(n, generator=g).to(DEV)
+    m0 = torch.randn(n, generator=g).to(DEV) * 0.1; v0 = torch.rand(n, generator=g).to(DEV) * 0.01
+    segs = [(0, 1000, 1e-3), (1024, 40000, 5e-2), (50000, 50000, 2e-2)]
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+    for (o, k, lr) in segs:
+        L.check(lib.us_adam_step(off(pa, o), off(gr, o), off(ma, o), off(va, o), k, lr, 0.9, 0.999, 1e-8, 3, st), "adam")
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    I64, DBL = ctypes.c_int64 * 3, ctypes.c_double * 3
+    L.check(lib.us_adam_step_segments(P(pb), P(gr), P(mb), P(vb), 3, I64(*[s[0] for s in segs]), I64(*[s[1] for s in segs]),
+                                      DBL(*[s[2] for s in segs]), 0.9, 0.999, 1e-8, 3, st), "adam segs")
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(pb[1000:1024], p0[1000:1024])                      # gaps between segments are left alone

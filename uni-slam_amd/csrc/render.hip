@@ -8,6 +8,7 @@
 // and z_vals is required to match it bit for bit.
 #include "us_common.h"
 #include <math.h>
+#include <string.h>
 
 // ---------------------------------------------------------------------------------------------------------------
 // K0a: depth-guided z sampling (Renderer.py:86-101) + jitter (Renderer.py:42-57)
@@ -135,6 +136,83 @@ __global__ __launch_bounds__(256) void k_bbox_filter(const float* __restrict__ r
         const float gt = gt_depth ? gt_depth[i] : 0.0f;
         if (valid) valid[i] = (far >= gt) && (!require_depth || gt > 0.0f) ? 1 : 0;
         if (far_out) far_out[i] = far;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0e: K0d + K0a + K0b in one launch (the mapping / tracking iteration when no ray needs the zero-depth branch): validity
+// flag, sorted + jittered z, unit-cube points.  Same arithmetic as the three kernels, value for value.
+// The jitter draws come from t_rand[R][S] or, when that is NULL, from a counter-based generator (splitmix64 of
+// seed + sample index, top 24 bits -> [0,1) like torch.rand): any iid uniform stream serves Renderer.py:42-57.
+// ---------------------------------------------------------------------------------------------------------------
+struct Bound3x { float lo[3]; float hi[3]; float span[3]; };
+
+__device__ __forceinline__ float uniform24(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void k_sample_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ gt_depth, Bound3x bd, int64_t n_rays,
+                                                       const float* __restrict__ t_uni, int n_strat,
+                                                       const float* __restrict__ t_surf, int n_imp, float c_free,
+                                                       float surf_off, float surf_span, const float* __restrict__ t_rand,
+                                                       unsigned long long seed, int perturb, int require_depth,
+                                                       uint8_t* __restrict__ valid, float* __restrict__ z_vals,
+                                                       float* __restrict__ pts, int rays_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
+    const int S = n_strat + n_imp;
+    const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
+    const int64_t ray = (int64_t)blockIdx.x * rays_per_block + rl;
+    const bool active = rl < rays_per_block && ray < n_rays;
+    float v = 0.0f, gt = 0.0f;
+    if (active) {
+        gt = gt_depth[ray];
+        const float fg = c_free * gt, sb = gt - surf_off;
+        int rank;
+        if (j < n_strat) {
+            v = fg * t_uni[j];
+            rank = j;
+            for (int k = 0; k < n_imp; ++k) rank += ((sb + surf_span * t_surf[k]) < v) ? 1 : 0;
+        } else {
+            const int k = j - n_strat;
+            v = sb + surf_span * t_surf[k];
+            rank = k;
+            for (int i = 0; i < n_strat; ++i) rank += ((fg * t_uni[i]) <= v) ? 1 : 0;
+        }
+        zs[rl * S + rank] = v;
+    }
+    __syncthreads();
+    if (active) {
+        const float* z = zs + rl * S;
+        float out = z[j];
+        if (perturb) {
+            const float lower = j > 0 ? 0.5f * (z[j] + z[j - 1]) : z[0];
+            const float upper = j < S - 1 ? 0.5f * (z[j + 1] + z[j]) : z[S - 1];
+            const float u = t_rand ? t_rand[ray * S + j] : uniform24(seed, (uint64_t)(ray * S + j));
+            out = lower + (upper - lower) * u;
+        }
+        z_vals[ray * S + j] = out;
+        float o3[3], d3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o3[k] = rays_o[ray * 3 + k]; d3[k] = rays_d[ray * 3 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p = o3[k] + d3[k] * out;
+            pts[(ray * S + j) * 3 + k] = (p - bd.lo[k]) / bd.span[k];
+        }
+        if (j == 0 && valid) {
+            float far = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float t0 = (bd.lo[k] - o3[k]) / d3[k], t1 = (bd.hi[k] - o3[k]) / d3[k];
+                far = fminf(far, fmaxf(t0, t1));
+            }
+            valid[ray] = (far >= gt) && (!require_depth || gt > 0.0f) ? 1 : 0;
+        }
     }
 }
 
@@ -470,6 +548,25 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// the same over up to ADAM_MAX_SEG segments of one flat parameter buffer, each with its own learning rate: one launch
+#define ADAM_MAX_SEG 8
+struct AdamSegs { int64_t off[ADAM_MAX_SEG]; int64_t n[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; };
+__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, AdamSegs sg, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float bc2_sqrt, float eps) {
+    const int64_t n = sg.n[blockIdx.y], o = sg.off[blockIdx.y];
+    const float step_size = sg.step_size[blockIdx.y];
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = o + k;
+        const float gi = g[i];
+        const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (one_minus_b2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (-step_size) * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Tracking: camera pose -> rays and the adjoint (src/common.py:95-107,196-208 + pytorch3d quaternion_to_matrix).
 // pose = (qr, qi, qj, qk, tx, ty, tz); R = I + s*M(q), s = 2/|q|^2; rays_d = R * dir_cam, rays_o = t.
@@ -591,6 +688,24 @@ extern "C" int us_sample_z(const float* gt_depth, int64_t n_rays, const float* t
                        (hipStream_t)stream, gt_depth, n_rays, t_uni, n_strat, t_surf, n_imp, c_free, surf_off, surf_span,
                        t_rand, z_vals, rpb);
     US_CHECK_LAUNCH("us_sample_z");
+    return US_OK;
+}
+
+extern "C" int us_sample_points(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
+                                int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf, int n_imp, float c_free,
+                                float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, int perturb,
+                                int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(rays_o && rays_d && gt_depth && bound_host && t_uni && t_surf && z_vals && pts, US_ERR_NULL, "us_sample_points: NULL pointer");
+    const int S = n_strat + n_imp;
+    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_sample_points: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
+    Bound3x bd;
+    for (int k = 0; k < 3; ++k) { bd.lo[k] = bound_host[k]; bd.hi[k] = bound_host[3 + k]; bd.span[k] = bound_host[3 + k] - bound_host[k]; }
+    const int rpb = 256 / S;
+    hipLaunchKernelGGL(k_sample_points, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float),
+                       (hipStream_t)stream, rays_o, rays_d, gt_depth, bd, n_rays, t_uni, n_strat, t_surf, n_imp, c_free, surf_off,
+                       surf_span, t_rand, (unsigned long long)rng_seed, perturb, require_depth, valid, z_vals, pts, rpb);
+    US_CHECK_LAUNCH("us_sample_points");
     return US_OK;
 }
 
@@ -735,6 +850,29 @@ extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_
     hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
     US_CHECK_LAUNCH("us_adam_step");
+    return US_OK;
+}
+
+extern "C" int us_adam_step_segments(float* p, const float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+                                     const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
+                                     void* stream) {
+    US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr, US_ERR_NULL, "us_adam_step_segments: NULL pointer");
+    US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_segments: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
+    US_REQUIRE(step >= 1, US_ERR_SHAPE, "us_adam_step_segments: step %d (1-based)", step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamSegs sg;
+    memset(&sg, 0, sizeof(sg));
+    int64_t n_max = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        US_REQUIRE(seg_off[k] >= 0 && seg_n[k] >= 0, US_ERR_SHAPE, "us_adam_step_segments: segment %d: offset %lld n %lld", k,
+                   (long long)seg_off[k], (long long)seg_n[k]);
+        sg.off[k] = seg_off[k]; sg.n[k] = seg_n[k]; sg.step_size[k] = (float)(seg_lr[k] / bc1);
+        if (seg_n[k] > n_max) n_max = seg_n[k];
+    }
+    if (n_max == 0) return US_OK;
+    hipLaunchKernelGGL(k_adam_segs, dim3(grid_1d(n_max, 256, 4096), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps);
+    US_CHECK_LAUNCH("us_adam_step_segments");
     return US_OK;
 }
 

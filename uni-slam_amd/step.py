@@ -47,6 +47,7 @@ class MapStep:
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = bool(overlap), None
+        self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
             raise L.UniSlamHipError("MapStep needs the model on the GPU")
@@ -210,19 +211,26 @@ class MapStep:
         P = L.ptr
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
         # pre-filter against the scene box (Mapper.py:396-406) as a validity flag instead of a compaction
-        L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 0, P(self.valid), None, st), "us_bbox_filter")
-        if self.perturb and t_rand is None:
-            t_rand = torch.rand((R, S), device=self.device)
-        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-        L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2),
-                                ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, P(self.z), st),
-                "us_sample_z")
-        if has_zero_depth is None or has_zero_depth:
+        c_free, s_off, s_span = ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation)
+        if has_zero_depth is False:
+            # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
+            tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
+            self.rng_calls += 1
+            L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
+                                         c_free, s_off, s_span, tr, (self.rng_seed + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1),
+                                         1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
+        else:
+            L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 0, P(self.valid), None, st), "us_bbox_filter")
+            if self.perturb and t_rand is None:
+                t_rand = torch.rand((R, S), device=self.device)
+            tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
+            L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, c_free, s_off, s_span, tr,
+                                    P(self.z), st), "us_sample_z")
             m0 = gd <= 0
             if bool(m0.any()):
                 self.z[:R][m0] = zero_depth_z(([self.es], [self.ec]), self.dec, o[m0], d[m0], self.bound, self.t_uni,
                                               self.n_imp, self.perturb, self.device)
-        L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
+            L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
         fl = self.flat
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
@@ -298,15 +306,15 @@ class MapStep:
         return self.backward()
 
     def adam_step(self):
-        lib, st = L.lib(), L.stream()
+        lib, st, P = L.lib(), L.stream(), L.ptr
         self.opt_step += 1
         f = self.lr_factor
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        for (o, n, lr) in ((0, self.n_dec, self.lr["decoders"] * f),
-                           (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
-                           (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f)):
-            L.check(lib.us_adam_step(off(self.flat, o), off(self.grad, o), off(self.m, o), off(self.v, o), n, lr, 0.9, 0.999,
-                                     1e-8, self.opt_step, st), "us_adam_step")
+        segs = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
+                (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
+        I64, DBL = ctypes.c_int64 * 3, ctypes.c_double * 3
+        L.check(lib.us_adam_step_segments(P(self.flat), P(self.grad), P(self.m), P(self.v), 3, I64(*[g[0] for g in segs]),
+                                          I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, self.opt_step, st),
+                "us_adam_step_segments")
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
