@@ -225,10 +225,11 @@ int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
 
 /* the same over n_seg (<= 8) segments [seg_off[k], seg_off[k] + seg_n[k]) of one flat buffer in ONE launch, each segment with
  * its own learning rate -- the optimizer's param_groups (src/Mapper.py:118-126: decoders, sdf tables, colour tables);
- * seg_off / seg_n / seg_lr are HOST arrays */
-int us_adam_step_segments(float* p, const float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+ * seg_off / seg_n / seg_lr are HOST arrays.  Bit k of zero_grad_mask: clear segment k of g once it has been consumed
+ * (the optimizer.zero_grad() of src/Mapper.py:443 for gradients that the next backward ADDS to). */
+int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
                           const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
-                          void* stream);
+                          unsigned zero_grad_mask, void* stream);
 
 /* the same with the 1-based step count in device memory (float[1]): nothing step-dependent is baked into the launch, so the
  * call can sit inside a captured hipGraph (torch.optim.Adam(capturable=True) arithmetic: bias corrections in fp32) */

@@ -719,6 +719,7 @@ def test_adam_segments_equals_adam_per_segment(us):
     pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
     I64, DBL = ctypes.c_int64 * 3, ctypes.c_double * 3
     L.check(lib.us_adam_step_segments(P(pb), P(gr), P(mb), P(vb), 3, I64(*[s[0] for s in segs]), I64(*[s[1] for s in segs]),
-                                      DBL(*[s[2] for s in segs]), 0.9, 0.999, 1e-8, 3, st), "adam segs")
+                                      DBL(*[s[2] for s in segs]), 0.9, 0.999, 1e-8, 3, 0b101, st), "adam segs")
+    assert float(gr[:1000].abs().max()) == 0.0 and float(gr[50000:].abs().max()) == 0.0 and float(gr[1024:41024].abs().min()) > 0.0
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     assert torch.equal(pb[1000:1024], p0[1000:1024])                      # gaps between segments are left alone

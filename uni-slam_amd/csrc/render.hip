@@ -463,29 +463,27 @@ __global__ __launch_bounds__(256) void k_loss_partials(int mode, const float* __
     }
 }
 
-// one workgroup, fixed summation order -> bitwise reproducible statistics (all 10 in one sweep over the rays)
+// one workgroup per statistic, fixed summation order -> bitwise reproducible statistics
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ partials, int64_t n_rays,
                                                       float* __restrict__ stats) {
-    __shared__ double sh[LOSS_NSTAT][64];
-    double acc[LOSS_NSTAT];
+    __shared__ double sh[16];
+    const int k = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t r0 = threadIdx.x; r0 < n_rays; r0 += 4096) {   // 4 independent loads in flight
+        float v[4];
 #pragma unroll
-    for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] = 0.0;
-    for (int64_t r = threadIdx.x; r < n_rays; r += 1024) {
+        for (int u = 0; u < 4; ++u) { const int64_t r = r0 + 1024 * u; v[u] = r < n_rays ? partials[r * LOSS_NSTAT + k] : 0.0f; }
 #pragma unroll
-        for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] += (double)partials[r * LOSS_NSTAT + k];
+        for (int u = 0; u < 4; ++u) acc += (double)v[u];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < LOSS_NSTAT; ++k) {
-        double v = acc[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) sh[k][wave] = v;
-    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) sh[wave] = acc;
     __syncthreads();
-    if (threadIdx.x < LOSS_NSTAT) {
+    if (threadIdx.x == 0) {
         double v = 0.0;
-        for (int w = 0; w < 16; ++w) v += sh[threadIdx.x][w];
-        stats[threadIdx.x] = (float)v;
+        for (int w = 0; w < 16; ++w) v += sh[w];
+        stats[k] = (float)v;
     }
 }
 
@@ -551,10 +549,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // the same over up to ADAM_MAX_SEG segments of one flat parameter buffer, each with its own learning rate: one launch
 #define ADAM_MAX_SEG 8
 struct AdamSegs { int64_t off[ADAM_MAX_SEG]; int64_t n[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; };
-__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, AdamSegs sg, float one_minus_b1, float b2,
-                                                   float one_minus_b2, float bc2_sqrt, float eps) {
+                                                   float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask) {
     const int64_t n = sg.n[blockIdx.y], o = sg.off[blockIdx.y];
+    const bool zero = (zero_mask >> blockIdx.y) & 1u;            // optimizer.zero_grad() of this segment, folded in
     const float step_size = sg.step_size[blockIdx.y];
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = o + k;
@@ -564,6 +563,7 @@ __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, const 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] + (-step_size) * (mi / denom);
         m[i] = mi; v[i] = vi;
+        if (zero) g[i] = 0.0f;
     }
 }
 
@@ -819,7 +819,7 @@ extern "C" int us_loss_stats(int mode, const float* sdf, int64_t sdf_stride, con
     hipLaunchKernelGGL(k_loss_partials, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, s, mode, sdf, sdf_stride, valid, z_vals, gt_depth, gt_color,
                        depth, rgb, pixel_unc, median, n_rays, n_samples, (float)truncation, (float)(0.4 * truncation), partials);
     US_CHECK_LAUNCH("us_loss_stats(partials)");
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, partials, n_rays, stats);
+    hipLaunchKernelGGL(k_loss_reduce, dim3(LOSS_NSTAT), dim3(1024), 0, s, partials, n_rays, stats);
     US_CHECK_LAUNCH("us_loss_stats(reduce)");
     return US_OK;
 }
@@ -853,9 +853,9 @@ extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_
     return US_OK;
 }
 
-extern "C" int us_adam_step_segments(float* p, const float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+extern "C" int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
                                      const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
-                                     void* stream) {
+                                     unsigned zero_grad_mask, void* stream) {
     US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr, US_ERR_NULL, "us_adam_step_segments: NULL pointer");
     US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_segments: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
     US_REQUIRE(step >= 1, US_ERR_SHAPE, "us_adam_step_segments: step %d (1-based)", step);
@@ -871,7 +871,7 @@ extern "C" int us_adam_step_segments(float* p, const float* g, float* m, float* 
     }
     if (n_max == 0) return US_OK;
     hipLaunchKernelGGL(k_adam_segs, dim3(grid_1d(n_max, 256, 4096), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask);
     US_CHECK_LAUNCH("us_adam_step_segments");
     return US_OK;
 }

@@ -47,6 +47,7 @@ class MapStep:
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = bool(overlap), None
+        self._dec_grad_clean = False
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
@@ -268,8 +269,13 @@ class MapStep:
         L.check(lib.us_loss_grad(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
                                  P(self.rgb), P(self.unc), None, R, S, self.truncation, self.w5, P(self.stats), P(self.g_sdf),
                                  P(self.g_depth), P(self.g_rgb), P(self.loss), st), "us_loss_grad")
-        # the binned table backward writes every table entry (US_GRID_BWD_OVERWRITE): only the decoder segment is cleared
-        (self.grad[:self.o_tab_s] if self.bwd_mode in (-1, 3) else self.grad).zero_()
+        # The binned table backward writes every table entry (US_GRID_BWD_OVERWRITE); the decoder segment, which the MLP
+        # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
+        if self.bwd_mode not in (-1, 3):
+            self.grad.zero_()
+        elif not self._dec_grad_clean:
+            self.grad[:self.o_tab_s].zero_()
+        self._dec_grad_clean = False
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
@@ -313,8 +319,9 @@ class MapStep:
                 (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
         I64, DBL = ctypes.c_int64 * 3, ctypes.c_double * 3
         L.check(lib.us_adam_step_segments(P(self.flat), P(self.grad), P(self.m), P(self.v), 3, I64(*[g[0] for g in segs]),
-                                          I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, self.opt_step, st),
+                                          I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, self.opt_step, 0b001, st),
                 "us_adam_step_segments")
+        self._dec_grad_clean = True
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
