@@ -205,7 +205,7 @@ def main():
         dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
-                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=not args.no_overlap)
+                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None)
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)

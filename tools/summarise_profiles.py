@@ -1,9 +1,11 @@
 """Build profiles/r01_pmc_summary.csv and profiles/traffic.json from the rocprofv3 output directories under gpurun_out/."""
 import collections, csv, glob, json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-newest = lambda pat: max(glob.glob(os.path.join(R, pat)), key=os.path.getmtime)
+import shutil
+newest = lambda pat: max(glob.glob(os.path.join(R, pat), recursive=True), key=os.path.getmtime)
 def load(d):
-    return list(csv.DictReader(open(newest(f"gpurun_out/{d}/runc/*counter_collection.csv"))))
+    return list(csv.DictReader(open(newest(f"gpurun_out/{d}/**/*counter_collection.csv"))))
+shutil.copy(newest("gpurun_out/r01_trace/**/*kernel_stats.csv"), os.path.join(R, "profiles/r01_kernel_stats.csv"))
 def agg(rows):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
@@ -12,7 +14,7 @@ def agg(rows):
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(R, "profiles/r01_kernel_stats.csv")))}
 fetch, write, mf = agg(load("r01_fetch")), agg(load("r01_write")), agg(load("r01_mfma"))
 avg = lambda v: sum(v) / max(len(v), 1)
-lines = ["# rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...), bench.py --steps 20 --warmup 5, MI355X, round 1",
+lines = ["# rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...), bench.py --steps 20 --warmup 5 --no-overlap, MI355X, round 1",
          "# per-launch averages. FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) and is",
          "# uncalibrated for other widths: k_bin_accum reads exactly what k_bin<2,true> wrote, which calibrates its FETCH_SIZE (ratio in DESIGN.md).",
          "# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)  (MFMA pipe busy cycles per SIMD-cycle while the CU is busy)",
@@ -29,15 +31,15 @@ def per_dispatch(d, counter):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 out = {}
-for grid, parity in (("color", 0), ("sdf", 1)):          # MapStep runs the colour branch first
+for grid, parity in (("color", 0), ("sdf", 1)):          # MapStep on one stream (--no-overlap) runs the colour branch first
     tot = 0.0
     for d, c in (("r01_fetch", "FETCH_SIZE"), ("r01_write", "WRITE_SIZE")):
         rows = per_dispatch(d, c)
-        for kname in ("k_bin<2, false>", "k_bin<2, true>", "k_bin_accum<2>", "k_bin_scan"):
+        for kname in ("k_bin<2, false>", "k_bin_colscan", "k_bin_scan", "k_bin<2, true>", "k_bin_accum<2>"):
             ks = [r for r in rows if kname in r["Kernel_Name"]][parity::2]
             tot += sum(float(r["Counter_Value"]) for r in ks) / max(len(ks), 1) * 1024
     out[f"hashgrid_bwd_{grid}"] = tot
     print(grid, round(tot / 1e6, 1), "MB")
-json.dump({**out, "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 summed over the kernels of us_hashgrid_bwd_binned (k_bin<count>, k_bin_scan, "
-                           "k_bin<write>, k_bin_accum), rocprofv3 --pmc in separate passes, round 1; FETCH_SIZE uncorrected (lower bound on the read side)"},
+json.dump({**out, "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 summed over the kernels of us_hashgrid_bwd_binned (k_bin<count>, k_bin_colscan, "
+                           "k_bin_scan, k_bin<write>, k_bin_accum), rocprofv3 --pmc in separate passes, round 1; FETCH_SIZE uncorrected (lower bound on the read side)"},
           open(os.path.join(R, "profiles/traffic.json"), "w"), indent=1)

@@ -35,18 +35,20 @@ def _align(n, a=64):
 
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=True):
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
         lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
         group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
-        overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch.
+        overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch;
+                 default: yes for a single process; no with a process group, where the branches run one after the other so that
+                 the all-reduce of the colour-table gradient hides behind the sdf branch.
         """
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
-        self.overlap, self.side = bool(overlap), None
+        self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
         self._dec_grad_clean = False
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
@@ -280,27 +282,40 @@ class MapStep:
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
         binned = self.ws is not None
-        with self._branch() as st2:                              # sdf branch on the side stream
+
+        def sdf_branch(q):
             self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                               off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
-                                                              P(self.mlp_ws_s), self.mlp_ws_bytes, st2))
+                                                              P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE, P(self.ws_s), self.ws_bytes, st2))
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE, P(self.ws_s), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
-                                                                                  off(self.grad, self.o_tab_s), self.bwd_mode, 3, st2))
-        self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                            N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
-        if binned:
-            self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, st))
-        else:
-            self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
-                                                                                off(self.grad, self.o_tab_c), self.bwd_mode, 3, st))
-        if on_ready is not None:
-            on_ready(self.grad[self.o_tab_c:])
-        self._join()
+                                                                                  off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
+
+        def color_branch(q):
+            self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
+                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
+            if binned:
+                self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
+                                                                                    3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, q))
+            else:
+                self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
+                                                                                    off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
+
+        if self.overlap and not self._probing:
+            with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
+                sdf_branch(st2)
+            color_branch(st)
+            if on_ready is not None:
+                on_ready(self.grad[self.o_tab_c:])
+            self._join()
+        else:                                                    # one stream: colour first, so that its (large) gradient
+            color_branch(st)                                     # segment can travel while the sdf branch computes
+            if on_ready is not None:
+                on_ready(self.grad[self.o_tab_c:])
+            sdf_branch(st)
         if on_ready is not None:
             on_ready(self.grad[:self.o_tab_c])
         self.n_rays = R
