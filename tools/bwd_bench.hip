@@ -38,10 +38,10 @@ int main(int argc, char** argv) {
             const size_t wsb = us_hashgrid_bwd_workspace_bytes(&d, n);
             void* ws; hipMalloc(&ws, wsb);
             for (int lm : {0, 2}) {
-                int rc = us_hashgrid_bwd_binned(&d, x, dy, n, g, lm, ws, wsb, 0); hipDeviceSynchronize();
+                int rc = us_hashgrid_bwd_binned(&d, x, dy, n, g, lm | US_GRID_BWD_OVERWRITE, ws, wsb, 0); hipDeviceSynchronize();
                 if (rc) printf("binned rc=%d %s\n", rc, us_last_error());
                 hipEventRecord(a);
-                for (int r = 0; r < 3; ++r) us_hashgrid_bwd_binned(&d, x, dy, n, g, lm, ws, wsb, 0);
+                for (int r = 0; r < 3; ++r) us_hashgrid_bwd_binned(&d, x, dy, n, g, lm | US_GRID_BWD_OVERWRITE, ws, wsb, 0);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b);
                 std::vector<uint32_t> hdr(2 * (BIN_MAX_TOTAL + 64)); hipMemcpy(hdr.data(), ws, hdr.size() * 4, hipMemcpyDeviceToHost);

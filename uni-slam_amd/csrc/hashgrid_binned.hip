@@ -413,10 +413,12 @@ __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab,
 }
 
 // exclusive scan of counts[0..TB) -> offsets[0..TB]   (TB <= 4096: 4 elements per thread), and the list of EXTRA chunks:
-// a bin with c > ACC_CHUNK records is accumulated by ceil(c / ACC_CHUNK) workgroups; chunk 0 belongs to the bin's own
-// workgroup, chunks 1.. are listed in extra[] as bin | chunk << 16.
+// a bin with c > chunk records is accumulated by ceil(c / chunk) workgroups; chunk 0 belongs to the bin's own workgroup,
+// chunks 1.. are listed in extra[] as bin | chunk << 16.  chunk = ACC_CHUNK, or the multiple of it that keeps the list within
+// ACC_EXTRA_MAX entries (hdr[0] = number of extras, hdr[1] = chunk).
+#define ACC_EXTRA_MAX 256
 __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ extra, uint32_t* __restrict__ n_extra) {
+                                                   uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t sx[1024];
     const uint32_t t = threadIdx.x;
@@ -431,16 +433,33 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
         sh[t] += v; sx[t] += w;
         __syncthreads();
     }
+    uint32_t chunk = ACC_CHUNK;
+    const uint32_t x_all = sx[1023];
+    if (x_all > ACC_EXTRA_MAX) {                                 // wave-uniform, rare: coarser chunks, scanned again
+        chunk = ACC_CHUNK * ((x_all + ACC_EXTRA_MAX - 1u) / ACC_EXTRA_MAX);
+        x4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x4 += c[k] > chunk ? (c[k] - 1u) / chunk : 0u;
+        __syncthreads();
+        sx[t] = x4;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            const uint32_t w = (t >= o) ? sx[t - o] : 0u;
+            __syncthreads();
+            sx[t] += w;
+            __syncthreads();
+        }
+    }
     uint32_t run = sh[t] - s4, xrun = sx[t] - x4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (4 * t + k < TB) offsets[4 * t + k] = run;
         run += c[k];
-        const uint32_t nx = c[k] > ACC_CHUNK ? (c[k] - 1u) / ACC_CHUNK : 0u;
+        const uint32_t nx = c[k] > chunk ? (c[k] - 1u) / chunk : 0u;
         for (uint32_t j = 0; j < nx; ++j) extra[xrun + j] = (4 * t + k) | ((j + 1u) << 16);
         xrun += nx;
     }
-    if (t == 1023) { offsets[TB] = sh[1023]; *n_extra = sx[1023]; }
+    if (t == 1023) { offsets[TB] = sh[1023]; hdr[0] = sx[1023]; hdr[1] = chunk; }
 }
 
 // B: one workgroup per bin (+ one per extra chunk of a hot bin; those come FIRST in the grid: they are the longest jobs)
@@ -451,8 +470,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
                                                            const uint32_t* __restrict__ rec, float* __restrict__ grad, int overwrite) {
     __shared__ double acc[BIN_ACC_DOUBLES];
     uint32_t b, chunk = 0;
+    const uint32_t CH = n_extra[1];                                    // records per workgroup (k_bin_scan)
     if (blockIdx.x < e_max) {
-        if (blockIdx.x >= *n_extra) return;
+        if (blockIdx.x >= n_extra[0]) return;
         const uint32_t pk = extra[blockIdx.x];
         b = pk & 0xFFFFu; chunk = pk >> 16;
     } else {
@@ -464,9 +484,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
     const uint32_t hs = tab.off[level + 1] - tab.off[level];
     const uint32_t n_local = bin_n_local(hs, bl, lg);                 // entries owned by this bin
     const uint32_t b0 = offsets[b], b1 = offsets[b + 1];
-    const bool split = (b1 - b0) > ACC_CHUNK;                         // several workgroups add into this bin's entries
-    const uint32_t r0 = b0 + chunk * ACC_CHUNK;
-    const uint32_t r1 = (b1 - r0 > ACC_CHUNK) ? r0 + ACC_CHUNK : b1;
+    const bool split = (b1 - b0) > CH;                                // several workgroups add into this bin's entries
+    const uint32_t r0 = b0 + chunk * CH;
+    const uint32_t r1 = (b1 - r0 > CH) ? r0 + CH : b1;
     float* gl = grad + (size_t)tab.off[level] * F;
     if (b0 == b1) {                                                   // nothing landed in this bin (wave-uniform)
         if (overwrite)
@@ -479,30 +499,51 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             }
         return;
     }
-    for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) acc[k] = 0.0;
-    __syncthreads();
-    for (uint32_t base = r0; base < r1; base += ACC_THREADS * ACC_UNROLL) {
-        uint32_t loc[ACC_UNROLL]; float v[ACC_UNROLL][F];
-#pragma unroll
-        for (int u = 0; u < ACC_UNROLL; ++u) {                   // issue every load of the group before the first use
-            const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
-            loc[u] = 0xFFFFFFFFu;
-            if (r < r1) {
-                const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
-                loc[u] = src[0];
-#pragma unroll
-                for (int f = 0; f < F; ++f) v[u][f] = __uint_as_float(src[1 + f]);
-            }
-        }
+    // Software-pipelined record stream: the loads of batch k+1 are in flight while batch k goes through the LDS atomics;
+    // the first batch is requested before the accumulators are cleared.
+    uint32_t loc[2][ACC_UNROLL]; float v[2][ACC_UNROLL][F];
+    auto fetch = [&](int buf, uint32_t base) {
 #pragma unroll
         for (int u = 0; u < ACC_UNROLL; ++u) {
-            if (loc[u] != 0xFFFFFFFFu) {
+            const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
+            loc[buf][u] = 0xFFFFFFFFu;
+            if (r < r1) {
+                const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
+                loc[buf][u] = src[0];
 #pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[loc[u] * F + f], (double)v[u][f]);            // ds_add_f64
+                for (int f = 0; f < F; ++f) v[buf][u][f] = __uint_as_float(src[1 + f]);
             }
+        }
+    };
+    auto add = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < ACC_UNROLL; ++u) {
+            if (loc[buf][u] != 0xFFFFFFFFu) {
+#pragma unroll
+#ifdef US_EXP_B_NOATOMIC
+                for (int f = 0; f < F; ++f) acc[loc[buf][u] * F + f] = (double)v[buf][u][f];
+#else
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[loc[buf][u] * F + f], (double)v[buf][u][f]);   // ds_add_f64
+#endif
+            }
+        }
+    };
+    fetch(0, r0);
+    for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) acc[k] = 0.0;
+    __syncthreads();
+    constexpr uint32_t STEP = ACC_THREADS * ACC_UNROLL;
+    for (uint32_t base = r0; base < r1; base += 2 * STEP) {
+        if (base + STEP < r1) fetch(1, base + STEP);
+        add(0);
+        if (base + STEP < r1) {
+            if (base + 2 * STEP < r1) fetch(0, base + 2 * STEP);
+            add(1);
         }
     }
     __syncthreads();
+#ifdef US_EXP_B_NOSWEEP
+    if (n_local != 0xFFFFFFF0u) return;
+#endif
     for (uint32_t loc = threadIdx.x; loc < n_local; loc += ACC_THREADS) {
         const uint32_t e = entry_of(loc, bl, lg);
         if (e >= hs) continue;
@@ -534,7 +575,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
 // ---------------------------------------------------------------------------------------------------------------
 // workspace: totals | offsets (2 x (BIN_MAX_TOTAL + 64) u32) | n_extra (16 u32) | extra[e_max] | per-workgroup count rows
 // [n_wg][BIN_MAX_TOTAL] | their column prefixes [n_wg][BIN_MAX_TOTAL] | records
-static uint32_t extra_max(const us_grid_desc* d, int64_t n) { return (uint32_t)(((uint64_t)n * 8ull * d->n_levels) / ACC_CHUNK) + 1u; }
+static uint32_t extra_max(const us_grid_desc*, int64_t) { return ACC_EXTRA_MAX; }
 static size_t header_bytes(const us_grid_desc* d, int64_t n) {
     const size_t em = ((size_t)extra_max(d, n) + 15u) & ~(size_t)15u;
     return (size_t)(2 * (BIN_MAX_TOTAL + 64) + 16 + em) * sizeof(uint32_t) + 2 * (size_t)us_cdiv(n, BIN_THREADS) * BIN_MAX_TOTAL * sizeof(uint32_t);
@@ -587,6 +628,11 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0;
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
+#ifdef US_EXP_B_TWICE
+#define US_EXP_TWICE(F) hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, grad_params, overwrite);
+#else
+#define US_EXP_TWICE(F)
+#endif
 #define LAUNCH_BIN(F)                                                                                                          \
     hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
     hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
@@ -594,7 +640,8 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
     hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
     hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
-                       grad_params, overwrite);
+                       grad_params, overwrite);                                                                                \
+    US_EXP_TWICE(F)
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
 #undef LAUNCH_BIN
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
