@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--bwd-mode", type=int, default=-1)
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
                     help="MFMA operand type of the decoders; the headline (parity-tested to 1e-3) is fp32")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
+                    help="payload type of the gradient all-reduce (N > 1); bf16 halves the xGMI bytes, not bit-faithful to one process")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
@@ -205,7 +207,8 @@ def main():
         dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
-                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None)
+                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
+                        grad_comm=args.grad_comm)
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)
@@ -248,7 +251,8 @@ def main():
                                       "L=16 F=2 hash grids log2T 16 (sdf) / 19 (colour) res 816, 2 hidden x %d MLP decoders with bias, "
                                       "mapping iteration = sample+encode+decode+composite+loss+backward+dense Adam" % args.hidden,
                           "rays_per_gpu": args.rays, "samples_per_ray": S, "points_per_gpu": N, "n_params": int(step.n_flat),
-                          "parallelism": f"dp{world} (frames/rays sharded, 1 all-reduce of {4 * step.n_flat / 1e6:.1f} MB grads per step)"},
+                          "parallelism": f"dp{world} (frames/rays sharded, 1 all-reduce of {(4 if args.grad_comm == 'fp32' else 2) * step.n_flat / 1e6:.1f} MB "
+                                         f"{args.grad_comm} grads per step)"},
                "rays_per_s_per_gpu": args.rays / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss)}
         if step.probe:
             kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in step.probe.items()}

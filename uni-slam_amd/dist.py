@@ -25,9 +25,12 @@ def _pg(group):
     return None if group is True else group
 
 
-def dp_iterate(engine, batch, group=None):
+def dp_iterate(engine, batch, group=None, grad_comm=None):
     """
     One optimiser step. group: None (single process) | True (default process group) | a process group.
+    grad_comm: None / "fp32" -> the gradient travels as it is; "bf16" -> every announced segment is rounded to bfloat16 for
+    the all-reduce and widened again before Adam (half the bytes on xGMI; the sum over ranks then carries bf16 rounding, so
+    N ranks no longer reproduce one process bit for bit -- opt-in, for when the all-reduce bounds the step).
 
     Overlap: engine.backward(on_ready) calls on_ready(view) as soon as a contiguous segment of engine.grad is final; each
     segment's all-reduce is issued asynchronously right then (RCCL runs it on its own stream, ordered after the kernels
@@ -38,17 +41,23 @@ def dp_iterate(engine, batch, group=None):
     if group is not None:
         dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
     works = []
+    if grad_comm is None:
+        grad_comm = getattr(engine, "grad_comm", None)
+    narrow = grad_comm in ("bf16", torch.bfloat16)
 
     def on_ready(view):
         if group is not None:
-            works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True))
+            buf = view.to(torch.bfloat16) if narrow else view
+            works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True), view, buf))
 
     loss = engine.backward(on_ready)
     if group is not None:
         if not works:                                   # an engine that does not announce segments: one reduction at the end
-            dist.all_reduce(engine.grad, op=dist.ReduceOp.SUM, group=_pg(group))
-        for w in works:
+            on_ready(engine.grad)
+        for w, view, buf in works:
             w.wait()
+            if buf is not view:
+                view.copy_(buf)
     engine.adam_step()
     return loss
 

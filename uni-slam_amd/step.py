@@ -35,7 +35,7 @@ def _align(n, a=64):
 
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None):
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -50,6 +50,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
         self._dec_grad_clean = False
+        self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
