@@ -72,6 +72,8 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * contributed) instead of added to, so the caller need not clear the table gradient beforehand (what optimizer.zero_grad()
  * does at src/Mapper.py:443 before loss.backward()). */
 #define US_GRID_BWD_OVERWRITE 4
+/* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
+#define US_GRID_ACCUMULATE 8
 
 /* out[N][C] = encode(x[N][3]);  dy_dx[N][C][3] optional (NULL when positions need no gradient) */
 int us_hashgrid_fwd(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n,
@@ -101,6 +103,12 @@ int us_hashgrid_bwd_binned(const us_grid_desc* desc_host, const float* x, const 
 /* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
 int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,
                           float* dL_dx, void* stream);
+/* the same value for value WITHOUT a stored dy_dx: the 8 vertices of every (point, level) are gathered again and dy/dx is
+ * formed on the fly (saves the [N][C][3] tensor the forward would write).  Gradient of the rays / camera poses:
+ * src/Tracker.py:170-174,241 and the joint pose optimisation of src/Mapper.py:358-374,442-459.
+ * flags: US_GRID_CLAMP01, US_GRID_LEVEL_MAJOR (layout of dL_dy), US_GRID_ACCUMULATE. */
+int us_hashgrid_bwd_input_gather(const us_grid_desc* desc_host, const float* params, const float* x, const float* dL_dy,
+                                 int64_t n, float* dL_dx, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused tiny MLP on MFMA  (replaces tcnn.Network "FullyFusedMLP" src/networks/decoders.py:50-70,123,148

@@ -78,6 +78,13 @@ def test_hashgrid_clamp_and_out_of_range(us):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), gx, rtol=2e-4, atol=2e-3)
     # without the clamp flag the raw coordinates are hashed as they are (tcnn behaviour)
     assert np.array_equal(us.grid_indices(enc.desc, xg.detach()).cpu().numpy().astype(np.uint32), O.hashgrid_indices(d, x))
+    # cells of slightly negative coordinates: the uint32 entry sum of a dense level reaches 0xFFFFFFFF (x cell -1, y = z = 0),
+    # which a 16-byte "x, x+1" pair gather must treat as a wrap-around (regression: out-of-bounds read)
+    xs = np.array([[-1.0 / 15, 0.01, 0.01], [-0.06, 0.0, 0.02], [-0.05, -0.01, 0.0], [-0.04, 0.02, -0.02], [1.02, 1.0, 1.0]], np.float32)
+    xs = np.concatenate([xs, -rng.random((200, 3), dtype=np.float32) * 0.1 + np.array([[0.0, 0.04, 0.04]], np.float32)])
+    o2 = enc(T(xs).to(DEV))
+    r2, _ = O.hashgrid_fwd(d, p, xs)
+    np.testing.assert_allclose(o2.detach().cpu().numpy(), r2, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, -1])
@@ -723,3 +730,41 @@ def test_adam_segments_equals_adam_per_segment(us):
     assert float(gr[:1000].abs().max()) == 0.0 and float(gr[50000:].abs().max()) == 0.0 and float(gr[1024:41024].abs().min()) > 0.0
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     assert torch.equal(pb[1000:1024], p0[1000:1024])                      # gaps between segments are left alone
+
+
+@pytest.mark.parametrize("log2T", [14, 19])
+def test_input_gradient_by_regathering_equals_stored_dydx(us, log2T):
+    """us_hashgrid_bwd_input_gather (no stored dy_dx) against us_hashgrid_fwd(dy_dx) + us_hashgrid_bwd_input, bit for bit;
+    both dL_dy layouts, the clamp flag, accumulation; and against the oracle."""
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(log2T)
+    n = 5003
+    x = torch.rand((n, 3), device=DEV, generator=g) * 1.2 - 0.1                 # some coordinates outside [0, 1]
+    enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+    with torch.no_grad():
+        enc.params.copy_(torch.randn(enc.params.shape, device=DEV, generator=g) * 0.2)
+    p = enc.params.detach()
+    dy = torch.randn((n, 32), device=DEV, generator=g)
+    dy_lm = dy.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    d = ctypes.byref(enc.desc)
+    for clamp in (0, 1):
+        out = torch.empty((n, 32), device=DEV); dydx = torch.empty((n, 32, 3), device=DEV)
+        L.check(lib.us_hashgrid_fwd(d, P(p), P(x), n, P(out), P(dydx), clamp, st), "fwd")
+        ref = torch.empty((n, 3), device=DEV)
+        L.check(lib.us_hashgrid_bwd_input(P(dy), P(dydx), n, 32, P(ref), st), "bwd_input")
+        a = torch.empty((n, 3), device=DEV); b = torch.empty((n, 3), device=DEV)
+        L.check(lib.us_hashgrid_bwd_input_gather(d, P(p), P(x), P(dy), n, P(a), clamp, st), "gather")
+        L.check(lib.us_hashgrid_bwd_input_gather(d, P(p), P(x), P(dy_lm), n, P(b), clamp | L.US_GRID_LEVEL_MAJOR, st), "gather lm")
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        L.check(lib.us_hashgrid_bwd_input_gather(d, P(p), P(x), P(dy), n, P(b), clamp | L.US_GRID_ACCUMULATE, st), "gather acc")
+        assert torch.allclose(b, 2 * ref, rtol=1e-6, atol=1e-7)
+        if clamp:
+            outside = ((x < 0) | (x > 1))
+            assert float(a[outside].abs().max()) == 0.0
+    xin = x.clamp(0, 1).cpu().numpy()
+    dsc = O.make_grid_desc(16, 2, log2T, 16, PLS816)
+    _, dydx_o = O.hashgrid_fwd(dsc, p.cpu().numpy(), xin, True)
+    gx = O.hashgrid_bwd_input(dy.cpu().numpy(), dydx_o) * ((x >= 0) & (x <= 1)).cpu().numpy()
+    np.testing.assert_allclose(a.cpu().numpy(), gx, rtol=2e-4, atol=2e-3)

@@ -62,6 +62,74 @@ extern "C" int us_grid_desc_init(us_grid_desc* d, uint32_t n_levels, uint32_t n_
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
+// the 8 vertices of the cell: v[c], c = x + 2y + 4z
+template <int F>
+__device__ __forceinline__ void gather_corners(const LevelGeom& g, const typename Feat<F>::T* __restrict__ grid, const uint32_t cell[3],
+                                               typename Feat<F>::T (&v)[8]) {
+    if constexpr (F == 2) {
+        // Divergent gathers cost one address cycle per lane, whatever their width: fetch the x and x+1 vertices of a
+        // cell edge with ONE 16-byte load where they are neighbours in memory.  Dense levels: always (entries e, e+1).
+        // Hashed levels: the coherent prime hash leaves x unmultiplied, so for even x the two vertices are the aligned
+        // pair {k & ~1, k | 1}; odd x needs a second (8-byte) gather, issued for those lanes only.
+        typedef float pair_t __attribute__((ext_vector_type(4), aligned(8)));
+        const float2* g2 = reinterpret_cast<const float2*>(grid);
+        if (g.hashed) {
+            const uint32_t mask = g.hs - 1u;
+            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
+            const bool odd = cell[0] & 1u;
+            pair_t pr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
+                const uint32_t k = (cell[0] ^ h) & mask;
+                pr[q] = *reinterpret_cast<const pair_t*>(g2 + (k & ~1u));
+            }
+            float2 up[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) up[q] = make_float2(0.f, 0.f);
+            if (odd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
+                    up[q] = g2[((cell[0] + 1u) ^ h) & mask];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
+                const bool k_odd = ((cell[0] ^ h) & 1u) != 0u;                  // which half of the pair is vertex x
+                const float2 lo = make_float2(pr[q].x, pr[q].y), hi = make_float2(pr[q].z, pr[q].w);
+                v[2 * q] = k_odd ? hi : lo;
+                v[2 * q + 1] = odd ? up[q] : (k_odd ? lo : hi);
+            }
+        } else {
+            const uint32_t base = cell[0] + cell[1] * g.res + cell[2] * g.res2;
+            uint32_t e[4]; bool wrap = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                e[q] = base + ((q & 1) ? g.res : 0u) + ((q & 2) ? g.res2 : 0u);
+                wrap |= (e[q] >= g.hs - 1u);                   // also catches e = 0xFFFFFFFF (cells of coordinates < 0)
+            }
+            if (!wrap) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const pair_t pr = *reinterpret_cast<const pair_t*>(g2 + e[q]);
+                    v[2 * q] = make_float2(pr.x, pr.y); v[2 * q + 1] = make_float2(pr.z, pr.w);
+                }
+            } else {                                                        // the +1 vertex wraps around the slab (x == 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = g2[e[q] % g.hs]; v[2 * q + 1] = g2[(e[q] + 1u) % g.hs];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)           // 8 independent gathers in flight
+            v[c] = grid[grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1))];
+    }
+}
+
 template <int F, bool DYDX>
 __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
                                              const float* __restrict__ x, int64_t n, float* __restrict__ out,
@@ -75,68 +143,7 @@ __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, 
 #pragma unroll
         for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
         typename Feat<F>::T v[8];
-        if constexpr (F == 2) {
-            // Divergent gathers cost one address cycle per lane, whatever their width: fetch the x and x+1 vertices of a
-            // cell edge with ONE 16-byte load where they are neighbours in memory.  Dense levels: always (entries e, e+1).
-            // Hashed levels: the coherent prime hash leaves x unmultiplied, so for even x the two vertices are the aligned
-            // pair {k & ~1, k | 1}; odd x needs a second (8-byte) gather, issued for those lanes only.
-            typedef float pair_t __attribute__((ext_vector_type(4), aligned(8)));
-            const float2* g2 = reinterpret_cast<const float2*>(grid);
-            if (g.hashed) {
-                const uint32_t mask = g.hs - 1u;
-                const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
-                const bool odd = cell[0] & 1u;
-                pair_t pr[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                    const uint32_t k = (cell[0] ^ h) & mask;
-                    pr[q] = *reinterpret_cast<const pair_t*>(g2 + (k & ~1u));
-                }
-                float2 up[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) up[q] = make_float2(0.f, 0.f);
-                if (odd) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                        up[q] = g2[((cell[0] + 1u) ^ h) & mask];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                    const bool k_odd = ((cell[0] ^ h) & 1u) != 0u;                  // which half of the pair is vertex x
-                    const float2 lo = make_float2(pr[q].x, pr[q].y), hi = make_float2(pr[q].z, pr[q].w);
-                    v[2 * q] = k_odd ? hi : lo;
-                    v[2 * q + 1] = odd ? up[q] : (k_odd ? lo : hi);
-                }
-            } else {
-                const uint32_t base = cell[0] + cell[1] * g.res + cell[2] * g.res2;
-                uint32_t e[4]; bool wrap = false;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e[q] = base + ((q & 1) ? g.res : 0u) + ((q & 2) ? g.res2 : 0u);
-                    wrap |= (e[q] + 1u >= g.hs);
-                }
-                if (!wrap) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const pair_t pr = *reinterpret_cast<const pair_t*>(g2 + e[q]);
-                        v[2 * q] = make_float2(pr.x, pr.y); v[2 * q + 1] = make_float2(pr.z, pr.w);
-                    }
-                } else {                                                        // the +1 vertex wraps around the slab (x == 1)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[2 * q] = g2[e[q] % g.hs]; v[2 * q + 1] = g2[(e[q] + 1u) % g.hs];
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)           // 8 independent gathers in flight
-                v[c] = grid[grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1))];
-        }
+        gather_corners<F>(g, grid, cell, v);
         float res[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) res[f] = 0.0f;
@@ -383,6 +390,67 @@ __global__ __launch_bounds__(256) void k_bwd_input(const float* __restrict__ dL_
     }
 }
 
+// The same without a stored dy_dx: every point re-gathers its 8 vertices per level and forms dy/dx on the fly
+// (what k_fwd<DYDX> writes, value for value, consumed in the same channel order as k_bwd_input).  Saves the [N][C][3]
+// tensor (100 MB per grid at 4096 x 64) at the price of a second gather pass.
+template <int F>
+__global__ __launch_bounds__(256) void k_bwd_input_gather(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
+                                                          const float* __restrict__ x, const float* __restrict__ dL_dy, int64_t n,
+                                                          float* __restrict__ dL_dx, int clamp, int lm, int accumulate) {
+    const uint32_t C = n_levels * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float xin[3], xv[3], r[3] = {0.f, 0.f, 0.f};
+        bool pass[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xin[k] = x[i * 3 + k];
+            xv[k] = clamp ? fminf(fmaxf(xin[k], 0.0f), 1.0f) : xin[k];
+            pass[k] = !clamp || (xin[k] >= 0.0f && xin[k] <= 1.0f);
+        }
+        for (uint32_t level = 0; level < n_levels; ++level) {
+            const LevelGeom g = level_geom(tab, level);
+            const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
+            float pos[3]; uint32_t cell[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pos_fract(xv[k], g.scale, pos[k], cell[k]);
+            typename Feat<F>::T v[8];
+            gather_corners<F>(g, grid, cell, v);
+            float va[8][F], dy[F];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat_to_array<F>(v[c], va[c]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f];
+            float d[F][3];
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float acc[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const int d0 = gd == 0 ? 1 : 0, d1 = gd == 2 ? 1 : 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w = g.scale;
+                    w *= (q & 1) ? pos[d0] : 1.0f - pos[d0];
+                    w *= (q & 2) ? pos[d1] : 1.0f - pos[d1];
+                    const int cl = ((q & 1) << d0) | (((q >> 1) & 1) << d1);
+                    const int cr = cl | (1 << gd);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) acc[f] += w * (va[cr][f] - va[cl][f]);
+                }
+#pragma unroll
+                for (int f = 0; f < F; ++f) d[f][gd] = pass[gd] ? acc[f] : 0.0f;
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int gd = 0; gd < 3; ++gd) r[gd] += dy[f] * d[f][gd];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dx[i * 3 + k] = accumulate ? dL_dx[i * 3 + k] + r[k] : r[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
@@ -498,5 +566,22 @@ extern "C" int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int
     US_REQUIRE(dL_dy && dy_dx && dL_dx, US_ERR_NULL, "us_hashgrid_bwd_input: NULL pointer");
     hipLaunchKernelGGL(k_bwd_input, dim3(point_blocks(n, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, dL_dy, dy_dx, n, C, dL_dx);
     US_CHECK_LAUNCH("us_hashgrid_bwd_input");
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_input_gather(const us_grid_desc* d, const float* params, const float* x, const float* dL_dy, int64_t n,
+                                            float* dL_dx, int flags, void* stream) {
+    int rc = check_desc("us_hashgrid_bwd_input_gather", d); if (rc) return rc;
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params && x && dL_dy && dL_dx, US_ERR_NULL, "us_hashgrid_bwd_input_gather: NULL pointer");
+    US_REQUIRE(((uintptr_t)params & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_bwd_input_gather: params must be 16-byte aligned");
+    const LevelTable t = make_table(d);
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0, acc = (flags & US_GRID_ACCUMULATE) ? 1 : 0;
+    dim3 grid(point_blocks(n, 256, 1 << 20)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_BIG(F) hipLaunchKernelGGL((k_bwd_input_gather<F>), grid, block, 0, s, t, d->n_levels, params, x, dL_dy, n, dL_dx, clamp, lm, acc);
+    switch (d->n_features) { case 1: LAUNCH_BIG(1) break; case 2: LAUNCH_BIG(2) break; default: LAUNCH_BIG(4) break; }
+#undef LAUNCH_BIG
+    US_CHECK_LAUNCH("us_hashgrid_bwd_input_gather");
     return US_OK;
 }
