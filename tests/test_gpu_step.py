@@ -404,3 +404,26 @@ def test_mapstep_bf16_decoders_track_fp32(tcnn, hidden):
     assert rel(gs_b, gs_f) < 0.15 and rel(gc_b, gc_f) < 0.15, (rel(gs_b, gs_f), rel(gc_b, gc_f))
     assert abs(losses["bf16"][0] - losses["fp32"][0]) < 2e-2 * abs(losses["fp32"][0])
     assert losses["bf16"][-1] < losses["bf16"][0] and abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * abs(losses["fp32"][-1])
+
+
+@pytest.mark.parametrize("tcnn", [False, True])
+def test_mapstep_ray_gradients_match_autograd(tcnn):
+    """backward(ray_grads=True): dL/d rays_o, dL/d rays_d of the mapping loss (what Mapper.py:358-374 joint_opt differentiates
+    through cam_pose_to_matrix) against torch autograd through Renderer + Decoders + losses on the same rays and draws."""
+    import unislam_amd as us
+    dec, es, ec = _scene(us, tcnn)
+    R, S = 257, 40
+    ro, rd, gd, gc = _rays(R, outside=True)
+    t_rand = torch.rand(R, S, device=DEV)
+    rend = us.Renderer(_cfg(tcnn), types.SimpleNamespace(bound=BOUND, device=DEV, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5))
+    roa, rda = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+    inside = us.common.bbox_filter(ro, rd, gd, BOUND)
+    ret = rend.render_batch_ray(([es], [ec]), dec, rda[inside], roa[inside], DEV, 0.06, gt_depth=gd[inside], t_rand=t_rand[inside])
+    us.mapping_loss(ret, gd[inside], gc[inside], 0.06, W).backward()
+    dec2, es2, ec2 = copy.deepcopy(dec), copy.deepcopy(es), copy.deepcopy(ec)
+    step = us.MapStep(es2, ec2, dec2, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+    step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False, ray_grads=True)
+    g_o, g_d = step.ray_gradients()
+    assert float(g_o[~inside].abs().max()) == 0.0 and float(g_d[~inside].abs().max()) == 0.0
+    for a, b in ((g_o, roa.grad), (g_d, rda.grad)):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max())), float((a - b).abs().max() / b.abs().max())

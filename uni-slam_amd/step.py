@@ -254,9 +254,11 @@ class MapStep:
         self._batch = (o, d, gd, gc, R)
         return self.stats
 
-    def backward(self, on_ready=None):
+    def backward(self, on_ready=None, ray_grads=False):
         """
         Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
+        ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
+        src/Mapper.py:358-374 differentiates through; the positions' gradient re-gathers the tables (no stored dy/dx).
         The colour branch runs first; on_ready(view) is called when the colour-table segment, and at the end the
         [decoders | beta | sdf table] segment, of self.grad are final (dist.dp_iterate overlaps their all-reduces).
         """
@@ -319,13 +321,27 @@ class MapStep:
             sdf_branch(st)
         if on_ready is not None:
             on_ready(self.grad[:self.o_tab_c])
+        if ray_grads:
+            if not hasattr(self, "d_pts") or self.d_pts.shape[0] < R:
+                f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
+                self.d_pts, self.g_o, self.g_d = f(self.max_rays, S, 3), f(self.max_rays, 3), f(self.max_rays, 3)
+            L.check(lib.us_hashgrid_bwd_input_gather(ds, off(fl, self.o_tab_s), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
+                    "us_hashgrid_bwd_input_gather")
+            L.check(lib.us_hashgrid_bwd_input_gather(dc, off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_c), N, P(self.d_pts),
+                                                     3 | L.US_GRID_ACCUMULATE, st), "us_hashgrid_bwd_input_gather")
+            L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
         self.n_rays = R
         return self.loss
 
-    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False):
         """single-process forward + backward (no optimiser step); returns loss[1]"""
         self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
-        return self.backward()
+        return self.backward(ray_grads=ray_grads)
+
+    def ray_gradients(self):
+        """(dL/d rays_o [R,3], dL/d rays_d [R,3]) of the last backward(ray_grads=True); rays dropped by the pre-filter get 0"""
+        R = self.n_rays
+        return self.g_o[:R], self.g_d[:R]
 
     def adam_step(self):
         lib, st, P = L.lib(), L.stream(), L.ptr
@@ -383,9 +399,8 @@ class TrackStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
-        self.z, self.pts, self.d_pts, self.d_pts2 = f(R, S), f(R, S, 3), f(R, S, 3), f(R, S, 3)
+        self.z, self.pts, self.d_pts = f(R, S), f(R, S, 3), f(R, S, 3)
         self.feat_s, self.feat_c, self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32), f(N, 32), f(N, 32)
-        self.dydx_s, self.dydx_c = f(N, 32, 3), f(N, 32, 3)
         self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
         self.term, self.unc, self.depth, self.dunc, self.rgb = f(R), f(R), f(R), f(R), f(R, 3)
         self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
@@ -429,10 +444,11 @@ class TrackStep:
         L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2),
                                 ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, P(self.z), st), "us_sample_z")
         L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
-        L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), P(self.dydx_s), 1, st), "us_hashgrid_fwd")
-        L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), P(self.dydx_c), 1, st), "us_hashgrid_fwd")
-        L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 0, st), "us_mlp_fwd")
-        L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 0, st), "us_mlp_fwd")
+        # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers
+        L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
+        L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
+        L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
+        L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), P(self._beta), R, S, P(self.term), P(self.unc), P(self.depth),
                                      P(self.rgb), P(self.dunc), None, st), "us_composite_fwd")
         med = None
@@ -451,13 +467,14 @@ class TrackStep:
                                  P(self.g_rgb), P(self.loss), st), "us_loss_grad")
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), P(self._beta), R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), None, None, st), "us_composite_bwd")
-        L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 0,
+        L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1,
                                None, 0, st), "us_mlp_bwd")
-        L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 0,
+        L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
                                None, 0, st), "us_mlp_bwd")
-        L.check(lib.us_hashgrid_bwd_input(P(self.d_feat_s), P(self.dydx_s), N, 32, P(self.d_pts), st), "us_hashgrid_bwd_input")
-        L.check(lib.us_hashgrid_bwd_input(P(self.d_feat_c), P(self.dydx_c), N, 32, P(self.d_pts2), st), "us_hashgrid_bwd_input")
-        self.d_pts[:R].add_(self.d_pts2[:R])
+        L.check(lib.us_hashgrid_bwd_input_gather(ds, P(ts), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
+                "us_hashgrid_bwd_input_gather")
+        L.check(lib.us_hashgrid_bwd_input_gather(dc, P(tc), P(self.pts), P(self.d_feat_c), N, P(self.d_pts), 3 | L.US_GRID_ACCUMULATE, st),
+                "us_hashgrid_bwd_input_gather")
         L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
         return self.loss, self.g_o[:R], self.g_d[:R], self.unc[:R], self.valid[:R]
 
