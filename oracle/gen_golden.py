@@ -17,6 +17,7 @@ Fixtures:
                hash grid plugged in as scene_rep (pins everything AROUND the encoder)
   g8_tracking  Tracker.optimize_tracking, one full iteration (dummy self)
   g9_mapping   Mapper.optimize_mapping, two full iterations incl. Adam (dummy self)
+  g10_keyframes Mapper.keyframe_selection_LC (dummy self): overlap ranking, loop-closure window, tracking-back draw
 """
 import os
 import sys
@@ -345,6 +346,38 @@ def g9():
     npz("g9_mapping", **out)
 
 
+def g10():
+    """Mapper.keyframe_selection_LC (Mapper.py:177-274) with a dummy self; three situations."""
+    g = torch.Generator().manual_seed(10)
+    H, W, fx, fy, cx, cy = 60, 80, 50.0, 50.0, 39.5, 29.5
+    gt_depth = torch.rand(H, W, generator=g) * 1.5 + 1.0
+    gt_depth[10, 5:25] = 0.0
+    gt_color = torch.rand(H, W, 3, generator=g)
+    base = O.cam_pose_to_matrix(torch.tensor([[0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0]]))[0]
+    n_frames = 140
+    est = torch.zeros(n_frames, 4, 4)
+    # keyframes every 10 frames: the camera drifts away and turns, then comes back to the start (loop) at frame 130
+    kfs = list(range(0, 130, 10))
+    for k in kfs:
+        t = k / 120.0
+        ang = 2.5 * np.sin(np.pi * t)                                        # turns away, returns at t = 1
+        q = torch.tensor([[np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0, 0.0, 0.0, 0.0]], dtype=torch.float32)
+        rot = O.cam_pose_to_matrix(q)[0]
+        c = base.clone(); c[:3, :3] = base[:3, :3] @ rot[:3, :3]; c[:3, 3] = base[:3, 3] + torch.tensor([0.8 * np.sin(np.pi * t), 0.3 * t * (1 - t), 0.0], dtype=torch.float32)
+        est[k] = c
+    out = dict(intr=np.array([H, W, fx, fy, cx, cy]), gt_depth=gt_depth, gt_color=gt_color, c2w=base, est=est, keyframe_list=np.array(kfs))
+    for tag, idx, tb, seed in (("plain", 35, 0, 101), ("loop", 135, 0, 102), ("back", 35, 1, 103)):
+        me = types.SimpleNamespace(device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, estimate_c2w_list=est, LC=True,
+                                   keyframe_list=kfs if tag != "plain" else kfs[:6], LC_cnt=torch.zeros(1).int(),
+                                   tracking_back=torch.tensor([tb]).int(), activated_mapping_mode=True)
+        torch.manual_seed(seed)
+        num = len(me.keyframe_list) - 2
+        sel = RefMapper.keyframe_selection_LC(me, num, idx, gt_color, gt_depth, base, 5)
+        out.update({f"{tag}_idx": idx, f"{tag}_tb": tb, f"{tag}_seed": seed, f"{tag}_n_kf": len(me.keyframe_list),
+                    f"{tag}_sel": np.array([int(v) for v in sel], dtype=np.int64), f"{tag}_lc": int(me.LC_cnt[0])})
+    npz("g10_keyframes", **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         fn()

@@ -190,3 +190,19 @@ def test_g9_mapping_two_iterations(golden):
     close(es.params, g["grid_s1"], 1e-4, 1e-6); close(ec.params, g["grid_c1"], 1e-4, 1e-6)
     for n, v in dec.state_dict().items():
         close(v, g["dec1__" + n.replace(".", "__")], 1e-4, 1e-6)
+
+
+def test_g10_keyframe_selection(golden):
+    """unislam_amd.slam.keyframe_selection_LC (host logic, torch ops only) against Mapper.keyframe_selection_LC of the reference"""
+    from unislam_amd.slam import keyframe_selection_LC
+    g = golden("g10_keyframes")
+    H, W, fx, fy, cx, cy = [float(v) for v in g["intr"]]
+    cam = (int(H), int(W), fx, fy, cx, cy)
+    est, kfs = T(g["est"]), [int(k) for k in g["keyframe_list"]]
+    for tag in ("plain", "loop", "back"):
+        kl = kfs[:int(g[f"{tag}_n_kf"])]
+        torch.manual_seed(int(g[f"{tag}_seed"]))
+        sel, pct, loop = keyframe_selection_LC(len(kl) - 2, int(g[f"{tag}_idx"]), T(g["gt_color"]), T(g["gt_depth"]), T(g["c2w"]), 5, kl, est,
+                                               cam, "cpu", tracking_back=bool(g[f"{tag}_tb"]), activated_mapping_mode=True, LC=True)
+        assert [int(v) for v in sel] == [int(v) for v in g[f"{tag}_sel"]], tag
+        assert int(loop) == int(g[f"{tag}_lc"])

@@ -1,0 +1,269 @@
+"""
+Thin tracking / mapping drivers around the hot path: the per-frame logic of the reference's
+Tracker.run (src/Tracker.py:271-370) and Mapper.run / optimize_mapping / keyframe_selection_LC (src/Mapper.py:177-545) with the
+inner loops served by TrackStep / MapStep.  One process, the two roles alternate (the reference runs them as two processes
+that wait for each other at every `every_frame`-th frame, so the order of operations is the same).
+
+Kept from the reference: constant-speed pose initialisation, per-frame fresh pose Adam (betas 0.5/0.999), keeping the
+minimum-loss pose, the uncertainty-triggered "activated mapping" (double iterations + an extra mapping pass), keyframe pools of
+10 % of the pixels, overlap-based keyframe selection incl. the loop-closure window, pixel budget per window frame, first-frame
+lr factor / iterations, joint optimisation of the window's camera poses (oldest fixed).
+Left out: visualiser, logger/checkpoints, mesher (SURVEY.md 8 "out of scope").
+"""
+import torch
+import torch.nn as nn
+
+from .common import (cam_pose_to_matrix, get_samples, get_samples_all, matrix_to_cam_pose)
+from .step import MapStep, TrackStep
+
+DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
+    "tracking": dict(ignore_edge_W=75, ignore_edge_H=75, const_speed_assumption=True, lr_T=0.002, lr_R=0.001, pixels=2000, iters=8,
+                     activated_mapping_mode=True, uncertainty_ts=0.001,
+                     w=dict(fs=10, center=200, tail=50, depth=1, color=5)),
+    "mapping": dict(every_frame=4, keyframe_every=4, joint_opt=True, joint_opt_cam_lr=0.001, mapping_window_size=20,
+                    lr_first_factor=5, lr_factor=1, pixels=4000, iters_first=10, iters=15, LC=True, LC_ts=0.95,
+                    lr=dict(decoders=0.001, sdf_grid=0.05, color_grid=0.05), w=dict(fs=5, center=200, tail=10, depth=0.1, color=5)),
+    "rendering": dict(n_stratified=32, n_importance=8, perturb=True), "truncation": 0.06,
+    "m_mask_mode": "original", "t_mask_mode": "original",
+}
+
+
+def keyframe_overlap(pts, keyframes_c2ws, H, W, fx, fy, cx, cy, edge=20):
+    """Mapper.py:217-240: fraction of the sample points `pts` [M,3] that project inside each keyframe's image."""
+    device = pts.device
+    w2cs = torch.inverse(keyframes_c2ws)
+    ones = torch.ones_like(pts[..., :1])
+    homo = torch.cat([pts, ones], dim=-1).reshape(1, -1, 4, 1).expand(w2cs.shape[0], -1, -1, -1)
+    cam = (w2cs.unsqueeze(1).expand(-1, homo.shape[1], -1, -1) @ homo)[:, :, :3]
+    K = torch.tensor([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]], device=device).reshape(3, 3)
+    cam = cam.clone()
+    cam[:, :, 0] *= -1
+    uv = K @ cam
+    z = uv[:, :, -1:] + 1e-5
+    uv = uv[:, :, :2] / z
+    mask = (uv[:, :, 0] < W - edge) * (uv[:, :, 0] > edge) * (uv[:, :, 1] < H - edge) * (uv[:, :, 1] > edge)
+    mask = (mask & (z[:, :, 0] < 0)).squeeze(-1)
+    return mask.sum(dim=1) / uv.shape[1]
+
+
+def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, device,
+                          tracking_back=False, activated_mapping_mode=True, LC=True, num_samples=8, num_rays=50):
+    """
+    Mapper.keyframe_selection_LC (src/Mapper.py:177-274): indices into the keyframe list (excluding its last two entries) of the
+    keyframes to optimise with the current view: ALL of them ("global"), from the loop partner on after a loop closure, or the
+    num_keyframes best-overlapping ones while tracking back.  cam = (H, W, fx, fy, cx, cy).
+    Returns (selected list, percent_inside, loop_closure).
+    """
+    H, W, fx, fy, cx, cy = cam
+    rays_o, rays_d, gd, _ = get_samples(0, H, 0, W, num_rays, H, W, fx, fy, cx, cy, c2w.unsqueeze(0), gt_depth.unsqueeze(0),
+                                        gt_color.unsqueeze(0), device)
+    gd = gd.reshape(-1, 1)
+    nz = gd[:, 0] > 0
+    rays_o, rays_d, gd = rays_o[nz], rays_d[nz], gd[nz].repeat(1, num_samples)
+    t_vals = torch.linspace(0., 1., steps=num_samples).to(device)
+    z_vals = gd * 0.8 * (1. - t_vals) + (gd + 0.5) * t_vals
+    pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]).reshape(-1, 3)
+    kf_c2ws = torch.stack([estimate_c2w_list[k] for k in keyframe_list], dim=0)[:-2]      # the last two are included anyway
+    loop = False
+    if kf_c2ws.shape[0] > 0:
+        percent_inside = keyframe_overlap(pts, kf_c2ws, H, W, fx, fy, cx, cy)
+        idx1 = keyframe_list[int(torch.argmax(percent_inside))]
+        if percent_inside.max() > 0.95 and (idx - idx1) > 100 and LC:
+            selected = list(range(0, num))[int(torch.argmax(percent_inside)):]           # only the frames of this loop
+            loop = True
+        else:
+            selected = list(range(0, num))
+    else:
+        percent_inside = torch.zeros(0, device=device)
+        selected = list(range(0, num))
+    if tracking_back and activated_mapping_mode:                                         # local BA while tracking back (:253-272)
+        sel = torch.nonzero(percent_inside).squeeze(-1)
+        sel = sel[torch.randperm(sel.shape[0])[:num_keyframes]]                          # (the draw is made, then overridden)
+        selected = [int(k) for k in sel.cpu().numpy()]
+        if percent_inside.shape[0] > 0:                                                  # the num_keyframes best-overlapping ones
+            order = sorted(range(len(percent_inside)), key=lambda k: float(percent_inside[k]), reverse=True)
+            selected = [k for k in order if percent_inside[k] > 0.00][:num_keyframes]
+    return selected, percent_inside, loop
+
+
+class Mapper:
+    """Mapper.run body for one frame + optimize_mapping (src/Mapper.py:276-459,461-545)"""
+
+    def __init__(self, slam):
+        self.s = slam
+        c = slam.cfg["mapping"]
+        r = slam.cfg["rendering"]
+        self.c = c
+        self.step = MapStep(slam.es, slam.ec, slam.decoders, slam.bound, r["n_stratified"], r["n_importance"], slam.cfg["truncation"],
+                            c["w"], c["lr"], mask_mode=slam.cfg["m_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"] + 2000)
+        self.keyframe_list, self.keyframe_dict = [], []
+        self.init_phase, self.LC_cnt = True, 0
+
+    def _pool(self, color, depth, rays_d):
+        """10 % of the pixels of a frame as its sampling pool (Mapper.py:329-337,516-523)"""
+        total = color.shape[0] * color.shape[1]
+        ind = torch.randperm(total, device=color.device)[:int(total * 0.1)]
+        return color.reshape(-1, 3)[ind], depth.reshape(-1)[ind], rays_d.reshape(-1, 3)[ind]
+
+    def optimize_mapping(self, iters, lr_factor, idx, cur_color, cur_depth, cur_c2w, cur_rays_d):
+        s, c, dev = self.s, self.c, self.s.device
+        H, W, fx, fy, cx, cy = s.cam
+        kd, kl = self.keyframe_dict, self.keyframe_list
+        if len(kd) == 0:
+            optimize_frame = []
+        else:
+            optimize_frame, _, loop = keyframe_selection_LC(len(kd) - 2, idx, cur_color, cur_depth, cur_c2w, c["mapping_window_size"] - 1,
+                                                            kl, s.estimate_c2w_list, s.cam, dev, s.tracking_back,
+                                                            s.cfg["tracking"]["activated_mapping_mode"], c["LC"])
+            self.LC_cnt += int(loop)
+        if len(kl) > 1:
+            optimize_frame = sorted(optimize_frame + [len(kl) - 1] + [len(kl) - 2])
+        optimize_frame += [-1]                                                          # -1 = the current frame
+        pixs_per_image = c["pixels"] // len(optimize_frame)
+        depths, colors, c2ws, dirs = [], [], [], []
+        for f in optimize_frame:
+            if f != -1:
+                depths.append(kd[f]["depth"]); colors.append(kd[f]["color"]); dirs.append(kd[f]["rays_d"]); c2ws.append(kd[f]["est_c2w"])
+            else:
+                pc, pd, pr = self._pool(cur_color, cur_depth, cur_rays_d)
+                depths.append(pd); colors.append(pc); dirs.append(pr); c2ws.append(cur_c2w)
+        depths, colors, c2ws, dirs = torch.stack(depths), torch.stack(colors), torch.stack(c2ws), torch.stack(dirs)
+        joint = self.joint_opt and c2ws.shape[0] > 1
+        self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
+        if joint:
+            cam_poses = nn.Parameter(matrix_to_cam_pose(c2ws[1:]))                      # the oldest pose stays fixed
+            pose_opt = torch.optim.Adam([cam_poses], lr=c["joint_opt_cam_lr"])
+        has_zero = bool((depths <= 0).any())                                            # once per mapped frame, on the pools
+        for _ in range(int(iters)):
+            c2ws_ = torch.cat([c2ws[0:1], cam_pose_to_matrix(cam_poses)], dim=0) if joint else c2ws
+            ro, rd, gd, gc = get_samples_all(0, H, 0, W, pixs_per_image, H, W, fx, fy, cx, cy, c2ws_, depths, colors, dev, dirs)
+            if not s.tracking_back and len(kl) > 20:                                    # extra rays from the newest frames (:381-390)
+                ro2, rd2, gd2, gc2 = get_samples_all(0, H, 0, W, 200, H, W, fx, fy, cx, cy, c2ws_[-10:], depths[-10:], colors[-10:], dev,
+                                                     dirs[-10:])
+                ro, rd, gd, gc = torch.cat([ro, ro2]), torch.cat([rd, rd2]), torch.cat([gd, gd2]), torch.cat([gc, gc2])
+            if joint:
+                self.step.forward(ro, rd, gd, gc, has_zero_depth=has_zero)
+                self.step.backward(ray_grads=True)
+                g_o, g_d = self.step.ray_gradients()
+                pose_opt.zero_grad()
+                torch.autograd.backward([ro, rd], [g_o, g_d])                           # rays -> c2ws -> quaternion / translation
+                self.step.adam_step()
+                pose_opt.step()
+            else:
+                self.step.iterate(ro, rd, gd, gc, has_zero_depth=has_zero)
+        if joint:
+            opt_c2ws = cam_pose_to_matrix(cam_poses.detach())
+            k = 0
+            for f in optimize_frame[1:]:
+                if f != -1:
+                    kd[f]["est_c2w"] = opt_c2ws[k]; k += 1
+                else:
+                    cur_c2w = opt_c2ws[-1]
+        return cur_c2w
+
+    def map_frame(self, idx, color, depth, gt_c2w, rays_d):
+        """one pass of the Mapper.run loop body for frame idx (Mapper.py:494-533)"""
+        s, c = self.s, self.c
+        cur_c2w = s.estimate_c2w_list[idx]
+        lr_factor = c["lr_first_factor"] if self.init_phase else c["lr_factor"]
+        iters = c["iters_first"] if self.init_phase else s.m_iters
+        self.joint_opt = (len(self.keyframe_list) > 4) and c["joint_opt"]
+        cur_c2w = self.optimize_mapping(iters, lr_factor, idx, color, depth, cur_c2w, rays_d)
+        if self.joint_opt:
+            s.estimate_c2w_list[idx] = cur_c2w
+        if idx % c["keyframe_every"] == 0 or s.tracking_back:
+            self.keyframe_list.append(idx)
+            pc, pd, pr = self._pool(color, depth, rays_d)
+            self.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "color": pc, "depth": pd, "est_c2w": cur_c2w.clone(), "rays_d": pr})
+        self.init_phase = False
+
+
+class Tracker:
+    """Tracker.run body for one frame (src/Tracker.py:296-361)"""
+
+    def __init__(self, slam):
+        self.s = slam
+        c, r = slam.cfg["tracking"], slam.cfg["rendering"]
+        self.c = c
+        self.step = TrackStep(slam.es, slam.ec, slam.decoders, slam.bound, r["n_stratified"], r["n_importance"], slam.cfg["truncation"],
+                              c["w"], mask_mode=slam.cfg["t_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"])
+        self.num_cam_iters = c["iters"]
+        self.rendered_weight = {}
+
+    def track_frame(self, idx, color, depth):
+        s, c, dev = self.s, self.c, self.s.device
+        H, W, fx, fy, cx, cy = s.cam
+        pre_c2w = s.estimate_c2w_list[idx - 1]
+        if c["const_speed_assumption"] and idx - 2 >= 0:                                # linear prediction (:317-320)
+            pre = matrix_to_cam_pose(torch.stack([s.estimate_c2w_list[idx - 2], pre_c2w], dim=0))
+            cam_pose = 2 * pre[1:] - pre[0:1]
+        else:
+            cam_pose = matrix_to_cam_pose(pre_c2w.unsqueeze(0))
+        self.step.begin_frame(cam_pose[0], color, depth, c["lr_T"], c["lr_R"], H, W, fx, fy, cx, cy, c["ignore_edge_H"], c["ignore_edge_W"],
+                              betas=(0.5, 0.999))
+        min_loss = torch.full((1,), float("inf"), device=dev)
+        cand = self.step.pose.clone()
+        it = 0
+        while it < self.num_cam_iters:                                                  # re-read: the count may double mid-frame
+            pose_before = self.step.pose.clone()                                        # the loss belongs to the pose it was rendered at
+            loss, unc, valid = self.step.iterate_fused(c["pixels"])
+            better = loss < min_loss                                                    # (:346-348), kept on the device
+            min_loss = torch.where(better, loss, min_loss)
+            cand = torch.where(better, pose_before, cand)
+            it += 1
+            if it == self.num_cam_iters - 1:                                            # (:352-364)
+                w = (unc * valid.float()).sum() / valid.float().sum().clamp(min=1)
+                self.rendered_weight[idx] = w
+                if c["activated_mapping_mode"] and float(w) > c["uncertainty_ts"]:
+                    self.num_cam_iters = c["iters"] * 2
+                    s.m_iters, s.tracking_back = s.cfg["mapping"]["iters"] * 2, True
+                else:
+                    self.num_cam_iters = c["iters"]
+                    s.m_iters, s.tracking_back = s.cfg["mapping"]["iters"], False
+        return cam_pose_to_matrix(cand.reshape(1, 7))[0]
+
+
+class SLAM:
+    """
+    Sequential tracking + mapping over a frame source (items: idx, color [H,W,3], depth [H,W], gt_c2w [4,4], rays_d [H,W,3]).
+    hash grids / decoders: the modules the reference builds at src/UNISLAM.py:241-259.
+    """
+
+    def __init__(self, frames, cam, hash_grid_sdf, hash_grid_color, decoders, bound, cfg=None):
+        import copy
+        self.frames, self.cam = frames, cam
+        self.cfg = copy.deepcopy(DEFAULTS)
+        for k, v in (cfg or {}).items():
+            if isinstance(v, dict):
+                self.cfg[k].update(v)
+            else:
+                self.cfg[k] = v
+        self.es, self.ec, self.decoders, self.bound = hash_grid_sdf, hash_grid_color, decoders, bound
+        self.device = hash_grid_sdf.params.device
+        n = len(frames)
+        self.estimate_c2w_list = torch.zeros((n, 4, 4), device=self.device)
+        self.gt_c2w_list = torch.zeros((n, 4, 4), device=self.device)
+        self.m_iters, self.tracking_back = self.cfg["mapping"]["iters"], False
+        self.mapper, self.tracker = Mapper(self), Tracker(self)
+
+    def run(self, n_frames=None, log=None):
+        every = self.cfg["mapping"]["every_frame"]
+        n = len(self.frames) if n_frames is None else n_frames
+        for idx in range(n):
+            _, color, depth, gt_c2w, rays_d = self.frames[idx]
+            self.gt_c2w_list[idx] = gt_c2w
+            if idx == 0:
+                self.estimate_c2w_list[0] = gt_c2w                                       # the first pose is given (Mapper.py:479)
+            else:
+                self.estimate_c2w_list[idx] = self.tracker.track_frame(idx, color, depth)
+            if idx % every == 0 or self.tracking_back or idx == n - 1:                  # Mapper.py:487-493
+                self.mapper.map_frame(idx, color, depth, gt_c2w, rays_d)
+            if log is not None:
+                log(idx, self)
+        return self.estimate_c2w_list[:n]
+
+    def ate_rmse(self, n=None):
+        """translation RMSE of the estimated trajectory against the given one, no alignment (frame 0 is shared)"""
+        n = self.estimate_c2w_list.shape[0] if n is None else n
+        d = self.estimate_c2w_list[:n, :3, 3] - self.gt_c2w_list[:n, :3, 3]
+        return float(d.pow(2).sum(-1).mean().sqrt())
