@@ -42,28 +42,30 @@ class _HashGridFn(torch.autograd.Function):
         n = x.shape[0]
         C = desc.n_levels * desc.n_features
         out = torch.empty((n, C), dtype=torch.float32, device=x.device)
-        need_dx = ctx.needs_input_grad[0]
-        dydx = torch.empty((n, C, 3), dtype=torch.float32, device=x.device) if need_dx else None
-        L.check(L.lib().us_hashgrid_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(out), L.ptr(dydx), flags,
+        L.check(L.lib().us_hashgrid_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(out), None, flags,
                                         L.stream()), "us_hashgrid_fwd")
         ctx.desc, ctx.flags, ctx.bwd_mode = desc, flags, bwd_mode
-        ctx.save_for_backward(x, dydx if need_dx else x.new_empty(0))
+        ctx.save_for_backward(x, p)           # no dy/dx tensor: the input gradient gathers the vertices again
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, dydx = ctx.saved_tensors
+        x, p = ctx.saved_tensors
         desc = ctx.desc
         dy = L.f32(dy)
         n = x.shape[0]
         gx = gp = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((n, 3), dtype=torch.float32, device=x.device)
-            L.check(L.lib().us_hashgrid_bwd_input(L.ptr(dy), L.ptr(dydx), n, desc.n_levels * desc.n_features,
-                                                  L.ptr(gx), L.stream()), "us_hashgrid_bwd_input")
+            L.check(L.lib().us_hashgrid_bwd_input_gather(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(dy), n, L.ptr(gx), ctx.flags,
+                                                         L.stream()), "us_hashgrid_bwd_input_gather")
         if ctx.needs_input_grad[1]:
             mode = ctx.bwd_mode
-            binned = mode == 3 or (mode == -1 and n >= 16384)
+            # the binned path addresses its 12-byte records with 32-bit offsets: beyond ~2.8 M points (L = 16, F = 2) fall back
+            fits = n * 8 * desc.n_levels * (1 + desc.n_features) * 4 <= 0xFFFFFFFF
+            binned = fits and (mode == 3 or (mode == -1 and n >= 16384))
+            if mode == 3 and not fits:
+                mode = 1
             gp = (torch.empty if binned else torch.zeros)(desc.n_params, dtype=torch.float32, device=x.device)
             if binned:
                 # bin once, accumulate in f64 (csrc/hashgrid_binned.hip); scratch comes from torch's caching allocator
