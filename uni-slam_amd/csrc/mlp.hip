@@ -344,29 +344,49 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
     gBL[0] = zero;
 
     const int64_t n_chunks = (n + PTS - 1) / PTS;
-    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
-        const int64_t base = chunk * PTS;
-        v4f xb[NQ][C::KB_IN];
-        load_inputs<NQ, NIN>(in, base, n, row, g, xb, lm);
-        v4f h0[NQ][C::MT], h1[NQ][C::MT];
-        dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
-        relu_<NQ, C::MT>(h0);
-        if (NHID == 2) {
-            dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WH, bias + WIDTH, h0, h1, row, g);
-            relu_<NQ, C::MT>(h1);
-        }
-        // dL/d(pre-activation of the output layer), rows >= n_out and points >= n are zero
-        v4f dO[NQ][1];
+    // Two waves per SIMD cannot hide a global round trip: everything a chunk reads (its 32 input features per point, out and
+    // dL/dout) is requested one chunk ahead and waited for only when the previous chunk's MFMA work has been issued.
+    const int64_t chunk0 = (int64_t)blockIdx.x * WAVES + wave, cstep = (int64_t)gridDim.x * WAVES;
+    v4f xn[NQ][C::KB_IN];
+    float on[NQ][4], dn[NQ][4];
+    auto fetch = [&](int64_t base) {
+        load_inputs<NQ, NIN>(in, base, n, row, g, xn, lm);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int64_t p = base + 16 * q + row;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 4 * g + r;
-                float d = 0.0f;
-                if (p < n && o < n_out) d = dL_dout[p * dout_stride + o] * act_bwd(out[p * out_stride + o], act);
-                dO[q][0][r] = d;
+                const bool ok = p < n && o < n_out;
+                on[q][r] = ok ? out[p * out_stride + o] : 0.0f;
+                dn[q][r] = ok ? dL_dout[p * dout_stride + o] : 0.0f;
             }
+        }
+    };
+    if (chunk0 < n_chunks) fetch(chunk0 * PTS);
+    for (int64_t chunk = chunk0; chunk < n_chunks; chunk += cstep) {
+        const int64_t base = chunk * PTS;
+        v4f xb[NQ][C::KB_IN];
+        // dL/d(pre-activation of the output layer), rows >= n_out and points >= n are zero
+        v4f dO[NQ][1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int b = 0; b < C::KB_IN; ++b) xb[q][b] = xn[q][b];
+            const int64_t p = base + 16 * q + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * g + r;
+                dO[q][0][r] = (p < n && o < n_out) ? dn[q][r] * act_bwd(on[q][r], act) : 0.0f;
+            }
+        }
+        if (chunk + cstep < n_chunks) fetch((chunk + cstep) * PTS);
+        v4f h0[NQ][C::MT], h1[NQ][C::MT];
+        dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
+        relu_<NQ, C::MT>(h0);
+        if (NHID == 2) {
+            dense<NQ, C::KB_H, C::MT, C::S_W>(lds + C::L_WH, bias + WIDTH, h0, h1, row, g);
+            relu_<NQ, C::MT>(h1);
         }
         // ---- output layer:  dWL += dO * Hlast^T ;  dHlast = WL^T dO (.) relu'
         v4f (&hl)[NQ][C::MT] = (NHID == 2) ? h1 : h0;
