@@ -25,7 +25,10 @@
 #include "hashgrid_dev.h"
 #include <string.h>
 
+#ifndef BIN_THREADS
 #define BIN_THREADS 1024                 // binning kernels: 1024 consecutive points per workgroup
+#endif
+#define BIN_SCAN_ELEMS (BIN_MAX_TOTAL / BIN_THREADS)
 #ifndef BIN_MAX_TOTAL
 #define BIN_MAX_TOTAL 4096               // bins over all levels (LDS counters of the binning passes: 16 KiB)
 #endif
@@ -162,23 +165,23 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
                                                      uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ wg_prefix,
                                                      const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec) {
     // lcnt: COUNT pass: records per bin.  WRITE pass: cursor into the workgroup's LDS stage, where the records of one level
-    // are collected sorted by bin (counting sort: the exclusive scan of this workgroup's own counts gives every bin's place).
+    // are collected sorted by bin (counting sort: the exclusive scan of this workgroup's own counts gives every bin's place),
+    // each with its final global slot; the copy-out is then one flat, fully occupied loop.
     // (F = 4 records do not fit a stage beside the counters: that instantiation stores every record straight from the
     //  lane that owns it, lcnt being the global cursor.)
     constexpr bool STAGED = WRITE && F <= 2;
     __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
-    __shared__ uint32_t gpos[STAGED ? BIN_MAX_TOTAL : 1];                      // first global record slot of (workgroup, bin)
-    __shared__ uint32_t st_loc[STAGED ? BIN_STAGE_RECORDS : 1];
-    __shared__ float    st_val[STAGED ? F : 1][STAGED ? BIN_STAGE_RECORDS : 1];
+    __shared__ uint32_t gdelta[STAGED ? BIN_MAX_TOTAL : 1];                    // global record slot = stage cursor + gdelta[bin]
+    __shared__ uint4    st[STAGED ? BIN_STAGE_RECORDS : 1];                    // {global slot, local entry, values}: 128 KiB
     uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL;
     if (WRITE && !STAGED) {
         const uint32_t* pre = wg_prefix + (size_t)blockIdx.x * BIN_MAX_TOTAL;
         for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = offsets[t] + pre[t];
     } else if (WRITE) {
-        uint32_t* sc = st_loc;                                   // scan scratch (the stage is not in use yet)
-        uint32_t c4[4], s4 = 0;
+        uint32_t* sc = reinterpret_cast<uint32_t*>(st);          // scan scratch (the stage is not in use yet)
+        uint32_t c4[BIN_SCAN_ELEMS], s4 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { c4[k] = (4 * threadIdx.x + k < TB) ? row[4 * threadIdx.x + k] : 0u; s4 += c4[k]; }
+        for (int k = 0; k < BIN_SCAN_ELEMS; ++k) { c4[k] = (BIN_SCAN_ELEMS * threadIdx.x + k < TB) ? row[BIN_SCAN_ELEMS * threadIdx.x + k] : 0u; s4 += c4[k]; }
         sc[threadIdx.x] = s4;
         __syncthreads();
         for (uint32_t o = 1; o < BIN_THREADS; o <<= 1) {
@@ -189,9 +192,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         }
         uint32_t run = sc[threadIdx.x] - s4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (4 * threadIdx.x + k < TB) lcnt[4 * threadIdx.x + k] = run; run += c4[k]; }
+        for (int k = 0; k < BIN_SCAN_ELEMS; ++k) { if (BIN_SCAN_ELEMS * threadIdx.x + k < TB) lcnt[BIN_SCAN_ELEMS * threadIdx.x + k] = run; run += c4[k]; }
+        __syncthreads();
         const uint32_t* pre = wg_prefix + (size_t)blockIdx.x * BIN_MAX_TOTAL;
-        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) gpos[t] = offsets[t] + pre[t];
+        for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) gdelta[t] = offsets[t] + pre[t] - lcnt[t];
     } else {
         for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0u;
     }
@@ -303,10 +307,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             for (int c = 0; c < 8; ++c) {
                 const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
                 if (STAGED) {
-                    const uint32_t slot = atomicAdd(&lcnt[b], 1u) - lbase;
-                    st_loc[slot] = local_of(idx[c], q.lg);
-#pragma unroll
-                    for (int f = 0; f < F; ++f) st_val[f][slot] = val[c][f];
+                    const uint32_t cur = atomicAdd(&lcnt[b], 1u);
+                    uint4 e;
+                    e.x = cur + gdelta[b];
+                    e.y = local_of(idx[c], q.lg);
+                    e.z = __float_as_uint(val[c][0]);
+                    e.w = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
+                    st[cur - lbase] = e;
                 } else if (WRITE) {
                     const uint32_t slot = atomicAdd(&lcnt[b], 1u);
                     uint32_t* dst = rec + (size_t)slot * RecW<F>::DW;
@@ -320,24 +327,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         }
         }   // wave has live samples
         if (STAGED) {
-            // ---- copy the level's records out: the stage holds them sorted by bin, bin t at [lcnt[t-1], lcnt[t]) - lbase;
-            //      16 lanes per bin write its records as one contiguous run
+            // ---- copy the level's records out.  The stage holds them sorted by bin, and inside a bin the global slots are
+            //      consecutive, so consecutive threads write consecutive 12-byte records: contiguous runs per bin.
             lds_barrier();
-            const uint32_t nb = 1u << q.lg, grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-            for (uint32_t bl = grp; bl < nb; bl += BIN_THREADS / 16) {
-                const uint32_t t = q.first + bl;
-                const uint32_t e0 = (bl == 0 ? lbase : lcnt[t - 1]) - lbase, e1 = lcnt[t] - lbase;
-                const uint32_t g0 = gpos[t];
-                for (uint32_t k = e0 + l16; k < e1; k += 16) {
-                    struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
-                    RecT r;
-                    r.w[0] = st_loc[k];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) r.w[1 + f] = __float_as_uint(st_val[f][k]);
-                    const uint32_t slot = g0 + (k - e0);
-                    const uint32_t byte_off = RecW<F>::DW == 3 ? (slot << 3) + (slot << 2) : slot * (uint32_t)(RecW<F>::DW * 4);   // < 2^32 (host check)
-                    *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;
-                }
+            const uint32_t n_lvl = lcnt[q.first + (1u << q.lg) - 1u] - lbase;
+            for (uint32_t k = threadIdx.x; k < n_lvl; k += BIN_THREADS) {
+                const uint4 e = st[k];
+                struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
+                RecT r;
+                r.w[0] = e.y; r.w[1] = e.z;
+                if (F > 1) r.w[F > 1 ? 2 : 1] = e.w;
+                const uint32_t byte_off = RecW<F>::DW == 3 ? (e.x << 3) + (e.x << 2) : e.x * (uint32_t)(RecW<F>::DW * 4);   // < 2^32 (host check)
+#ifdef US_EXP_A_NOSTORE
+                if (e.x == 0xFFFFFFF0u)
+#endif
+                *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;
             }
         }
     }
