@@ -80,3 +80,29 @@ def test_modules_pickle_deepcopy_and_state_dict_keys(built):
     assert torch.equal(enc.params, e2.params) and torch.equal(enc.params, e3.params) and e2.desc.n_params == enc.desc.n_params
     packed = us.Decoders.pack_linear_params(dec.linears, dec.output_linear)
     assert packed.numel() == 32 * 16 + 16 * 16 + 16 * 16 + 16 + 16 + 16
+
+
+def test_checkpoint_roundtrip_reference_keys(tmp_path):
+    """unislam_amd.checkpoint: the reference's .tar keys (Logger.py:36-46) + the two tables; round trip on the CPU (no kernels)."""
+    import types
+    import torch
+    import unislam_amd as us
+    from unislam_amd.checkpoint import load_checkpoint, save_checkpoint
+    ecfg = {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 8, "base_resolution": 4, "per_level_scale": 1.5}
+    mk = lambda seed: us.HashGridEncoding(3, ecfg, seed=seed)
+    cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}}
+    torch.manual_seed(0)
+    dec, es, ec = us.Decoders(cfg, c_dim=32), mk(1), mk(2)
+    slam = types.SimpleNamespace(decoders=dec, es=es, ec=ec, gt_c2w_list=torch.rand(5, 4, 4), estimate_c2w_list=torch.rand(5, 4, 4),
+                                 mapper=types.SimpleNamespace(keyframe_list=[0, 4]))
+    p = save_checkpoint(str(tmp_path / "ckpts" / "00004.tar"), slam, 4)
+    ck = torch.load(p, map_location="cpu", weights_only=False)
+    assert {"decoder_state_dict", "gt_c2w_list", "estimate_c2w_list", "keyframe_list", "idx", "tracking_rendered_weight_list",
+            "addtional_map_records"} <= set(ck.keys())
+    assert set(ck["decoder_state_dict"].keys()) == set(dec.state_dict().keys())
+    torch.manual_seed(1)
+    dec2, es2, ec2 = us.Decoders(cfg, c_dim=32), mk(3), mk(4)
+    out = load_checkpoint(p, dec2, es2, ec2)
+    assert out["idx"] == 4 and out["keyframe_list"] == [0, 4]
+    assert all(torch.equal(a, b) for a, b in zip(dec.state_dict().values(), dec2.state_dict().values()))
+    assert torch.equal(es.params, es2.params) and torch.equal(ec.params, ec2.params)

@@ -39,7 +39,9 @@
 // of f64 LDS atomics at 4.9 TB/s; 256 x 8 reaches 3.8, the LDS footprint caps the resident waves)
 #define ACC_THREADS 512
 #define ACC_UNROLL 4
+#ifndef ACC_CHUNK
 #define ACC_CHUNK 16384                  // records per accumulate workgroup: hotter bins are split (see k_bin_accum)
+#endif
 #define BIN_LINE_LOG2 4                  // bins interleave LINES of 16 entries (128 B of F = 2 gradients)
 
 struct BinMap {
