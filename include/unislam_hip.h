@@ -72,6 +72,9 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * contributed) instead of added to, so the caller need not clear the table gradient beforehand (what optimizer.zero_grad()
  * does at src/Mapper.py:443 before loss.backward()). */
 #define US_GRID_BWD_OVERWRITE 4
+/* US_GRID_BWD_COUNTED (us_hashgrid_bwd_binned only): the workspace already holds the binning counts of these x, written
+ * by us_hashgrid_fwd_counted with the same desc / n / clamp flag; the counting pass is skipped. */
+#define US_GRID_BWD_COUNTED 16
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 
@@ -99,6 +102,12 @@ int us_hashgrid_bwd_params(const us_grid_desc* desc_host, const float* x, const 
 size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* desc_host, int64_t n);
 int us_hashgrid_bwd_binned(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
                            float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/* us_hashgrid_fwd (without dy_dx) that also leaves the counts of the binned backward in `workspace` (the buffer later given to
+ * us_hashgrid_bwd_binned together with US_GRID_BWD_COUNTED; same size).  The encoder is bound by its gathers, so the counting
+ * rides along and the backward pass of the same points starts one kernel later. */
+int us_hashgrid_fwd_counted(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n, float* out,
+                            int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
 int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,

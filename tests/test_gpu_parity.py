@@ -768,3 +768,43 @@ def test_input_gradient_by_regathering_equals_stored_dydx(us, log2T):
     _, dydx_o = O.hashgrid_fwd(dsc, p.cpu().numpy(), xin, True)
     gx = O.hashgrid_bwd_input(dy.cpu().numpy(), dydx_o) * ((x >= 0) & (x <= 1)).cpu().numpy()
     np.testing.assert_allclose(a.cpu().numpy(), gx, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("log2T,n", [(16, 70001), (19, 20000)])
+def test_forward_counted_feeds_the_binned_backward(us, log2T, n):
+    """us_hashgrid_fwd_counted = us_hashgrid_fwd bit for bit + the counts of the binning; us_hashgrid_bwd_binned(COUNTED) on them
+    gives the gradient of the counting backward (dead samples -- zero gradient rows -- become zero records)."""
+    import ctypes
+    from unislam_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(n)
+    # ray-like order (runs of samples in one cell) + some out-of-range coordinates for the clamp
+    R = n // 50 + 1
+    o = torch.rand((R, 1, 3), device=DEV, generator=g) * 0.8 + 0.1
+    dirs = torch.randn((R, 1, 3), device=DEV, generator=g) * 0.2
+    t = torch.linspace(0, 1, 50, device=DEV).reshape(1, 50, 1)
+    x = (o + dirs * t).reshape(-1, 3)[:n].contiguous()
+    enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
+    with torch.no_grad():
+        enc.params.copy_(torch.randn(enc.params.shape, device=DEV, generator=g) * 0.2)
+    p = enc.params.detach()
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    d = ctypes.byref(enc.desc)
+    nbytes = int(lib.us_hashgrid_bwd_workspace_bytes(d, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    for flags in (1, 3):
+        shape = (n, 32) if flags == 1 else (16, n, 2)
+        ref = torch.empty(shape, device=DEV); out = torch.empty(shape, device=DEV)
+        L.check(lib.us_hashgrid_fwd(d, P(p), P(x), n, P(ref), None, flags, st), "fwd")
+        L.check(lib.us_hashgrid_fwd_counted(d, P(p), P(x), n, P(out), flags, P(ws), nbytes, st), "fwd counted")
+        assert torch.equal(out, ref)
+        dy = torch.randn(shape, device=DEV, generator=g)
+        if flags == 1:
+            dy[::9] = 0.0
+        else:
+            dy[:, ::9] = 0.0
+        g0 = torch.empty(enc.desc.n_params, device=DEV); g1 = torch.full((enc.desc.n_params,), 7.0, device=DEV)
+        ws0 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g0), flags | L.US_GRID_BWD_OVERWRITE, P(ws0), nbytes, st), "bwd")
+        L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g1), flags | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st),
+                "bwd counted")
+        assert torch.allclose(g1, g0, rtol=1e-6, atol=1e-7 * float(g0.abs().max()))

@@ -15,6 +15,7 @@ US_GRID_CLAMP01 = 1
 US_GRID_LEVEL_MAJOR = 2
 US_GRID_BWD_OVERWRITE = 4
 US_GRID_ACCUMULATE = 8
+US_GRID_BWD_COUNTED = 16
 US_MLP_LEVEL_MAJOR = 1
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
@@ -54,6 +55,7 @@ SIGNATURES = {
     "us_hashgrid_bwd_params": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_int, c_f]),
     "us_hashgrid_bwd_workspace_bytes": (ctypes.c_size_t, [_GP, c_i64]),
     "us_hashgrid_bwd_binned": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_fwd_counted": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_hashgrid_bwd_input_gather": (c_int, [_GP, c_f, c_f, c_f, c_i64, c_f, c_int, c_f]),
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),

@@ -62,74 +62,6 @@ extern "C" int us_grid_desc_init(us_grid_desc* d, uint32_t n_levels, uint32_t n_
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-// the 8 vertices of the cell: v[c], c = x + 2y + 4z
-template <int F>
-__device__ __forceinline__ void gather_corners(const LevelGeom& g, const typename Feat<F>::T* __restrict__ grid, const uint32_t cell[3],
-                                               typename Feat<F>::T (&v)[8]) {
-    if constexpr (F == 2) {
-        // Divergent gathers cost one address cycle per lane, whatever their width: fetch the x and x+1 vertices of a
-        // cell edge with ONE 16-byte load where they are neighbours in memory.  Dense levels: always (entries e, e+1).
-        // Hashed levels: the coherent prime hash leaves x unmultiplied, so for even x the two vertices are the aligned
-        // pair {k & ~1, k | 1}; odd x needs a second (8-byte) gather, issued for those lanes only.
-        typedef float pair_t __attribute__((ext_vector_type(4), aligned(8)));
-        const float2* g2 = reinterpret_cast<const float2*>(grid);
-        if (g.hashed) {
-            const uint32_t mask = g.hs - 1u;
-            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
-            const bool odd = cell[0] & 1u;
-            pair_t pr[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                const uint32_t k = (cell[0] ^ h) & mask;
-                pr[q] = *reinterpret_cast<const pair_t*>(g2 + (k & ~1u));
-            }
-            float2 up[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) up[q] = make_float2(0.f, 0.f);
-            if (odd) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                    up[q] = g2[((cell[0] + 1u) ^ h) & mask];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t h = ((q & 1) ? hy0 + 2654435761u : hy0) ^ ((q & 2) ? hz0 + 805459861u : hz0);
-                const bool k_odd = ((cell[0] ^ h) & 1u) != 0u;                  // which half of the pair is vertex x
-                const float2 lo = make_float2(pr[q].x, pr[q].y), hi = make_float2(pr[q].z, pr[q].w);
-                v[2 * q] = k_odd ? hi : lo;
-                v[2 * q + 1] = odd ? up[q] : (k_odd ? lo : hi);
-            }
-        } else {
-            const uint32_t base = cell[0] + cell[1] * g.res + cell[2] * g.res2;
-            uint32_t e[4]; bool wrap = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                e[q] = base + ((q & 1) ? g.res : 0u) + ((q & 2) ? g.res2 : 0u);
-                wrap |= (e[q] >= g.hs - 1u);                   // also catches e = 0xFFFFFFFF (cells of coordinates < 0)
-            }
-            if (!wrap) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const pair_t pr = *reinterpret_cast<const pair_t*>(g2 + e[q]);
-                    v[2 * q] = make_float2(pr.x, pr.y); v[2 * q + 1] = make_float2(pr.z, pr.w);
-                }
-            } else {                                                        // the +1 vertex wraps around the slab (x == 1)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[2 * q] = g2[e[q] % g.hs]; v[2 * q + 1] = g2[(e[q] + 1u) % g.hs];
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)           // 8 independent gathers in flight
-            v[c] = grid[grid_index(g, cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1))];
-    }
-}
-
 template <int F, bool DYDX>
 __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
                                              const float* __restrict__ x, int64_t n, float* __restrict__ out,

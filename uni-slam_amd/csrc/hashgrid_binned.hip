@@ -165,7 +165,9 @@ template <int F, bool WRITE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_levels, uint32_t TB, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
                                                      uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ wg_prefix,
-                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec) {
+                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec, int all_live) {
+    // all_live: every point counts as live whatever its gradient (the counts came from the forward pass, which has no
+    // gradients to look at: us_hashgrid_fwd_counted); a dead sample then emits zero records.
     // lcnt: COUNT pass: records per bin.  WRITE pass: cursor into the workgroup's LDS stage, where the records of one level
     // are collected sorted by bin (counting sort: the exclusive scan of this workgroup's own counts gives every bin's place),
     // each with its final global slot; the copy-out is then one flat, fully occupied loop.
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             default: break;
         }
 #undef US_DY_CASE
-        bool live = false;
+        bool live = all_live && in;
 #pragma unroll
         for (int f = 0; f < F; ++f) live |= (dy[f] != 0.0f);
         const uint32_t lbase = STAGED ? lcnt[q.first] : 0u;      // stage slot 0 of this level, read before anyone adds to it;
@@ -631,7 +633,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     uint32_t* wg_prefix = wg_counts + (size_t)n_wg * BIN_MAX_TOTAL;
     dim3 gridA(n_wg), block(BIN_THREADS);
     const uint32_t L = d->n_levels;
-    const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0;
+    const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0, counted = (flags & US_GRID_BWD_COUNTED) ? 1 : 0;
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #ifdef US_EXP_B_TWICE
@@ -640,16 +642,114 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
 #define US_EXP_TWICE(F)
 #endif
 #define LAUNCH_BIN(F)                                                                                                          \
-    hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
+    if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
     hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
                        (uint32_t)TB, totals, grad_params, overwrite);                                                          \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
-    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec); \
+    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
     hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
                        grad_params, overwrite);                                                                                \
     US_EXP_TWICE(F)
     switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
 #undef LAUNCH_BIN
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
+    return US_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward pass that also produces the counts of the binning (us_hashgrid_fwd_counted): the encoder is bound by its gathers
+// (L2 sector traffic), so the run flags and the 8 LDS counter increments per (point, level) ride along almost for free and
+// the backward pass starts at the column scan.  One 1024-thread workgroup = the 1024 points of one k_bin workgroup x one
+// level; it writes that level's segment of the workgroup's count row.  Every point counts as live (no gradient exists yet).
+// ---------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLevels lv, uint32_t n_levels, const float* __restrict__ params,
+                                                           const float* __restrict__ x, int64_t n, float* __restrict__ out, int clamp,
+                                                           int lm, uint32_t* __restrict__ wg_counts) {
+    __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
+    const uint32_t level = blockIdx.y;
+    const BinLevel q = lv.l[level];
+    const uint32_t nb = 1u << q.lg;
+    for (uint32_t t = threadIdx.x; t < nb; t += BIN_THREADS) lcnt[t] = 0u;
+    __syncthreads();
+    const LevelGeom g = level_geom(tab, level);
+    const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
+    const uint32_t C = n_levels * F;
+    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
+    const bool in = i < n;
+    float pos[3]; uint32_t cell[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos_fract(in ? load_x(x, i, k, clamp) : 0.0f, g.scale, pos[k], cell[k]);
+    if (in) {
+        typename Feat<F>::T v[8];
+        gather_corners<F>(g, grid, cell, v);
+        float res[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) res[f] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float va[F];
+            feat_to_array<F>(v[c], va);
+            const float w = corner_weight(c, pos);
+#pragma unroll
+            for (int f = 0; f < F; ++f) res[f] = fmaf(w, va[f], res[f]);
+        }
+        float* o = out + feat_index(lm, i, n, level, C, F);
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = res[f];
+    }
+    // ---- the counts of k_bin<COUNT> with every point live (same key, same tails, same bins)
+    uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
+    if (!in || !q.packable) key = 0xC0000000u | (uint32_t)lane;
+    const uint32_t knext = dpp_u32<DPP_ROW_SHL1>(key);               // whole wave active here
+    const bool tail = in & ((l8 == 7) | (knext != key));
+    if (tail) {
+        const uint32_t nbm = nb - 1u;
+        if (q.hashed) {
+            const uint32_t hx[2] = {cell[0], cell[0] + 1u};
+            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
+            const uint32_t hy[2] = {hy0, hy0 + 2654435761u}, hz[2] = {hz0, hz0 + 805459861u};
+            const uint32_t mask = q.hs - 1u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) atomicAdd(&lcnt[(((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask) >> BIN_LINE_LOG2) & nbm], 1u);
+        } else {
+            const uint32_t base = cell[0] + __umul24(cell[1], q.res) + __umul24(cell[2], q.res2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t e = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? q.res : 0u) + ((c & 4) ? q.res2 : 0u);
+                atomicAdd(&lcnt[(min(e, e - q.hs) >> BIN_LINE_LOG2) & nbm], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL + q.first;
+    for (uint32_t t = threadIdx.x; t < nb; t += BIN_THREADS) row[t] = lcnt[t];
+}
+
+extern "C" int us_hashgrid_fwd_counted(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out, int flags,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(d, US_ERR_NULL, "us_hashgrid_fwd_counted: desc is NULL");
+    US_REQUIRE(d->n_levels >= 1 && d->n_levels <= US_MAX_LEVELS && (d->n_features == 1 || d->n_features == 2 || d->n_features == 4) &&
+               d->n_params == d->offset[d->n_levels] * d->n_features, US_ERR_CONFIG, "us_hashgrid_fwd_counted: bad descriptor");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params && x && out && workspace, US_ERR_NULL, "us_hashgrid_fwd_counted: NULL pointer");
+    US_REQUIRE(((uintptr_t)params & 15u) == 0 && ((uintptr_t)workspace & 15u) == 0, US_ERR_SHAPE,
+               "us_hashgrid_fwd_counted: params and workspace must be 16-byte aligned");
+    US_REQUIRE(workspace_bytes >= us_hashgrid_bwd_workspace_bytes(d, n), US_ERR_WORKSPACE,
+               "us_hashgrid_fwd_counted: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_bwd_workspace_bytes(d, n));
+    BinMap bm;
+    const int TB = make_binmap(d, n, &bm);
+    US_REQUIRE(TB > 0 && TB <= BIN_MAX_TOTAL, US_ERR_CONFIG, "us_hashgrid_fwd_counted: %d bins > %d", TB, BIN_MAX_TOTAL);
+    const LevelTable t = make_table(d);
+    const BinLevels lv = make_bin_levels(d, bm);
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
+    uint32_t* wg_counts = (uint32_t*)workspace + 2 * (BIN_MAX_TOTAL + 64) + 16 + (((size_t)extra_max(d, n) + 15u) & ~(size_t)15u);
+    dim3 grid((unsigned)us_cdiv(n, BIN_THREADS), d->n_levels), block(BIN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_FC(F) hipLaunchKernelGGL((k_fwd_count<F>), grid, block, 0, s, t, lv, d->n_levels, params, x, n, out, clamp, lm, wg_counts);
+    switch (d->n_features) { case 1: LAUNCH_FC(1) break; case 2: LAUNCH_FC(2) break; default: LAUNCH_FC(4) break; }
+#undef LAUNCH_FC
+    US_CHECK_LAUNCH("us_hashgrid_fwd_counted");
     return US_OK;
 }

@@ -50,6 +50,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
         self._dec_grad_clean = False
+        self.count_in_forward, self._counted = True, False
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
@@ -146,7 +147,7 @@ class MapStep:
                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
         # one scratch set per branch (sdf / colour): the two branches run on two streams
         mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
-        self.ws, self.ws_s = mk_ws(), (mk_ws() if self.overlap else None)
+        self.ws, self.ws_s = mk_ws(), mk_ws()              # the forward pass leaves each branch's binning counts in its own
         self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
                                 int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
@@ -239,10 +240,22 @@ class MapStep:
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
         # the sdf and the colour branch are independent between the sample points and the compositing: two streams
+        # with the binned backward the encoder also leaves the binning counts of these points in the branch's workspace
+        # (us_hashgrid_fwd_counted: the gathers bound the kernel, the counting rides along), and the backward skips its count pass
+        counted = self.ws is not None and self.count_in_forward
+        self._counted = counted
         with self._branch() as st2:
-            self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
+            if counted:
+                self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd_counted(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), 3,
+                                                                                    P(self.ws_s), self.ws_bytes, st2))
+            else:
+                self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
             self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
-        self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
+        if counted:
+            self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd_counted(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), 3,
+                                                                                  P(self.ws), self.ws_bytes, st))
+        else:
+            self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
         self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
         self._join()
         beta = off(fl, self.o_beta)
@@ -292,7 +305,7 @@ class MapStep:
                                                               P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE, P(self.ws_s), self.ws_bytes, q))
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws_s), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
                                                                                   off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
@@ -302,7 +315,7 @@ class MapStep:
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                    3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, q))
+                                                                                    3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
