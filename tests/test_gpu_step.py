@@ -427,3 +427,32 @@ def test_mapstep_ray_gradients_match_autograd(tcnn):
     assert float(g_o[~inside].abs().max()) == 0.0 and float(g_d[~inside].abs().max()) == 0.0
     for a, b in ((g_o, roa.grad), (g_d, rda.grad)):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max())), float((a - b).abs().max() / b.abs().max())
+
+
+def test_mapstep_fixed_beta_tum_config():
+    """configs/TUM_RGBD/tum.yaml:49 `learnable_beta: False`: beta is the python scalar 10 (decoders.py:86-89), no beta gradient."""
+    import unislam_amd as us
+    torch.manual_seed(0)
+    dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06, learnable_beta=False).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(14)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+    assert not isinstance(dec.beta, torch.nn.Parameter) and float(dec.beta) == 10
+    dec2, es2, ec2 = copy.deepcopy(dec), copy.deepcopy(es), copy.deepcopy(ec)
+    R, S = 200, 40
+    ro, rd, gd, gc = _rays(R)
+    t_rand = torch.rand(R, S, device=DEV)
+    rend = us.Renderer(_cfg(False), types.SimpleNamespace(bound=BOUND, device=DEV, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5))
+    opt = torch.optim.Adam([{"params": list(dec2.parameters()), "lr": LR["decoders"]},
+                            {"params": [es2.params], "lr": LR["sdf_grid"]}, {"params": [ec2.params], "lr": LR["color_grid"]}])
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+    for it in range(2):
+        inside = us.common.bbox_filter(ro, rd, gd, BOUND)                   # Mapper.py:396-406
+        ret = rend.render_batch_ray(([es2], [ec2]), dec2, rd[inside], ro[inside], DEV, 0.06, gt_depth=gd[inside], t_rand=t_rand[inside])
+        loss_a = us.mapping_loss(ret, gd[inside], gc[inside], 0.06, W)
+        opt.zero_grad(); loss_a.backward(); opt.step()
+        loss_b = step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+        np.testing.assert_allclose(float(loss_b), float(loss_a.detach()), rtol=5e-5)
+    assert torch.allclose(es.params, es2.params, rtol=1e-3, atol=1e-5) and torch.allclose(ec.params, ec2.params, rtol=1e-3, atol=1e-5)
+    for (n, pa), (_, pb) in zip(dec2.named_parameters(), dec.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-5), n
