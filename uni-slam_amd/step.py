@@ -265,6 +265,7 @@ class MapStep:
                                   P(self.rgb), P(self.unc), None, R, S, self.truncation, P(self.partials), P(self.stats), st),
                 "us_loss_stats")
         self._batch = (o, d, gd, gc, R)
+        self.n_rays = R
         return self.stats
 
     def backward(self, on_ready=None, ray_grads=False):
