@@ -345,7 +345,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
 #ifdef US_EXP_A_NOSTORE
                 if (e.x == 0xFFFFFFF0u)
 #endif
-                *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;
+                *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;     // (non-temporal stores: 127 vs 78 us)
             }
         }
     }
@@ -517,9 +517,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             loc[buf][u] = 0xFFFFFFFFu;
             if (r < r1) {
                 const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
-                loc[buf][u] = src[0];
+                // every record is read exactly once: non-temporal loads keep the stream out of the caches (measured -7 us)
+                loc[buf][u] = __builtin_nontemporal_load(src);
 #pragma unroll
-                for (int f = 0; f < F; ++f) v[buf][u][f] = __uint_as_float(src[1 + f]);
+                for (int f = 0; f < F; ++f) v[buf][u][f] = __uint_as_float(__builtin_nontemporal_load(src + 1 + f));
             }
         }
     };

@@ -557,12 +557,14 @@ __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float*
     const float step_size = sg.step_size[blockIdx.y];
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = o + k;
-        const float gi = g[i];
-        const float mi = m[i] + one_minus_b1 * (gi - m[i]);
-        const float vi = v[i] * b2 + (one_minus_b2 * gi) * gi;
+        // g, m, v are streamed once per step: non-temporal, so that the tables (p), which the next forward gathers from, stay cached
+        const float gi = __builtin_nontemporal_load(g + i);
+        const float m0 = __builtin_nontemporal_load(m + i), v0 = __builtin_nontemporal_load(v + i);
+        const float mi = m0 + one_minus_b1 * (gi - m0);
+        const float vi = v0 * b2 + (one_minus_b2 * gi) * gi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] + (-step_size) * (mi / denom);
-        m[i] = mi; v[i] = vi;
+        __builtin_nontemporal_store(mi, m + i); __builtin_nontemporal_store(vi, v + i);
         if (zero) g[i] = 0.0f;
     }
 }
