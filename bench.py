@@ -269,6 +269,21 @@ def main():
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
                                "avg_launch_ms": kern[dom]}
+        if world == 1 and not args.no_probe:
+            # also the forward-only rate (the render_img / meshing use) and the iteration without Adam
+            step.probe = None
+            def timed(fn, k=max(10, args.steps // 2)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t1) / k
+            fwd_ms = timed(lambda: step.forward(ro, rd, gd, gc, has_zero_depth=False))
+            fb_ms = timed(lambda: step.forward_backward(ro, rd, gd, gc, has_zero_depth=False))
+            rec["extra"] = {"forward_only_ms": fwd_ms, "forward_only_rays_per_s": args.rays / (fwd_ms / 1e3),
+                            "iteration_without_adam_ms": fb_ms}
         if world == 1 and args.mlp_precision == "fp32" and not args.no_probe:
             # the same iteration with bf16 MFMA operands in the two decoders (v_mfma_f32_16x16x32_bf16); not the headline
             st2 = build_step("bf16")[0]
