@@ -98,8 +98,10 @@ def get_samples_all(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws, depths, color
     b, P = depths.shape
     if indices is None:
         indices = torch.randint(P, (n * b,), device=device).reshape(b, -1)
-    if c2ws.requires_grad or not depths.is_cuda:
-        # joint pose optimisation (Mapper.py:372-376): keep the rotation in the autograd graph
+    if not depths.is_cuda:
+        raise L.UniSlamHipError("get_samples_all: the pixel pools must be on the GPU (unislam_amd has no CPU path)")
+    if c2ws.requires_grad:
+        # joint pose optimisation (Mapper.py:372-376): keep the rotation in the autograd graph (torch ops on the GPU)
         sd = torch.gather(depths, 1, indices)
         sc = torch.gather(colors, 1, indices.unsqueeze(-1).expand(-1, -1, 3))
         gi = indices.unsqueeze(-1).expand(-1, -1, 3)
