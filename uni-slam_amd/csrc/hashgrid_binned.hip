@@ -8,20 +8,24 @@
 //   * ds_add_f64 runs at 21 cycles per 64 lanes (9x faster than f32), ds_add_u32 at 7.
 // So each (point, level) is hashed a constant number of times instead of once per slice:
 //   A0 k_bin<COUNT>   every workgroup takes 1024 consecutive points through ALL levels.  Per level, lanes whose neighbours
-//                     (inside aligned groups of 8 lanes = 8 consecutive samples of one ray) sit in the same grid cell are
-//                     RUN-COMBINED with DPP row shifts (segmented inclusive scan of the 8 corner contributions), so a run
-//                     emits one record per corner instead of one per sample.  Records are counted per BIN, where
-//                     bin = entry index mod n_bins(level): interleaving makes bins equally loaded whatever the geometry.
-//                     The counts are kept PER WORKGROUP: row w of a [workgroups][bins] matrix.
-//   scan              column scan over the workgroups + exclusive scan of the bin totals -> every (workgroup, bin) pair owns
-//                     an exact, gap-free record range (no over-allocation, no overflow, no cursor to reserve from).
-//   A1 k_bin<WRITE>   same pass again with the LDS counters preloaded with the workgroup's range starts: an LDS integer
-//                     atomic returns the record's final position, so the pass has no barrier, no global atomic and no
-//                     dependence between levels; it writes {local entry, F values} records.
-//   B  k_bin_accum    one 256-thread workgroup per bin: 32 KiB of f64 accumulators in LDS (thousands of bins, ~5 resident
-//                     workgroups per CU, 8 record loads in flight per thread), ds_add_f64 over the bin's records, then a
-//                     plain (non-atomic) add into the gradient table: a bin owns its entries exclusively.
-// Sums are formed in double precision and in a fixed order of records per bin up to the order of LDS atomics; no global atomics.
+//      (or the        (inside aligned groups of 8 lanes = 8 consecutive samples of one ray) sit in the same grid cell are
+//      encoder,       RUN-COMBINED with DPP row shifts (segmented inclusive scan of the 8 corner contributions), so a run
+//      k_fwd_count)   emits one record per corner instead of one per sample.  Records are counted per BIN; a bin owns every
+//                     n_bins-th 128-byte LINE of the level's gradient slab (interleaving balances the load whatever the
+//                     geometry or the hash does).  The counts are kept PER WORKGROUP: row w of a [workgroups][bins] matrix.
+//   scans             k_bin_colscan: column scan over the workgroups (XCD-major order); k_bin_scan: exclusive scan of the bin
+//                     totals -> every (workgroup, bin) pair owns an exact, gap-free record range (no over-allocation, no
+//                     overflow, no cursor to reserve from) + the list of bins hot enough to be split.
+//   A1 k_bin<WRITE>   same pass with the values.  The records of one level are collected in an LDS stage sorted by bin (the
+//                     scan of the workgroup's own counts seeds the cursors: one ds_add_rtn + one ds_write_b128 per record,
+//                     each already carrying its final global slot) and copied out by a flat loop, consecutive threads
+//                     writing consecutive 12-byte records {local entry, F values}: HBM sees full-line writes.
+//   B  k_bin_accum    one 512-thread workgroup per bin (hot bins: one per 16 384-record chunk): 32 KiB of f64 accumulators
+//                     in LDS, ds_add_f64 over the bin's records (non-temporal loads, 2 x 4 in flight per thread), then
+//                     the bin's lines of the gradient table are written (OVERWRITE), added to, or -- split bins -- added
+//                     with float atomics.
+// Sums are formed in double precision; the only global float atomics are those of split bins.
+// The US_EXP_* macros are measurement hooks of tools/ablate.sh (what a pass costs without its stores, atomics, sweep ...).
 #include "hashgrid_dev.h"
 #include <string.h>
 
