@@ -178,6 +178,8 @@ def main():
                     help="MFMA operand type of the decoders; the headline (parity-tested to 1e-3) is fp32")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="payload type of the gradient all-reduce (N > 1); bf16 halves the xGMI bytes, not bit-faithful to one process")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
@@ -208,7 +210,7 @@ def main():
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
-                        grad_comm=args.grad_comm)
+                        grad_comm=args.grad_comm, sharded_adam=args.sharded_adam)
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)

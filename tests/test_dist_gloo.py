@@ -70,6 +70,88 @@ class OracleEngine:
         return torch.cat([p.detach().reshape(-1) for p in self.params])
 
 
+class ShardedOracleEngine(OracleEngine):
+    """the same engine with flat parameter / moment buffers and adam_step(ranges): what dist._finish_sharded drives"""
+    sharded_adam = True
+
+    def __init__(self):
+        super().__init__()
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.n_pad = (n + 3) // 4 * 4                                  # two announced halves, each divisible by 2 ranks
+        self.flat = torch.zeros(self.n_pad); self.flat[:n] = super().flat()
+        self.m, self.v, self.t = torch.zeros(self.n_pad), torch.zeros(self.n_pad), 0
+        self.lr = torch.zeros(self.n_pad); o = 0
+        for g in self.opt.param_groups:
+            for p in g["params"]:
+                self.lr[o:o + p.numel()] = g["lr"]; o += p.numel()
+
+    def forward(self, *batch):
+        o = 0
+        with torch.no_grad():                                          # parameters <- the (all-gathered) flat buffer
+            for p in self.params:
+                p.copy_(self.flat[o:o + p.numel()].view_as(p)); o += p.numel()
+        super().forward(*batch)
+
+    def backward(self, on_ready=None):
+        loss = super().backward(None)
+        g = torch.zeros(self.n_pad); g[:self.n] = self.grad
+        self.grad = g
+        if on_ready is not None:
+            h = self.n_pad // 2
+            on_ready(self.grad[h:]); on_ready(self.grad[:h])
+        return loss
+
+    def adam_step(self, ranges=None):
+        self.t += 1
+        for (lo, hi) in (ranges or [(0, self.n_pad)]):
+            g = self.grad[lo:hi]
+            self.m[lo:hi] = 0.9 * self.m[lo:hi] + 0.1 * g
+            self.v[lo:hi] = 0.999 * self.v[lo:hi] + 0.001 * g * g
+            denom = (self.v[lo:hi].sqrt() / (1 - 0.999 ** self.t) ** 0.5) + 1e-8
+            self.flat[lo:hi] -= self.lr[lo:hi] / (1 - 0.9 ** self.t) * self.m[lo:hi] / denom
+
+    def flat_params(self):
+        return self.flat[:self.n].clone()
+
+
+def _worker_sharded(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from unislam_amd.dist import dp_iterate, init_from_env
+    init_from_env(backend="gloo")
+    eng = ShardedOracleEngine()
+    losses = []
+    for it in range(3):
+        full = make_batch(48, 100 + it)
+        losses.append(float(dp_iterate(eng, tuple(t[rank::world] for t in full), group=True)))
+    flat = eng.flat_params()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        assert torch.equal(gathered[0], gathered[1])                  # replicas stay bit-identical
+        # the moments of the other rank's shard were never touched
+        h, q = eng.n_pad // 2, eng.n_pad // 4
+        assert float(eng.m[h + q:].abs().max()) == 0.0 and float(eng.m[q:h].abs().max()) == 0.0
+        np.savez(out_path, flat=flat.numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_adam_equal_one_process():
+    """reduce-scatter + Adam on the rank's shard + all-gather (dist._finish_sharded; gloo: all-reduce stands in for the
+    reduce-scatter) gives the parameters of one process with a dense torch.optim.Adam on the concatenated batch"""
+    from unislam_amd.dist import dp_iterate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r0.npz")
+        mp.spawn(_worker_sharded, args=(2, port, out), nprocs=2, join=True)
+        res = np.load(out)
+    eng = OracleEngine()
+    losses = [float(dp_iterate(eng, make_batch(48, 100 + it), group=None)) for it in range(3)]
+    np.testing.assert_allclose(res["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(res["flat"], eng.flat().numpy(), rtol=2e-4, atol=2e-6)
+
+
 def make_batch(R, seed):
     g = torch.Generator().manual_seed(seed)
     ro = torch.tensor([[3.0, 1.2, 0.0]]).repeat(R, 1) + torch.randn(R, 3, generator=g) * 0.05

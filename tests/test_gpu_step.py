@@ -225,15 +225,20 @@ def test_mapstep_single_rank_process_group_matches_plain():
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         outs = []
-        for group in (None, True):
+        for group, kw in ((None, {}), (True, {}), (True, dict(sharded_adam=True)), (True, dict(grad_comm="bf16"))):
             dec, es, ec = _scene(us, False, seed=11)
-            step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=256, group=group)
+            step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=256, group=group, **kw)
             ro, rd, gd, gc = _rays(256, seed=12)
             t_rand = torch.rand(256, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
             for _ in range(3):
                 loss = step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
             outs.append((step.flat.clone(), float(loss)))
         assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6) and abs(outs[0][1] - outs[1][1]) < 1e-5
+        # reduce-scatter + Adam on the rank's shard + all-gather (in place, RCCL): the same parameters
+        assert torch.allclose(outs[0][0], outs[2][0], rtol=1e-5, atol=1e-6) and abs(outs[0][1] - outs[2][1]) < 1e-5
+        # bf16 gradient payload: close, not identical (Adam steps are bounded by lr, a tiny gradient may flip its sign)
+        d = (outs[3][0] - outs[0][0]).norm() / (outs[0][0]).norm()
+        assert float(d) < 2e-2
     finally:
         dist.destroy_process_group()
 

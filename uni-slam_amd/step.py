@@ -29,13 +29,14 @@ from .renderer import zero_depth_z
 from .dist import dp_iterate
 
 
-def _align(n, a=64):
+def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for 1, 2, 4, 8 ... ranks (dist: sharded Adam)
     return (n + a - 1) // a * a
+
 
 
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None):
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -52,6 +53,7 @@ class MapStep:
         self._dec_grad_clean = False
         self.count_in_forward, self._counted = True, False
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
+        self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
@@ -357,17 +359,34 @@ class MapStep:
         R = self.n_rays
         return self.g_o[:R], self.g_d[:R]
 
-    def adam_step(self):
+    def adam_step(self, ranges=None):
+        """
+        torch.optim.Adam over the three param groups (Mapper.py:118-126) in one launch.  ranges: None (everything) or a list of
+        (lo, hi) index ranges of the flat buffer -- the shards this rank owns when the optimiser state is sharded over ranks.
+        """
         lib, st, P = L.lib(), L.stream(), L.ptr
         self.opt_step += 1
         f = self.lr_factor
-        segs = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
-                (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
-        I64, DBL = ctypes.c_int64 * 3, ctypes.c_double * 3
-        L.check(lib.us_adam_step_segments(P(self.flat), P(self.grad), P(self.m), P(self.v), 3, I64(*[g[0] for g in segs]),
-                                          I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, self.opt_step, 0b001, st),
-                "us_adam_step_segments")
-        self._dec_grad_clean = True
+        groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
+                  (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
+        if ranges is None:
+            segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
+            self._dec_grad_clean = True                          # cleared on the way
+        else:
+            segs, zero_mask = [], 0
+            for (lo, hi) in ranges:
+                for (o, n, lr) in groups:
+                    a, b = max(lo, o), min(hi, o + n)
+                    if b > a:
+                        segs.append((a, b - a, lr))
+            self._dec_grad_clean = False
+        if not segs:
+            return
+        k = len(segs)
+        I64, DBL = ctypes.c_int64 * k, ctypes.c_double * k
+        L.check(lib.us_adam_step_segments(P(self.flat), P(self.grad), P(self.m), P(self.v), k, I64(*[g[0] for g in segs]),
+                                          I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, self.opt_step,
+                                          zero_mask, st), "us_adam_step_segments")
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
