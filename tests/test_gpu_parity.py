@@ -808,3 +808,39 @@ def test_forward_counted_feeds_the_binned_backward(us, log2T, n):
         L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g1), flags | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st),
                 "bwd counted")
         assert torch.allclose(g1, g0, rtol=1e-6, atol=1e-7 * float(g0.abs().max()))
+
+
+@pytest.mark.parametrize("F,n", [(1, 333), (1, 40000), (4, 333), (4, 40000)])
+def test_binned_backward_other_feature_widths(us, F, n):
+    """the binned table gradient for F = 1 (staged records with one value) and F = 4 (records stored straight from the lanes),
+    ray-ordered points so that runs get combined; also the counting forward pass for these widths"""
+    import ctypes
+    from unislam_amd import _lib as L
+    rng = np.random.default_rng(F * 100 + n % 97)
+    R = n // 40 + 1
+    o = rng.random((R, 1, 3), dtype=np.float32) * 0.8 + 0.1
+    dirs = (rng.standard_normal((R, 1, 3)) * 0.15).astype(np.float32)
+    x = np.clip((o + dirs * np.linspace(0, 1, 40, dtype=np.float32).reshape(1, 40, 1)).reshape(-1, 3)[:n], 0, 1).astype(np.float32)
+    e = us.HashGridEncoding(3, enc_cfg(12, res=300, L=8, F=F)).to(DEV)
+    d = O.make_grid_desc(8, F, 12, 16, O.per_level_scale(300))
+    p = rng.standard_normal(d.n_params).astype(np.float32)
+    with torch.no_grad():
+        e.params.copy_(T(p))
+    dy = rng.standard_normal((n, 8 * F)).astype(np.float32)
+    dy[::11] = 0.0
+    gp = O.hashgrid_bwd_params(d, x, dy)
+    xd, dyd, pd = T(x).to(DEV), T(dy).to(DEV), e.params.detach()
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    dd = ctypes.byref(e.desc)
+    nbytes = int(lib.us_hashgrid_bwd_workspace_bytes(dd, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    g = torch.full((d.n_params,), 3.0, device=DEV)
+    L.check(lib.us_hashgrid_bwd_binned(dd, P(xd), P(dyd), n, P(g), L.US_GRID_BWD_OVERWRITE, P(ws), nbytes, st), "binned")
+    np.testing.assert_allclose(g.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * np.abs(gp).max())
+    out = torch.empty((n, 8 * F), device=DEV); ref = torch.empty((n, 8 * F), device=DEV)
+    L.check(lib.us_hashgrid_fwd(dd, P(pd), P(xd), n, P(ref), None, 0, st), "fwd")
+    L.check(lib.us_hashgrid_fwd_counted(dd, P(pd), P(xd), n, P(out), 0, P(ws), nbytes, st), "fwd counted")
+    assert torch.equal(out, ref)
+    g2 = torch.full((d.n_params,), -1.0, device=DEV)
+    L.check(lib.us_hashgrid_bwd_binned(dd, P(xd), P(dyd), n, P(g2), L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st), "counted")
+    np.testing.assert_allclose(g2.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * np.abs(gp).max())
