@@ -265,28 +265,41 @@ __device__ __forceinline__ void bias_acc(v4f (&db)[MT], const v4f (&dh)[NQ][MT])
 // to its row of a partials workspace (plain stores; k_mlp_reduce sums the rows in a fixed order) or, without a
 // workspace, to the gradient with ONE atomic per parameter per workgroup.
 template <int MO, int MI>
-__device__ __forceinline__ void stage_wgrad(float* stage, int poff, int K, const v4f (&acc)[MO][MI], int row, int g, bool first) {
+__device__ __forceinline__ void stage_wgrad(float* stage, int poff, int K, const v4f (&acc)[MO][MI], int row, int g) {
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* d = stage + poff + (16 * mo + 4 * g + r) * K + 16 * mi + row;
-                *d = first ? acc[mo][mi][r] : *d + acc[mo][mi][r];
-            }
+            for (int r = 0; r < 4; ++r) stage[poff + (16 * mo + 4 * g + r) * K + 16 * mi + row] = acc[mo][mi][r];
 }
 
 template <int MT>
-__device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT], int row, int g, bool first) {
+__device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT], int row, int g) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = db[m][r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (row == 0) { float* d = stage + poff + 16 * m + 4 * g + r; *d = first ? v : *d + v; }
+            if (row == 0) stage[poff + 16 * m + 4 * g + r] = v;
         }
+}
+
+// End of the backward kernels: the WAVES waves of a workgroup hold one set of weight-gradient tiles each.  Every wave stores
+// its set into its OWN region of LDS (plain, independent stores -- the serial "wave w adds into one image" form spent 24 us
+// in dependent LDS read-modify-writes), then all threads sum the regions in wave order (fixed order: reproducible).
+template <int WAVES, int NP>
+__device__ __forceinline__ void sum_wave_regions(const float* stage, int np, int threads, float* __restrict__ grad_params,
+                                                 float* __restrict__ partials) {
+    constexpr int NPP = (NP + 3) / 4 * 4;
+    for (int k = threadIdx.x; k < np; k += threads) {
+        float v = stage[k];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += stage[w * NPP + k];
+        if (partials) partials[(size_t)blockIdx.x * np + k] = v;
+        else if (v != 0.0f) atomicAdd(grad_params + k, v);
+    }
 }
 
 // sum of the per-workgroup partial rows, fixed order -> bitwise reproducible decoder gradients.
@@ -446,29 +459,23 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
             }
         }
     }
+#ifdef US_EXP_MLP_NOEPI
+    if (grad_params && n == -12345) {
+#else
     if (grad_params) {
-        constexpr int NP = C::N_W + C::N_B;
-        static_assert(NP <= WAVES * C::SCR_PER_WAVE, "staging area");
-        float* stage = lds + C::L_SCR;                            // the scratch images are dead now
-        for (int w = 0; w < WAVES; ++w) {
-            __syncthreads();
-            if (wave == w) {
-                const bool first = (w == 0);
-                stage_wgrad<C::MT, C::KB_IN>(stage, C::P_W0, NIN, gW0, row, g, first);
-                if (NHID == 2) stage_wgrad<C::MT, C::MT>(stage, C::P_WH, WIDTH, gWH, row, g, first);
-                stage_wgrad<1, C::MT>(stage, C::P_WL, WIDTH, gWL, row, g, first);
-                stage_bgrad<C::MT>(stage, C::P_B0, gB0, row, g, first);
-                if (NHID == 2) stage_bgrad<C::MT>(stage, C::P_BH, gBH, row, g, first);
-                stage_bgrad<1>(stage, C::P_BL, gBL, row, g, first);
-            }
-        }
+#endif
+        constexpr int NP = C::N_W + C::N_B, NPP = (NP + 3) / 4 * 4;
+        static_assert(WAVES * NPP <= C::L_TOTAL_BWD, "staging area");
+        __syncthreads();                                           // weights and scratch images are dead now: the whole LDS is stage
+        float* stage = lds + wave * NPP;
+        stage_wgrad<C::MT, C::KB_IN>(stage, C::P_W0, NIN, gW0, row, g);
+        if (NHID == 2) stage_wgrad<C::MT, C::MT>(stage, C::P_WH, WIDTH, gWH, row, g);
+        stage_wgrad<1, C::MT>(stage, C::P_WL, WIDTH, gWL, row, g);
+        stage_bgrad<C::MT>(stage, C::P_B0, gB0, row, g);
+        if (NHID == 2) stage_bgrad<C::MT>(stage, C::P_BH, gBH, row, g);
+        stage_bgrad<1>(stage, C::P_BL, gBL, row, g);
         __syncthreads();
-        const int np = has_bias ? NP : C::N_W;
-        if (partials) {
-            for (int k = threadIdx.x; k < np; k += THREADS) partials[(size_t)blockIdx.x * np + k] = stage[k];
-        } else {
-            for (int k = threadIdx.x; k < np; k += THREADS) { const float v = stage[k]; if (v != 0.0f) atomicAdd(grad_params + k, v); }
-        }
+        sum_wave_regions<WAVES, NP>(lds, has_bias ? NP : C::N_W, THREADS, grad_params, partials);
     }
 }
 
@@ -556,7 +563,11 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     else MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                       dout_stride, n, dL_din, grad_params, lm, partials);
     US_CHECK_LAUNCH("us_mlp_bwd");
+#ifdef US_EXP_MLP_NOEPI
+    if (partials && n == -12345) {
+#else
     if (partials) {
+#endif
         const int np = (int)us_mlp_n_params(d);
         hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, s, partials, (int)nb, np, grad_params);
         US_CHECK_LAUNCH("us_mlp_bwd(reduce)");
