@@ -4,7 +4,7 @@ import torch
 import unislam_amd as us
 from unislam_amd import _lib as L
 DEV = "cuda:0"
-n = 262144
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 for width, nh, prec in [(w, h, pr) for (w, h) in [(32, 2), (16, 2), (16, 1), (64, 2)] for pr in ("fp32", "bf16")]:
     desc = us.make_mlp_desc(32, width, nh, 3, "sigmoid", True, prec)
     p = torch.randn(us.network.mlp_n_params(desc), device=DEV) * 0.3

@@ -250,8 +250,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         bool live = all_live && in;
 #pragma unroll
         for (int f = 0; f < F; ++f) live |= (dy[f] != 0.0f);
-        const uint32_t lbase = STAGED ? lcnt[q.first] : 0u;      // stage slot 0 of this level, read before anyone adds to it;
-        if (STAGED) lds_barrier();                               // the barrier also ends the previous level's copy-out
+        const uint32_t lbase = STAGED ? lcnt[q.first] : 0u;      // stage slot 0 of this level, read before anyone adds to it
+        // The level's arithmetic (cells, indices, products, run scan) runs BEFORE the barrier that ends the previous level's
+        // copy-out: the VALU phase of one wave overlaps the store phase of the others.
+        uint32_t idx[8];
+        float val[8][F];
+        bool tail = false;
         if (__ballot(live) != 0ull) {                            // a wave whose samples all have zero gradient skips the level
         // ---- cell and position
         float pos[3]; uint32_t cell[3];
@@ -262,9 +266,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         if (!live || !q.packable) key = 0xC0000000u | (uint32_t)lane;   // never equals a packed cell, unique per lane
         const uint32_t kprev = dpp_u32<DPP_ROW_SHR(1)>(key), knext = dpp_u32<DPP_ROW_SHL1>(key);
         bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
-        const bool tail = live & ((l8 == 7) | (knext != key));
+        tail = live & ((l8 == 7) | (knext != key));
         // ---- entry indices
-        uint32_t idx[8];
         if (q.hashed) {                                          // wave-uniform
             const uint32_t hx[2] = {cell[0], cell[0] + 1u};
             const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
@@ -281,7 +284,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             }
         }
         // ---- corner products and their segmented scan (only the writing pass needs the values)
-        float val[8][F];
         if (WRITE) {
             const float a0[2] = {1.0f - pos[0], pos[0]}, a1[2] = {1.0f - pos[1], pos[1]}, a2[2] = {1.0f - pos[2], pos[2]};
             float wxy[4];
@@ -307,33 +309,48 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             US_SCAN_STEP(4)
 #undef US_SCAN_STEP
         }
+        }   // wave has live samples
+        if (STAGED) lds_barrier();                               // the previous level's copy-out has left the stage
         // ---- emit: every corner of every live run tail (a corner whose weight is exactly 0 becomes a zero record, so the
         //      counted ranges are exact)
         if (tail) {
             const uint32_t nbm = (1u << q.lg) - 1u;
+            if (STAGED) {
+                // all 8 cursor atomics (and the bins' slot offsets) are in flight before the first record is staged: one LDS
+                // round trip per level instead of eight
+                uint32_t cur[8], gd[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
-                if (STAGED) {
-                    const uint32_t cur = atomicAdd(&lcnt[b], 1u);
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
+                    cur[c] = atomicAdd(&lcnt[b], 1u);
+                    gd[c] = gdelta[b];
+                    idx[c] = local_of(idx[c], q.lg);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
                     uint4 e;
-                    e.x = cur + gdelta[b];
-                    e.y = local_of(idx[c], q.lg);
+                    e.x = cur[c] + gd[c];
+                    e.y = idx[c];
                     e.z = __float_as_uint(val[c][0]);
                     e.w = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
-                    st[cur - lbase] = e;
-                } else if (WRITE) {
-                    const uint32_t slot = atomicAdd(&lcnt[b], 1u);
-                    uint32_t* dst = rec + (size_t)slot * RecW<F>::DW;
-                    dst[0] = local_of(idx[c], q.lg);
+                    st[cur[c] - lbase] = e;
+                }
+            } else {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(val[c][f]);
-                } else {
-                    atomicAdd(&lcnt[b], 1u);
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
+                    if (WRITE) {
+                        const uint32_t slot = atomicAdd(&lcnt[b], 1u);
+                        uint32_t* dst = rec + (size_t)slot * RecW<F>::DW;
+                        dst[0] = local_of(idx[c], q.lg);
+#pragma unroll
+                        for (int f = 0; f < F; ++f) dst[1 + f] = __float_as_uint(val[c][f]);
+                    } else {
+                        atomicAdd(&lcnt[b], 1u);
+                    }
                 }
             }
         }
-        }   // wave has live samples
         if (STAGED) {
             // ---- copy the level's records out.  The stage holds them sorted by bin, and inside a bin the global slots are
             //      consecutive, so consecutive threads write consecutive 12-byte records: contiguous runs per bin.
