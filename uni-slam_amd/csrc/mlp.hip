@@ -125,28 +125,38 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     return 1.0f;
 }
 
-// cooperative load of the flat parameter vector into the LDS images
-template <typename C, bool BWD>
+// cooperative load of the flat parameter vector [W0 | WH | WL | biases] into the LDS images.  All of a thread's global loads
+// are issued before the first LDS store (a load -> store -> load ... loop cost ~11 dependent round trips = most of the
+// kernels' fixed 9 us).
+template <typename C, bool BWD, int THREADS>
 __device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ params, bool has_bias) {
     constexpr int NIN = C::N_IN, WIDTH = C::W, NHID = C::NH;
-    const int nthr = blockDim.x;
-    for (int i = threadIdx.x; i < WIDTH * NIN; i += nthr) {
-        const int r = i / NIN, c = i % NIN; const float v = params[C::P_W0 + i];
-        lds[C::L_W0 + r * C::S_IN + c] = v;
-        if (BWD) lds[C::L_W0T + c * C::S_W + r] = v;
+    constexpr int NP = C::N_W + C::N_B, PER = (NP + THREADS - 1) / THREADS;
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int k = (int)threadIdx.x + j * THREADS;
+        v[j] = (k < C::N_W || (has_bias && k < NP)) ? params[k] : 0.0f;
     }
-    if (NHID == 2)
-        for (int i = threadIdx.x; i < WIDTH * WIDTH; i += nthr) {
-            const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WH + i];
-            lds[C::L_WH + r * C::S_W + c] = v;
-            if (BWD) lds[C::L_WHT + c * C::S_W + r] = v;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int k = (int)threadIdx.x + j * THREADS;
+        if (k < WIDTH * NIN) {
+            const int r = k / NIN, c = k % NIN;
+            lds[C::L_W0 + r * C::S_IN + c] = v[j];
+            if (BWD) lds[C::L_W0T + c * C::S_W + r] = v[j];
+        } else if (NHID == 2 && k < C::P_WL) {
+            const int i = k - C::P_WH, r = i / WIDTH, c = i % WIDTH;
+            lds[C::L_WH + r * C::S_W + c] = v[j];
+            if (BWD) lds[C::L_WHT + c * C::S_W + r] = v[j];
+        } else if (k < C::N_W) {
+            const int i = k - C::P_WL, r = i / WIDTH, c = i % WIDTH;
+            lds[C::L_WL + r * C::S_W + c] = v[j];
+            if (BWD) lds[C::L_WLT + c * C::S_O + r] = v[j];
+        } else if (k < NP) {
+            lds[C::L_B + (k - C::N_W)] = v[j];
         }
-    for (int i = threadIdx.x; i < 16 * WIDTH; i += nthr) {
-        const int r = i / WIDTH, c = i % WIDTH; const float v = params[C::P_WL + i];
-        lds[C::L_WL + r * C::S_W + c] = v;
-        if (BWD) lds[C::L_WLT + c * C::S_O + r] = v;
     }
-    for (int i = threadIdx.x; i < C::N_B; i += nthr) lds[C::L_B + i] = has_bias ? params[C::P_B0 + i] : 0.0f;
 }
 
 // input features of 64 points as B operands: xb[q][b][c] = in[p(q)][16b + 4g + c]
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_FWD_END];
-    load_weights<C, false>(lds, params, has_bias != 0);
+    load_weights<C, false, MLP_THREADS>(lds, params, has_bias != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
     const float* bias = lds + C::L_B;
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
     static_assert(C::L_TOTAL_BWD <= 40960, "MLP backward exceeds 160 KiB of LDS");
     constexpr int NQ = C::NQ, PTS = C::PTS, WAVES = C::WAVES, THREADS = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
-    load_weights<C, true>(lds, params, has_bias != 0);
+    load_weights<C, true, THREADS>(lds, params, has_bias != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
     const float* bias = lds + C::L_B;
