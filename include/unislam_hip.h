@@ -100,6 +100,9 @@ int us_hashgrid_bwd_params(const us_grid_desc* desc_host, const float* x, const 
  * provided workspace of us_hashgrid_bwd_workspace_bytes(desc, n) bytes (scratch: contents undefined afterwards).
  * This is the path MapStep uses for the 4096 x 64 mapping batch. */
 size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* desc_host, int64_t n);
+/* 1 if us_hashgrid_bwd_binned takes this table and batch (bin budget: 4096 bins of <= 2048 entries; 32-bit record offsets:
+ * n * 8 * L * 12 B < 4 GiB), else 0 -- then us_hashgrid_bwd_params serves */
+int us_hashgrid_bwd_binned_supported(const us_grid_desc* desc_host, int64_t n);
 int us_hashgrid_bwd_binned(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
                            float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -844,3 +844,20 @@ def test_binned_backward_other_feature_widths(us, F, n):
     g2 = torch.full((d.n_params,), -1.0, device=DEV)
     L.check(lib.us_hashgrid_bwd_binned(dd, P(xd), P(dyd), n, P(g2), L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st), "counted")
     np.testing.assert_allclose(g2.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * np.abs(gp).max())
+
+
+def test_backward_of_a_table_beyond_the_bin_budget_falls_back(us):
+    """log2T = 22: more than 4096 bins of 2048 entries -> us_hashgrid_bwd_binned answers US_ERR_CONFIG and the module's automatic
+    mode takes the sliced kernels; the gradient still satisfies the adjoint identity"""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    n = 20000
+    enc = us.HashGridEncoding(3, enc_cfg(22)).to(DEV)
+    with torch.no_grad():
+        enc.params.copy_(torch.randn(enc.params.shape, device=DEV, generator=g) * 0.1)
+    x = torch.rand((n, 3), device=DEV, generator=g)
+    dy = torch.randn((n, 32), device=DEV, generator=g)
+    out = enc(x)
+    out.backward(dy)
+    lhs = (dy.double() * out.detach().double()).sum()
+    rhs = (enc.params.grad.double() * enc.params.detach().double()).sum()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2

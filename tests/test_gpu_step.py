@@ -461,3 +461,17 @@ def test_mapstep_fixed_beta_tum_config():
     assert torch.allclose(es.params, es2.params, rtol=1e-3, atol=1e-5) and torch.allclose(ec.params, ec2.params, rtol=1e-3, atol=1e-5)
     for (n, pa), (_, pb) in zip(dec2.named_parameters(), dec.named_parameters()):
         assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-5), n
+
+
+def test_mapstep_with_a_table_beyond_the_bin_budget():
+    """a colour table of 2^22 entries per level does not fit the binned backward's 4096 bins: MapStep falls back to the sliced
+    kernels by itself and still optimises"""
+    import unislam_amd as us
+    torch.manual_seed(0)
+    dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(22)).to(DEV)
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=1024)
+    assert step.bwd_mode == 1 and step.ws is None
+    ro, rd, gd, gc = _rays(1024, seed=3)
+    losses = [float(step.iterate(ro, rd, gd, gc, has_zero_depth=False)) for _ in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

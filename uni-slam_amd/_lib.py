@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunislam_hip.so")
 US_MAX_LEVELS = 32
+US_ERR_CONFIG = -3          # unislam_hip.h: unsupported descriptor / configuration
 US_GRID_CLAMP01 = 1
 US_GRID_LEVEL_MAJOR = 2
 US_GRID_BWD_OVERWRITE = 4
@@ -54,6 +55,7 @@ SIGNATURES = {
     "us_hashgrid_indices": (c_int, [_GP, c_f, c_i64, c_f, c_int, c_f]),
     "us_hashgrid_bwd_params": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_int, c_f]),
     "us_hashgrid_bwd_workspace_bytes": (ctypes.c_size_t, [_GP, c_i64]),
+    "us_hashgrid_bwd_binned_supported": (c_int, [_GP, c_i64]),
     "us_hashgrid_bwd_binned": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_fwd_counted": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),

@@ -616,6 +616,15 @@ extern "C" size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* d, int64_t
     return header_bytes(d, n) + (size_t)n * 8u * d->n_levels * rec_dwords(d->n_features) * sizeof(uint32_t);
 }
 
+extern "C" int us_hashgrid_bwd_binned_supported(const us_grid_desc* d, int64_t n) {
+    if (!d || n <= 0 || d->n_levels < 1 || d->n_levels > US_MAX_LEVELS) return 0;
+    if (!(d->n_features == 1 || d->n_features == 2 || d->n_features == 4)) return 0;
+    if ((uint64_t)n * 8ull * d->n_levels * rec_dwords(d->n_features) * 4ull > 0xFFFFFFFFull) return 0;
+    BinMap bm;
+    const int TB = make_binmap(d, n, &bm);
+    return (TB > 0 && TB <= BIN_MAX_TOTAL) ? 1 : 0;
+}
+
 extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
                                       int flags, void* workspace, size_t workspace_bytes, void* stream) {
     US_REQUIRE(d, US_ERR_NULL, "us_hashgrid_bwd_binned: desc is NULL");

@@ -71,10 +71,14 @@ class _HashGridFn(torch.autograd.Function):
                 # bin once, accumulate in f64 (csrc/hashgrid_binned.hip); scratch comes from torch's caching allocator
                 nbytes = int(L.lib().us_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), n))
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-                L.check(L.lib().us_hashgrid_bwd_binned(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp),
-                                                       ctx.flags | L.US_GRID_BWD_OVERWRITE, L.ptr(ws), nbytes, L.stream()),
-                        "us_hashgrid_bwd_binned")
-            else:
+                rc = L.lib().us_hashgrid_bwd_binned(ctypes.byref(desc), L.ptr(x), L.ptr(dy), n, L.ptr(gp),
+                                                    ctx.flags | L.US_GRID_BWD_OVERWRITE, L.ptr(ws), nbytes, L.stream())
+                if rc == L.US_ERR_CONFIG and mode == -1:
+                    binned = False          # a table too large for the bin budget: the sliced kernels take any size
+                    gp.zero_()
+                else:
+                    L.check(rc, "us_hashgrid_bwd_binned")
+            if not binned:
                 # the sliced kernel streams one level at a time: hand it level-major planes [L][N][F]
                 dy_lm = dy.view(n, desc.n_levels, desc.n_features).permute(1, 0, 2).contiguous()
                 L.check(L.lib().us_hashgrid_bwd_params(ctypes.byref(desc), L.ptr(x), L.ptr(dy_lm), n, L.ptr(gp), mode,

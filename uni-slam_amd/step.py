@@ -147,6 +147,9 @@ class MapStep:
         lib = L.lib()
         self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
+        if self.bwd_mode == -1 and not (lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.es.desc), N) and
+                                        lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.ec.desc), N)):
+            self.bwd_mode = 1               # a table / batch beyond the binned path's budget: LDS-sliced kernels
         # one scratch set per branch (sdf / colour): the two branches run on two streams
         mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
         self.ws, self.ws_s = mk_ws(), mk_ws()              # the forward pass leaves each branch's binning counts in its own
