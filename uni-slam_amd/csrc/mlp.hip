@@ -233,6 +233,9 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict
 template <int NQ, int MT>
 __device__ __forceinline__ void scratch_store(float* buf, const v4f (&t)[NQ][MT], int row, int g) {
     constexpr int SCR_STRIDE = 16 * NQ + 4;
+#ifdef US_EXP_MLP_NOSCRATCH
+    if (row != 12345) return;
+#endif
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
