@@ -181,11 +181,12 @@ int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bo
 /* us_bbox_filter + us_sample_z + us_ray_points in ONE launch, value for value (the iteration of src/Mapper.py:396-406 +
  * src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  perturb != 0: jitter with t_rand[R][S], or,
  * when t_rand is NULL, with an in-kernel counter-based uniform generator seeded by rng_seed (the reference draws
- * torch.rand there, Renderer.py:54; any iid U[0,1) stream serves).  valid may be NULL. */
+ * torch.rand there, Renderer.py:54; any iid U[0,1) stream serves); rng_counter (device float[1], may be NULL) is mixed into
+ * the seed on the device, so that replays of a captured hipGraph draw fresh numbers.  valid may be NULL. */
 int us_sample_points(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
                      int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf, int n_imp, float c_free,
-                     float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, int perturb,
-                     int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream);
+                     float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, const float* rng_counter,
+                     int perturb, int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream);
 
 /* bounding-box pre-filter (Mapper.py:396-402, Tracker.py:177-184): far = min_dim max((lo-o)/d, (hi-o)/d);
  * valid[i] = far >= gt_depth[i] (&& gt_depth[i] > 0 when require_depth); far_out[R] optional (Renderer.py:108-113) */
@@ -235,6 +236,10 @@ int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* 
                  const float* depth, const float* rgb, const float* pixel_unc, const float* median,
                  int64_t n_rays, int n_samples, double truncation, const float* w_host5, const float* stats,
                  float* g_sdf, float* g_depth, float* g_rgb, float* loss_out, void* stream);
+
+/* out[0] = lower median (torch.median) of |a[i] - b[i]| over the elements with valid[i] != 0 (valid NULL: all); +inf if none.
+ * n <= 8192.  The 10 x median gate of the tracking loss: src/Tracker.py:212-214. */
+int us_masked_median(const float* a, const float* b, const uint8_t* valid, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser  (replaces torch.optim.Adam at src/Mapper.py:364,445 / src/Tracker.py:328,242)

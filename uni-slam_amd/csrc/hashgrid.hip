@@ -322,64 +322,93 @@ __global__ __launch_bounds__(256) void k_bwd_input(const float* __restrict__ dL_
     }
 }
 
-// The same without a stored dy_dx: every point re-gathers its 8 vertices per level and forms dy/dx on the fly
-// (what k_fwd<DYDX> writes, value for value, consumed in the same channel order as k_bwd_input).  Saves the [N][C][3]
-// tensor (100 MB per grid at 4096 x 64) at the price of a second gather pass.
+// The same without a stored dy_dx: every (point, level) gathers its 8 vertices again and forms dy/dx on the fly (what
+// k_fwd<DYDX> writes, value for value).  Saves the [N][C][3] tensor (100 MB per grid at 4096 x 64) at the price of a second
+// gather pass.  Parallel over levels like the encoder: a 1024-thread workgroup = 64 points x 16 levels (wave = level), the 16
+// per-level contributions of a point are summed through LDS in level order.
 template <int F>
-__global__ __launch_bounds__(256) void k_bwd_input_gather(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
-                                                          const float* __restrict__ x, const float* __restrict__ dL_dy, int64_t n,
-                                                          float* __restrict__ dL_dx, int clamp, int lm, int accumulate) {
+__device__ __forceinline__ void input_grad_level(const LevelTable& tab, uint32_t level, uint32_t n_levels, const float* __restrict__ params,
+                                                 const float xv[3], const bool pass[3], const float* __restrict__ dL_dy, int64_t i, int64_t n,
+                                                 int lm, float r[3]) {
     const uint32_t C = n_levels * F;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float xin[3], xv[3], r[3] = {0.f, 0.f, 0.f};
-        bool pass[3];
+    const LevelGeom g = level_geom(tab, level);
+    const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
+    float pos[3]; uint32_t cell[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos_fract(xv[k], g.scale, pos[k], cell[k]);
+    typename Feat<F>::T v[8];
+    gather_corners<F>(g, grid, cell, v);
+    float va[8][F], dy[F];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) feat_to_array<F>(v[c], va[c]);
+#pragma unroll
+    for (int f = 0; f < F; ++f) dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f];
+    float d[F][3];
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+        float acc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+        const int d0 = gd == 0 ? 1 : 0, d1 = gd == 2 ? 1 : 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float w = g.scale;
+            w *= (q & 1) ? pos[d0] : 1.0f - pos[d0];
+            w *= (q & 2) ? pos[d1] : 1.0f - pos[d1];
+            const int cl = ((q & 1) << d0) | (((q >> 1) & 1) << d1);
+            const int cr = cl | (1 << gd);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += w * (va[cr][f] - va[cl][f]);
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) d[f][gd] = pass[gd] ? acc[f] : 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) r[gd] += dy[f] * d[f][gd];
+    }
+}
+
+#define IG_POINTS 64
+#define IG_LEVELS 16
+template <int F>
+__global__ __launch_bounds__(IG_POINTS * IG_LEVELS) void k_bwd_input_gather(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
+                                                                            const float* __restrict__ x, const float* __restrict__ dL_dy,
+                                                                            int64_t n, float* __restrict__ dL_dx, int clamp, int lm,
+                                                                            int accumulate) {
+    __shared__ float part[IG_LEVELS][3][IG_POINTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * IG_POINTS + lane;
+    const bool in = i < n;
+    float xv[3] = {0.f, 0.f, 0.f}, total[3] = {0.f, 0.f, 0.f};
+    bool pass[3] = {true, true, true};
+    if (in) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            xin[k] = x[i * 3 + k];
-            xv[k] = clamp ? fminf(fmaxf(xin[k], 0.0f), 1.0f) : xin[k];
-            pass[k] = !clamp || (xin[k] >= 0.0f && xin[k] <= 1.0f);
+            const float xin = x[i * 3 + k];
+            xv[k] = clamp ? fminf(fmaxf(xin, 0.0f), 1.0f) : xin;
+            pass[k] = !clamp || (xin >= 0.0f && xin <= 1.0f);
         }
-        for (uint32_t level = 0; level < n_levels; ++level) {
-            const LevelGeom g = level_geom(tab, level);
-            const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
-            float pos[3]; uint32_t cell[3];
+    }
+    for (uint32_t l0 = 0; l0 < n_levels; l0 += IG_LEVELS) {
+        const uint32_t level = l0 + (uint32_t)wave;                // wave-uniform
+        float r[3] = {0.f, 0.f, 0.f};
+        if (in && level < n_levels) input_grad_level<F>(tab, level, n_levels, params, xv, pass, dL_dy, i, n, lm, r);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pos_fract(xv[k], g.scale, pos[k], cell[k]);
-            typename Feat<F>::T v[8];
-            gather_corners<F>(g, grid, cell, v);
-            float va[8][F], dy[F];
+        for (int k = 0; k < 3; ++k) part[wave][k][lane] = r[k];
+        __syncthreads();
+        if (wave == 0) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) feat_to_array<F>(v[c], va[c]);
+            for (int w = 0; w < IG_LEVELS; ++w)
 #pragma unroll
-            for (int f = 0; f < F; ++f) dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f];
-            float d[F][3];
-#pragma unroll
-            for (int gd = 0; gd < 3; ++gd) {
-                float acc[F];
-#pragma unroll
-                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
-                const int d0 = gd == 0 ? 1 : 0, d1 = gd == 2 ? 1 : 2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float w = g.scale;
-                    w *= (q & 1) ? pos[d0] : 1.0f - pos[d0];
-                    w *= (q & 2) ? pos[d1] : 1.0f - pos[d1];
-                    const int cl = ((q & 1) << d0) | (((q >> 1) & 1) << d1);
-                    const int cr = cl | (1 << gd);
-#pragma unroll
-                    for (int f = 0; f < F; ++f) acc[f] += w * (va[cr][f] - va[cl][f]);
-                }
-#pragma unroll
-                for (int f = 0; f < F; ++f) d[f][gd] = pass[gd] ? acc[f] : 0.0f;
-            }
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-#pragma unroll
-                for (int gd = 0; gd < 3; ++gd) r[gd] += dy[f] * d[f][gd];
-            }
+                for (int k = 0; k < 3; ++k) total[k] += part[w][k][lane];
         }
+        __syncthreads();
+    }
+    if (wave == 0 && in) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dx[i * 3 + k] = accumulate ? dL_dx[i * 3 + k] + r[k] : r[k];
+        for (int k = 0; k < 3; ++k) dL_dx[i * 3 + k] = accumulate ? dL_dx[i * 3 + k] + total[k] : total[k];
     }
 }
 
@@ -509,7 +538,7 @@ extern "C" int us_hashgrid_bwd_input_gather(const us_grid_desc* d, const float* 
     US_REQUIRE(((uintptr_t)params & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_bwd_input_gather: params must be 16-byte aligned");
     const LevelTable t = make_table(d);
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0, acc = (flags & US_GRID_ACCUMULATE) ? 1 : 0;
-    dim3 grid(point_blocks(n, 256, 1 << 20)), block(256);
+    dim3 grid((unsigned)us_cdiv(n, IG_POINTS)), block(IG_POINTS * IG_LEVELS);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_BIG(F) hipLaunchKernelGGL((k_bwd_input_gather<F>), grid, block, 0, s, t, d->n_levels, params, x, dL_dy, n, dL_dx, clamp, lm, acc);
     switch (d->n_features) { case 1: LAUNCH_BIG(1) break; case 2: LAUNCH_BIG(2) break; default: LAUNCH_BIG(4) break; }

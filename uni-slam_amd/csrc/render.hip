@@ -160,9 +160,13 @@ __global__ __launch_bounds__(256) void k_sample_points(const float* __restrict__
                                                        const float* __restrict__ t_uni, int n_strat,
                                                        const float* __restrict__ t_surf, int n_imp, float c_free,
                                                        float surf_off, float surf_span, const float* __restrict__ t_rand,
-                                                       unsigned long long seed, int perturb, int require_depth,
+                                                       unsigned long long seed, const float* __restrict__ rng_counter,
+                                                       int perturb, int require_depth,
                                                        uint8_t* __restrict__ valid, float* __restrict__ z_vals,
                                                        float* __restrict__ pts, int rays_per_block) {
+    // a device-side counter (e.g. the optimiser's step count) varies the stream between replays of a captured hipGraph,
+    // where the host-side seed is frozen into the launch
+    if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
     extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
     const int S = n_strat + n_imp;
     const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
@@ -531,6 +535,46 @@ __global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Lower median of |a - b| over the flagged elements (Tracker.py:212-214: depth_error.median() of the rays that passed the
+// pre-filter; torch.median returns the lower of the two middle values).  One workgroup, bitonic sort in LDS, flagged-out
+// elements sort to the end as +inf; no element flagged -> +inf.  n <= MEDIAN_MAX.
+// ---------------------------------------------------------------------------------------------------------------
+#define MEDIAN_MAX 8192
+__global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const uint8_t* __restrict__ valid, int n, int P, float* __restrict__ out) {
+    __shared__ float v[MEDIAN_MAX];
+    __shared__ int cnt_sh;
+    if (threadIdx.x == 0) cnt_sh = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = threadIdx.x; i < P; i += 1024) {
+        float e = INFINITY;
+        if (i < n && (!valid || valid[i])) { e = fabsf(a[i] - b[i]); ++local; }
+        v[i] = e;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&cnt_sh, local);
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float x = v[i], y = v[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { v[i] = y; v[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        const int c = cnt_sh;
+        out[0] = c > 0 ? v[(c - 1) >> 1] : INFINITY;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam op order: lerp, mul+addcmul, sqrt/div/add, addcdiv)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -695,8 +739,8 @@ extern "C" int us_sample_z(const float* gt_depth, int64_t n_rays, const float* t
 
 extern "C" int us_sample_points(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound_host,
                                 int64_t n_rays, const float* t_uni, int n_strat, const float* t_surf, int n_imp, float c_free,
-                                float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, int perturb,
-                                int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream) {
+                                float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, const float* rng_counter,
+                                int perturb, int require_depth, uint8_t* valid, float* z_vals, float* pts, void* stream) {
     if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(rays_o && rays_d && gt_depth && bound_host && t_uni && t_surf && z_vals && pts, US_ERR_NULL, "us_sample_points: NULL pointer");
     const int S = n_strat + n_imp;
@@ -706,7 +750,7 @@ extern "C" int us_sample_points(const float* rays_o, const float* rays_d, const 
     const int rpb = 256 / S;
     hipLaunchKernelGGL(k_sample_points, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float),
                        (hipStream_t)stream, rays_o, rays_d, gt_depth, bd, n_rays, t_uni, n_strat, t_surf, n_imp, c_free, surf_off,
-                       surf_span, t_rand, (unsigned long long)rng_seed, perturb, require_depth, valid, z_vals, pts, rpb);
+                       surf_span, t_rand, (unsigned long long)rng_seed, rng_counter, perturb, require_depth, valid, z_vals, pts, rpb);
     US_CHECK_LAUNCH("us_sample_points");
     return US_OK;
 }
@@ -840,6 +884,16 @@ extern "C" int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, cons
                        gt_depth, gt_color, depth, rgb, pixel_unc, median, n_rays, n_samples, (float)truncation,
                        (float)(0.4 * truncation), lw, stats, g_sdf, g_depth, g_rgb, loss_out);
     US_CHECK_LAUNCH("us_loss_grad");
+    return US_OK;
+}
+
+extern "C" int us_masked_median(const float* a, const float* b, const uint8_t* valid, int64_t n, float* out, void* stream) {
+    US_REQUIRE(a && b && out, US_ERR_NULL, "us_masked_median: NULL pointer");
+    US_REQUIRE(n >= 0 && n <= MEDIAN_MAX, US_ERR_SHAPE, "us_masked_median: n = %lld not in 0..%d", (long long)n, MEDIAN_MAX);
+    int P = 2;
+    while (P < (int)n) P <<= 1;
+    hipLaunchKernelGGL(k_masked_median, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, valid, (int)n, P, out);
+    US_CHECK_LAUNCH("us_masked_median");
     return US_OK;
 }
 

@@ -227,7 +227,7 @@ class MapStep:
             tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
             self.rng_calls += 1
             L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
-                                         c_free, s_off, s_span, tr, (self.rng_seed + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1),
+                                         c_free, s_off, s_span, tr, (self.rng_seed + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1), None,
                                          1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
         else:
             L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 0, P(self.valid), None, st), "us_bbox_filter")
@@ -472,14 +472,15 @@ class TrackStep:
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
         ts, tc = L.f32(self.es.params.detach()), L.f32(self.ec.params.detach())
-        # Tracker.py:177-184: inside the box AND a depth measurement; kept as flags
-        L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 1, P(self.valid), None, st), "us_bbox_filter")
-        if self.perturb and t_rand is None:
-            t_rand = torch.rand((R, S), device=self.device)
+        # Tracker.py:177-184 (inside the box AND a depth measurement, kept as flags) + Renderer.py:81-101,132-137 in one launch;
+        # jitter from t_rand or from the in-kernel generator (the device-side step count varies it between graph replays)
         tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-        L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2),
-                                ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, P(self.z), st), "us_sample_z")
-        L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
+        self.rng_calls = getattr(self, "rng_calls", 0) + 1
+        seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1)
+        L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
+                                     ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
+                                     P(self.pstep) if hasattr(self, "pstep") else None, 1 if self.perturb else 0, 1, P(self.valid),
+                                     P(self.z), P(self.pts), st), "us_sample_points")
         # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers
         L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
         L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
@@ -491,10 +492,13 @@ class TrackStep:
         if self.mode == 2:
             # Tracker.py:214-215: median of |gt - depth| over the rays that passed the pre-filter (lower median, like
             # torch.median), without compaction: rejected rays sort to the end as +inf
-            valid = self.valid[:R].bool()
-            err = torch.where(valid, (gd - self.depth[:R]).abs(), torch.full_like(gd, float("inf")))
-            k = torch.clamp((valid.sum() - 1) // 2, min=0)
-            self.median.copy_(torch.sort(err)[0].gather(0, k.reshape(1)))
+            if R <= 8192:
+                L.check(lib.us_masked_median(P(gd), P(self.depth), P(self.valid), R, P(self.median), st), "us_masked_median")
+            else:
+                valid = self.valid[:R].bool()
+                err = torch.where(valid, (gd - self.depth[:R]).abs(), torch.full_like(gd, float("inf")))
+                k = torch.clamp((valid.sum() - 1) // 2, min=0)
+                self.median.copy_(torch.sort(err)[0].gather(0, k.reshape(1)))
             med = P(self.median)
         L.check(lib.us_loss_stats(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth), P(self.rgb),
                                   P(self.unc), med, R, S, self.truncation, P(self.partials), P(self.stats), st), "us_loss_stats")
