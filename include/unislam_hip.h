@@ -237,6 +237,11 @@ int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* 
                  int64_t n_rays, int n_samples, double truncation, const float* w_host5, const float* stats,
                  float* g_sdf, float* g_depth, float* g_rgb, float* loss_out, void* stream);
 
+/* the tracker's optimiser step (src/Tracker.py:322-329,242) in one launch: Adam on pose7 = (quaternion[4] with lr_R,
+ * translation[3] with lr_T), us_adam_step_dev arithmetic; step_dev[0] (float) is incremented by the kernel before use */
+int us_pose_adam_step(float* pose7, const float* g7, float* m7, float* v7, double lr_R, double lr_T, double beta1, double beta2,
+                      double eps, float* step_dev, void* stream);
+
 /* out[0] = lower median (torch.median) of |a[i] - b[i]| over the elements with valid[i] != 0 (valid NULL: all); +inf if none.
  * n <= 8192.  The 10 x median gate of the tracking loss: src/Tracker.py:212-214. */
 int us_masked_median(const float* a, const float* b, const uint8_t* valid, int64_t n, float* out, void* stream);

@@ -536,42 +536,58 @@ __global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // Lower median of |a - b| over the flagged elements (Tracker.py:212-214: depth_error.median() of the rays that passed the
-// pre-filter; torch.median returns the lower of the two middle values).  One workgroup, bitonic sort in LDS, flagged-out
-// elements sort to the end as +inf; no element flagged -> +inf.  n <= MEDIAN_MAX.
+// pre-filter; torch.median returns the lower of the two middle values).  One workgroup; no element flagged -> +inf.
+// n <= MEDIAN_MAX.
 // ---------------------------------------------------------------------------------------------------------------
 #define MEDIAN_MAX 8192
+// Radix select on the bit patterns (non-negative floats order like their bits): 4 passes of an 8-bit histogram in LDS.
 __global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict__ a, const float* __restrict__ b,
-                                                        const uint8_t* __restrict__ valid, int n, int P, float* __restrict__ out) {
-    __shared__ float v[MEDIAN_MAX];
-    __shared__ int cnt_sh;
-    if (threadIdx.x == 0) cnt_sh = 0;
+                                                        const uint8_t* __restrict__ valid, int n, float* __restrict__ out) {
+    __shared__ uint32_t key[MEDIAN_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel[3];                                  // count of flagged elements / prefix / remaining rank
+    if (threadIdx.x == 0) sel[0] = 0;
     __syncthreads();
-    int local = 0;
-    for (int i = threadIdx.x; i < P; i += 1024) {
-        float e = INFINITY;
-        if (i < n && (!valid || valid[i])) { e = fabsf(a[i] - b[i]); ++local; }
-        v[i] = e;
+    uint32_t local = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        uint32_t k = 0xFFFFFFFFu;                                // flagged-out elements never enter a histogram
+        if (!valid || valid[i]) { k = __float_as_uint(fabsf(a[i] - b[i])); ++local; }
+        key[i] = k;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&cnt_sh, local);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&sel[0], local);
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const float x = v[i], y = v[p];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { v[i] = y; v[p] = x; }
-                }
-            }
-            __syncthreads();
+    const uint32_t cnt = sel[0];
+    if (cnt == 0) { if (threadIdx.x == 0) out[0] = INFINITY; return; }
+    if (threadIdx.x == 0) { sel[1] = 0; sel[2] = (cnt - 1u) >> 1; }      // lower median: rank (cnt-1)/2, 0-based
+    for (int pass = 3; pass >= 0; --pass) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = sel[1];
+        const int sh = 8 * pass;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t k = key[i];
+            if (k != 0xFFFFFFFFu && (pass == 3 || (k >> (sh + 8)) == prefix)) atomicAdd(&hist[(k >> sh) & 255u], 1u);
         }
+        __syncthreads();
+        if (threadIdx.x < 64) {                                  // one wave: 4 bins per lane, wave scan, pick the bin of the rank
+            const uint32_t rank = sel[2];
+            uint32_t c[4], s4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = hist[4 * threadIdx.x + q]; s4 += c[q]; }
+            uint32_t inc = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += t; }
+            uint32_t run = inc - s4;                             // elements in bins before this lane's four
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (rank >= run && rank < run + c[q]) { sel[1] = (prefix << 8) | (4u * threadIdx.x + q); sel[2] = rank - run; }
+                run += c[q];
+            }
+        }
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int c = cnt_sh;
-        out[0] = c > 0 ? v[(c - 1) >> 1] : INFINITY;
-    }
+    if (threadIdx.x == 0) out[0] = __uint_as_float(sel[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -708,6 +724,27 @@ __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const f
         const float vi = v[i] * b2 + ((1.0f - b2) * gi) * gi;
         const float denom = sqrtf(vi) / bc2s + eps;
         p[i] = p[i] + (-step_size) * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// The tracker's per-iteration optimiser step in one launch (Tracker.py:322-329,242): Adam with betas (0.5, 0.999) on the 7 pose
+// numbers, lr_R for the quaternion and lr_T for the translation, step count on the device and incremented here.
+__global__ __launch_bounds__(64) void k_pose_adam(float* __restrict__ pose, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, float lr_R, float lr_T, float b1, float b2, float eps,
+                                                  float* __restrict__ step_dev) {
+    const float step = step_dev[0] + 1.0f;
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i == 0) step_dev[0] = step;
+    if (i < 7) {
+        const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
+        const float step_size = (i < 4 ? lr_R : lr_T) / bc1;
+        const float gi = g[i];
+        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);
+        const float vi = v[i] * b2 + ((1.0f - b2) * gi) * gi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        pose[i] = pose[i] + (-step_size) * (mi / denom);
         m[i] = mi; v[i] = vi;
     }
 }
@@ -887,12 +924,19 @@ extern "C" int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, cons
     return US_OK;
 }
 
+extern "C" int us_pose_adam_step(float* pose, const float* g, float* m, float* v, double lr_R, double lr_T, double beta1, double beta2,
+                                 double eps, float* step_dev, void* stream) {
+    US_REQUIRE(pose && g && m && v && step_dev, US_ERR_NULL, "us_pose_adam_step: NULL pointer");
+    hipLaunchKernelGGL(k_pose_adam, dim3(1), dim3(64), 0, (hipStream_t)stream, pose, g, m, v, (float)lr_R, (float)lr_T, (float)beta1,
+                       (float)beta2, (float)eps, step_dev);
+    US_CHECK_LAUNCH("us_pose_adam_step");
+    return US_OK;
+}
+
 extern "C" int us_masked_median(const float* a, const float* b, const uint8_t* valid, int64_t n, float* out, void* stream) {
     US_REQUIRE(a && b && out, US_ERR_NULL, "us_masked_median: NULL pointer");
     US_REQUIRE(n >= 0 && n <= MEDIAN_MAX, US_ERR_SHAPE, "us_masked_median: n = %lld not in 0..%d", (long long)n, MEDIAN_MAX);
-    int P = 2;
-    while (P < (int)n) P <<= 1;
-    hipLaunchKernelGGL(k_masked_median, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, valid, (int)n, P, out);
+    hipLaunchKernelGGL(k_masked_median, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, valid, (int)n, out);
     US_CHECK_LAUNCH("us_masked_median");
     return US_OK;
 }

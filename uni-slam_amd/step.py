@@ -586,11 +586,7 @@ class TrackStep:
                                  P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
         loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
         L.check(lib.us_pose_grad(P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.g_pose), st), "us_pose_grad")
-        self.pstep.add_(1.0)
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
         b1, b2 = self.betas
-        L.check(lib.us_adam_step_dev(P(self.pose), P(self.g_pose), P(self.pm), P(self.pv), 4, self.lr_R, b1, b2, 1e-8, P(self.pstep), st),
-                "us_adam_step_dev")
-        L.check(lib.us_adam_step_dev(off(self.pose, 4), off(self.g_pose, 4), off(self.pm, 4), off(self.pv, 4), 3, self.lr_T, b1, b2, 1e-8,
-                                     P(self.pstep), st), "us_adam_step_dev")
+        L.check(lib.us_pose_adam_step(P(self.pose), P(self.g_pose), P(self.pm), P(self.pv), self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), st),
+                "us_pose_adam_step")
         return loss, unc, valid
