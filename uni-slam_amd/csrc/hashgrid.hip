@@ -324,8 +324,7 @@ __global__ __launch_bounds__(256) void k_bwd_input(const float* __restrict__ dL_
 
 // The same without a stored dy_dx: every (point, level) gathers its 8 vertices again and forms dy/dx on the fly (what
 // k_fwd<DYDX> writes, value for value).  Saves the [N][C][3] tensor (100 MB per grid at 4096 x 64) at the price of a second
-// gather pass.  Parallel over levels like the encoder: a 1024-thread workgroup = 64 points x 16 levels (wave = level), the 16
-// per-level contributions of a point are summed through LDS in level order.
+// gather pass.
 template <int F>
 __device__ __forceinline__ void input_grad_level(const LevelTable& tab, uint32_t level, uint32_t n_levels, const float* __restrict__ params,
                                                  const float xv[3], const bool pass[3], const float* __restrict__ dL_dy, int64_t i, int64_t n,
@@ -370,18 +369,19 @@ __device__ __forceinline__ void input_grad_level(const LevelTable& tab, uint32_t
     }
 }
 
-#define IG_POINTS 64
-#define IG_LEVELS 16
+// A wavefront = 16 points x 4 levels (lane = point + 16 * (level mod 4)): every lane walks the levels {r, r+4, r+8, ...} of its
+// point (r = its row of 16 lanes), keeping its share of dL/dx in registers; two cross-row shuffles add the four shares.
+// No LDS, no barrier: a wave stalled on the cache misses of a fine level holds up nobody else.  The 16 lanes of a row read 16
+// consecutive points of one level plane (128 contiguous bytes of dL_dy in the level-major layout).
+#define IG_POINTS 16
 template <int F>
-__global__ __launch_bounds__(IG_POINTS * IG_LEVELS) void k_bwd_input_gather(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
-                                                                            const float* __restrict__ x, const float* __restrict__ dL_dy,
-                                                                            int64_t n, float* __restrict__ dL_dx, int clamp, int lm,
-                                                                            int accumulate) {
-    __shared__ float part[IG_LEVELS][3][IG_POINTS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * IG_POINTS + lane;
+__global__ __launch_bounds__(256) void k_bwd_input_gather(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
+                                                          const float* __restrict__ x, const float* __restrict__ dL_dy, int64_t n,
+                                                          float* __restrict__ dL_dx, int clamp, int lm, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, pt = lane & 15;
+    const int64_t i = ((int64_t)blockIdx.x * 4 + wave) * IG_POINTS + pt;
     const bool in = i < n;
-    float xv[3] = {0.f, 0.f, 0.f}, total[3] = {0.f, 0.f, 0.f};
+    float xv[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
     bool pass[3] = {true, true, true};
     if (in) {
 #pragma unroll
@@ -390,25 +390,17 @@ __global__ __launch_bounds__(IG_POINTS * IG_LEVELS) void k_bwd_input_gather(Leve
             xv[k] = clamp ? fminf(fmaxf(xin, 0.0f), 1.0f) : xin;
             pass[k] = !clamp || (xin >= 0.0f && xin <= 1.0f);
         }
+        for (uint32_t level = (uint32_t)row; level < n_levels; level += 4)
+            input_grad_level<F>(tab, level, n_levels, params, xv, pass, dL_dy, i, n, lm, r);
     }
-    for (uint32_t l0 = 0; l0 < n_levels; l0 += IG_LEVELS) {
-        const uint32_t level = l0 + (uint32_t)wave;                // wave-uniform
-        float r[3] = {0.f, 0.f, 0.f};
-        if (in && level < n_levels) input_grad_level<F>(tab, level, n_levels, params, xv, pass, dL_dy, i, n, lm, r);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) part[wave][k][lane] = r[k];
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int w = 0; w < IG_LEVELS; ++w)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) total[k] += part[w][k][lane];
-        }
-        __syncthreads();
+    for (int k = 0; k < 3; ++k) {                                  // whole wave active: add the four rows' shares
+        r[k] += __shfl_xor(r[k], 16, 64);
+        r[k] += __shfl_xor(r[k], 32, 64);
     }
-    if (wave == 0 && in) {
+    if (row == 0 && in) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dx[i * 3 + k] = accumulate ? dL_dx[i * 3 + k] + total[k] : total[k];
+        for (int k = 0; k < 3; ++k) dL_dx[i * 3 + k] = accumulate ? dL_dx[i * 3 + k] + r[k] : r[k];
     }
 }
 
@@ -538,7 +530,7 @@ extern "C" int us_hashgrid_bwd_input_gather(const us_grid_desc* d, const float* 
     US_REQUIRE(((uintptr_t)params & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_bwd_input_gather: params must be 16-byte aligned");
     const LevelTable t = make_table(d);
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0, acc = (flags & US_GRID_ACCUMULATE) ? 1 : 0;
-    dim3 grid((unsigned)us_cdiv(n, IG_POINTS)), block(IG_POINTS * IG_LEVELS);
+    dim3 grid((unsigned)us_cdiv(n, 4 * IG_POINTS)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_BIG(F) hipLaunchKernelGGL((k_bwd_input_gather<F>), grid, block, 0, s, t, d->n_levels, params, x, dL_dy, n, dL_dx, clamp, lm, acc);
     switch (d->n_features) { case 1: LAUNCH_BIG(1) break; case 2: LAUNCH_BIG(2) break; default: LAUNCH_BIG(4) break; }
