@@ -237,6 +237,18 @@ int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, const uint8_t* 
                  int64_t n_rays, int n_samples, double truncation, const float* w_host5, const float* stats,
                  float* g_sdf, float* g_depth, float* g_rgb, float* loss_out, void* stream);
 
+/* us_composite_fwd + us_loss_stats in one launch + the reduction, and us_loss_grad + us_composite_bwd in one launch (+ the beta
+ * reduction): the mapping iteration's per-ray chain src/utils/Renderer.py:140-158 -> src/Mapper.py:411-440 and its adjoint.  Modes
+ * without the median gate only (US_LOSS_MAP_ORIGINAL, US_LOSS_MAP_NOMASK, US_LOSS_TRK_NOMASK); same values as the separate calls
+ * (bit for bit for n_samples <= 64). */
+int us_render_loss_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, int mode,
+                       const uint8_t* valid, const float* gt_depth, const float* gt_color, double truncation, float* termination,
+                       float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* partials, float* stats, void* stream);
+int us_render_loss_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, int mode,
+                       const uint8_t* valid, const float* gt_depth, const float* gt_color, const float* depth, const float* rgb,
+                       const float* pixel_unc, double truncation, const float* w_host5, const float* stats, float* d_raw,
+                       float* d_beta, float* beta_partials, float* loss_out, void* stream);
+
 /* the tracker's optimiser step (src/Tracker.py:322-329,242) in one launch: Adam on pose7 = (quaternion[4] with lr_R,
  * translation[3] with lr_T), us_adam_step_dev arithmetic; step_dev[0] (float) is incremented by the kernel before use */
 int us_pose_adam_step(float* pose7, const float* g7, float* m7, float* v7, double lr_R, double lr_T, double beta1, double beta2,

@@ -75,6 +75,9 @@ SIGNATURES = {
     "us_loss_stats": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, c_f, c_f, c_f]),
     "us_loss_grad": (c_int, [c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_dbl, _HF, c_f,
                              c_f, c_f, c_f, c_f, c_f]),
+    "us_render_loss_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_dbl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_render_loss_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_dbl, _HF, c_f, c_f, c_f, c_f, c_f,
+                                   c_f]),
     "us_pose_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_masked_median": (c_int, [c_f, c_f, c_f, c_i64, c_f, c_f]),
     "us_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_f]),

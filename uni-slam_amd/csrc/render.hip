@@ -254,25 +254,49 @@ __device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
     return lane == 63 ? 0.0f : ex;
 }
 
+// ---- shared by the compositing and the loss kernels -------------------------------------------------------------------
+#define LOSS_NSTAT 10
+struct LossW { float w[5]; };
+struct RayGate { bool sdf_depth; bool color; };
+
+__device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float unc, const float* median) {
+    RayGate g; g.sdf_depth = true; g.color = true;
+    const bool alpha_mask = (1.0f - unc) > 0.99f;                       // Mapper.py:414-415 / Tracker.py:210-211
+    if (mode == US_LOSS_MAP_ORIGINAL) {
+        g.sdf_depth = (gt > 0.0f) && alpha_mask;                        // Mapper.py:417-419; colour uses all rays (:427)
+    } else if (mode == US_LOSS_TRK_ORIGINAL) {
+        const float err = fabsf(gt - d);
+        g.sdf_depth = (err < 10.0f * median[0]) && alpha_mask;          // Tracker.py:214-218
+        g.color = g.sdf_depth;                                          // Tracker.py:225
+    }
+    return g;
+}
+
+// loss terms riding on the compositing kernels (us_render_loss_fwd / us_render_loss_bwd): enabled == 0 -> plain compositing
+struct LossFwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; float tr, tr04; float* partials; };
+struct LossBwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; const float* depth; const float* rgb;
+                 const float* unc; float tr, tr04; LossW lw; const float* stats; float* loss_out; };
+
 template <int EPL>
 __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
                                                        const float* __restrict__ beta_p, int64_t n_rays, int S,
                                                        float* __restrict__ term, float* __restrict__ unc,
                                                        float* __restrict__ depth, float* __restrict__ rgb,
-                                                       float* __restrict__ dunc, float* __restrict__ weights) {
+                                                       float* __restrict__ dunc, float* __restrict__ weights, LossFwd lf) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     const float beta = beta_p[0];
-    float a[EPL], z[EPL], c[EPL][3], tl[EPL];
+    float a[EPL], z[EPL], c[EPL][3], tl[EPL], sdfv[EPL];
     float tprod = 1.0f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int s = lane * EPL + e;
-        a[e] = 0.0f; z[e] = 0.0f; c[e][0] = c[e][1] = c[e][2] = 0.0f; tl[e] = 1.0f;
+        a[e] = 0.0f; z[e] = 0.0f; c[e][0] = c[e][1] = c[e][2] = 0.0f; tl[e] = 1.0f; sdfv[e] = 0.0f;
         if (s < S) {
             const float4 r = *reinterpret_cast<const float4*>(raw + (ray * S + s) * 4);
             float sig, ex;
+            sdfv[e] = r.w;
             a[e] = sdf_to_alpha(r.w, beta, sig, ex);
             z[e] = z_vals[ray * S + s];
             c[e][0] = r.x; c[e][1] = r.y; c[e][2] = r.z;
@@ -308,6 +332,39 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__
         rgb[ray * 3 + 0] = s_c[0]; rgb[ray * 3 + 1] = s_c[1]; rgb[ray * 3 + 2] = s_c[2];
         dunc[ray] = sqrtf(s_v);
     }
+    if (lf.enabled) {                                // k_loss_partials on the values this wave holds (mapping modes: no median)
+        const float gt = lf.gt_depth[ray], d = s_z;
+        RayGate gate = ray_gate(lf.mode, gt, d, (1.0f - s_w) * (1.0f - s_w), nullptr);
+        if (lf.valid && !lf.valid[ray]) { gate.sdf_depth = false; gate.color = false; }
+        float s3[3] = {0.f, 0.f, 0.f}, n3[3] = {0.f, 0.f, 0.f};
+        if (gate.sdf_depth) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (lane * EPL + e < S) {
+                    const float zz = z[e], sdf = sdfv[e];
+                    const bool front = zz < (gt - lf.tr), back = zz > (gt + lf.tr);
+                    const bool center = (zz > (gt - lf.tr04)) && (zz < (gt + lf.tr04));
+                    if (front) { const float r = sdf - 1.0f; s3[0] += r * r; n3[0] += 1.f; }
+                    else if (center) { const float r = (zz + sdf * lf.tr) - gt; s3[1] += r * r; n3[1] += 1.f; }
+                    else if (!back) { const float r = (zz + sdf * lf.tr) - gt; s3[2] += r * r; n3[2] += 1.f; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s3[k] = wave_sum(s3[k]); n3[k] = wave_sum(n3[k]); }
+        if (lane == 0) {
+            float* p = lf.partials + ray * LOSS_NSTAT;
+            p[0] = s3[0]; p[1] = s3[1]; p[2] = s3[2]; p[5] = n3[0]; p[6] = n3[1]; p[7] = n3[2];
+            float cs = 0.f;
+            if (gate.color) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const float r = lf.gt_color[ray * 3 + k] - s_c[k]; cs += r * r; }
+            }
+            p[3] = cs; p[8] = gate.color ? 3.f : 0.f;
+            const float r = gt - d;
+            p[4] = gate.sdf_depth ? r * r : 0.f; p[9] = gate.sdf_depth ? 1.f : 0.f;
+        }
+    }
 }
 
 template <int EPL>
@@ -317,9 +374,14 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
                                                        const float* __restrict__ g_depth, const float* __restrict__ g_rgb,
                                                        const float* __restrict__ g_dunc, const float* __restrict__ g_sdf,
                                                        float* __restrict__ d_raw, float* __restrict__ d_beta,
-                                                       float* __restrict__ beta_partials) {
+                                                       float* __restrict__ beta_partials, LossBwd lb) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (lb.enabled && blockIdx.x == 0 && threadIdx.x == 0 && lb.loss_out) {
+        float l = 0.f;
+        for (int k = 0; k < 5; ++k) l += lb.lw.w[k] * (lb.stats[k] / lb.stats[5 + k]);      // 0/0 -> NaN like torch.mean([])
+        lb.loss_out[0] = l;
+    }
     if (ray >= n_rays) return;
     const float beta = beta_p[0];
     float a[EPL], z[EPL], c[EPL][3], tl[EPL], sg[EPL], ex[EPL], sdf[EPL];
@@ -351,6 +413,21 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     float gd = g_depth ? g_depth[ray] : 0.f;
     float gc[3] = {0.f, 0.f, 0.f};
     if (g_rgb) { gc[0] = g_rgb[ray * 3]; gc[1] = g_rgb[ray * 3 + 1]; gc[2] = g_rgb[ray * 3 + 2]; }
+    // k_loss_grad on the fly (us_render_loss_bwd): the loss gradients wrt depth / colour / sdf of this ray from the statistics
+    float gt_l = 0.f, k_fs = 0.f, k_ce = 0.f, k_ta = 0.f;
+    bool gate_sdf = false;
+    if (lb.enabled) {
+        gt_l = lb.gt_depth[ray];
+        const float d = lb.depth[ray];
+        RayGate gate = ray_gate(lb.mode, gt_l, d, lb.unc[ray], nullptr);
+        if (lb.valid && !lb.valid[ray]) { gate.sdf_depth = false; gate.color = false; }
+        gate_sdf = gate.sdf_depth;
+        k_fs = 2.0f * lb.lw.w[0] / lb.stats[5]; k_ce = 2.0f * lb.lw.w[1] / lb.stats[6]; k_ta = 2.0f * lb.lw.w[2] / lb.stats[7];
+        gd = gate.sdf_depth ? (2.0f * lb.lw.w[4] / lb.stats[9]) * (d - gt_l) : 0.f;
+        const float kc = 2.0f * lb.lw.w[3] / lb.stats[8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gc[k] = gate.color ? kc * (lb.rgb[ray * 3 + k] - lb.gt_color[ray * 3 + k]) : 0.f;
+    }
     float kv = 0.f;                                  // g_dunc / (2 dunc): derivative of sqrt(V)
     if (gdu != 0.f) {
         float s_v = 0.f;
@@ -384,7 +461,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             const float da_dbeta = ex[e] * (sg[e] - beta * sdf[e] * dsig);
             float4 o;
             o.x = gc[0] * w[e]; o.y = gc[1] * w[e]; o.z = gc[2] * w[e];
-            o.w = da * da_dsdf + (g_sdf ? g_sdf[ray * S + s] : 0.f);
+            float gs = g_sdf ? g_sdf[ray * S + s] : 0.f;
+            if (lb.enabled && gate_sdf) {
+                const bool front = z[e] < (gt_l - lb.tr), back = z[e] > (gt_l + lb.tr);
+                const bool center = (z[e] > (gt_l - lb.tr04)) && (z[e] < (gt_l + lb.tr04));
+                if (front) gs = k_fs * (sdf[e] - 1.0f);
+                else if (center) gs = k_ce * ((z[e] + sdf[e] * lb.tr) - gt_l) * lb.tr;
+                else if (!back) gs = k_ta * ((z[e] + sdf[e] * lb.tr) - gt_l) * lb.tr;
+            }
+            o.w = da * da_dsdf + gs;
             *reinterpret_cast<float4*>(d_raw + (ray * S + s) * 4) = o;
             dbeta_local += da * da_dbeta;
         }
@@ -411,22 +496,6 @@ __global__ __launch_bounds__(1024) void k_beta_reduce(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 // K6: masked losses.  Phase 1: per-ray partial sums/counts -> fixed-order reduction.  Phase 2: gradients.
 // ---------------------------------------------------------------------------------------------------------------
-struct RayGate { bool sdf_depth; bool color; };
-
-__device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float unc, const float* median) {
-    RayGate g; g.sdf_depth = true; g.color = true;
-    const bool alpha_mask = (1.0f - unc) > 0.99f;                       // Mapper.py:414-415 / Tracker.py:210-211
-    if (mode == US_LOSS_MAP_ORIGINAL) {
-        g.sdf_depth = (gt > 0.0f) && alpha_mask;                        // Mapper.py:417-419; colour uses all rays (:427)
-    } else if (mode == US_LOSS_TRK_ORIGINAL) {
-        const float err = fabsf(gt - d);
-        g.sdf_depth = (err < 10.0f * median[0]) && alpha_mask;          // Tracker.py:214-218
-        g.color = g.sdf_depth;                                          // Tracker.py:225
-    }
-    return g;
-}
-
-#define LOSS_NSTAT 10
 __global__ __launch_bounds__(256) void k_loss_partials(int mode, const float* __restrict__ sdf_p, int64_t sdf_stride,
                                                        const uint8_t* __restrict__ valid,
                                                        const float* __restrict__ z_vals, const float* __restrict__ gt_depth,
@@ -490,8 +559,6 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ 
         stats[k] = (float)v;
     }
 }
-
-struct LossW { float w[5]; };
 
 __global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __restrict__ sdf_p, int64_t sdf_stride,
                                                    const uint8_t* __restrict__ valid, const float* __restrict__ z_vals,
@@ -855,9 +922,9 @@ extern "C" int us_composite_fwd(const float* raw, const float* z_vals, const flo
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_fwd: n_samples %d not in 1..128", n_samples);
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     if (n_samples <= 64)
-        hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights);
+        hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights, LossFwd{});
     else
-        hipLaunchKernelGGL((k_composite_fwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights);
+        hipLaunchKernelGGL((k_composite_fwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, weights, LossFwd{});
     US_CHECK_LAUNCH("us_composite_fwd");
     return US_OK;
 }
@@ -871,9 +938,9 @@ extern "C" int us_composite_bwd(const float* raw, const float* z_vals, const flo
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_composite_bwd: n_samples %d not in 1..128", n_samples);
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     if (n_samples <= 64)
-        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr);
+        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr, LossBwd{});
     else
-        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr);
+        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, beta, n_rays, n_samples, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf, d_raw, d_beta, d_beta ? beta_partials : nullptr, LossBwd{});
     US_CHECK_LAUNCH("us_composite_bwd");
     if (d_beta && beta_partials) {
         hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, beta_partials, n_rays, d_beta);
@@ -921,6 +988,60 @@ extern "C" int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, cons
                        gt_depth, gt_color, depth, rgb, pixel_unc, median, n_rays, n_samples, (float)truncation,
                        (float)(0.4 * truncation), lw, stats, g_sdf, g_depth, g_rgb, loss_out);
     US_CHECK_LAUNCH("us_loss_grad");
+    return US_OK;
+}
+
+// compositing + loss statistics in one launch, loss gradients + compositing backward in one launch (mapping modes: no median)
+extern "C" int us_render_loss_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, int mode,
+                                  const uint8_t* valid, const float* gt_depth, const float* gt_color, double truncation, float* term,
+                                  float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* partials, float* stats, void* stream) {
+    US_REQUIRE(mode == US_LOSS_MAP_ORIGINAL || mode == US_LOSS_MAP_NOMASK || mode == US_LOSS_TRK_NOMASK, US_ERR_CONFIG,
+               "us_render_loss_fwd: mode %d needs the median of the rendered depth error (use us_composite_fwd + us_loss_stats)", mode);
+    US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_render_loss_fwd: empty batch");
+    US_REQUIRE(raw && z_vals && beta && gt_depth && gt_color && term && pixel_unc && depth && rgb && depth_unc && partials && stats, US_ERR_NULL,
+               "us_render_loss_fwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_render_loss_fwd: n_samples %d not in 1..128", n_samples);
+    LossFwd lf{1, mode, valid, gt_depth, gt_color, (float)truncation, (float)(0.4 * truncation), partials};
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, (float*)nullptr, lf);
+    else
+        hipLaunchKernelGGL((k_composite_fwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, (float*)nullptr, lf);
+    US_CHECK_LAUNCH("us_render_loss_fwd");
+    hipLaunchKernelGGL(k_loss_reduce, dim3(LOSS_NSTAT), dim3(1024), 0, s, partials, n_rays, stats);
+    US_CHECK_LAUNCH("us_render_loss_fwd(reduce)");
+    return US_OK;
+}
+
+extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, int mode,
+                                  const uint8_t* valid, const float* gt_depth, const float* gt_color, const float* depth, const float* rgb,
+                                  const float* pixel_unc, double truncation, const float* w5_host, const float* stats, float* d_raw,
+                                  float* d_beta, float* beta_partials, float* loss_out, void* stream) {
+    US_REQUIRE(mode == US_LOSS_MAP_ORIGINAL || mode == US_LOSS_MAP_NOMASK || mode == US_LOSS_TRK_NOMASK, US_ERR_CONFIG,
+               "us_render_loss_bwd: mode %d needs the median of the rendered depth error (use us_loss_grad + us_composite_bwd)", mode);
+    US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_render_loss_bwd: empty batch");
+    US_REQUIRE(raw && z_vals && beta && gt_depth && gt_color && depth && rgb && pixel_unc && w5_host && stats && d_raw, US_ERR_NULL,
+               "us_render_loss_bwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_render_loss_bwd: n_samples %d not in 1..128", n_samples);
+    LossBwd lb{};
+    lb.enabled = 1; lb.mode = mode; lb.valid = valid; lb.gt_depth = gt_depth; lb.gt_color = gt_color; lb.depth = depth; lb.rgb = rgb;
+    lb.unc = pixel_unc; lb.tr = (float)truncation; lb.tr04 = (float)(0.4 * truncation); lb.stats = stats; lb.loss_out = loss_out;
+    for (int k = 0; k < 5; ++k) lb.lw.w[k] = w5_host[k];
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float* nul = nullptr;
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, d_beta,
+                           d_beta ? beta_partials : nullptr, lb);
+    else
+        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, d_beta,
+                           d_beta ? beta_partials : nullptr, lb);
+    US_CHECK_LAUNCH("us_render_loss_bwd");
+    if (d_beta && beta_partials) {
+        hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, s, beta_partials, n_rays, d_beta);
+        US_CHECK_LAUNCH("us_render_loss_bwd(beta)");
+    }
     return US_OK;
 }
 

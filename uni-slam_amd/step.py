@@ -264,11 +264,10 @@ class MapStep:
         self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
         self._join()
         beta = off(fl, self.o_beta)
-        L.check(lib.us_composite_fwd(P(self.raw), P(self.z), beta, R, S, P(self.term), P(self.unc), P(self.depth), P(self.rgb),
-                                     P(self.dunc), None, st), "us_composite_fwd")
-        L.check(lib.us_loss_stats(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
-                                  P(self.rgb), P(self.unc), None, R, S, self.truncation, P(self.partials), P(self.stats), st),
-                "us_loss_stats")
+        # compositing + the loss's sums and counts in one launch (+ the fixed-order reduction)
+        L.check(lib.us_render_loss_fwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), self.truncation,
+                                       P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.stats), st),
+                "us_render_loss_fwd")
         self._batch = (o, d, gd, gc, R)
         self.n_rays = R
         return self.stats
@@ -290,9 +289,6 @@ class MapStep:
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
         beta = off(fl, self.o_beta)
-        L.check(lib.us_loss_grad(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth),
-                                 P(self.rgb), P(self.unc), None, R, S, self.truncation, self.w5, P(self.stats), P(self.g_sdf),
-                                 P(self.g_depth), P(self.g_rgb), P(self.loss), st), "us_loss_grad")
         # The binned table backward writes every table entry (US_GRID_BWD_OVERWRITE); the decoder segment, which the MLP
         # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
         if self.bwd_mode not in (-1, 3):
@@ -301,8 +297,10 @@ class MapStep:
             self.grad[:self.o_tab_s].zero_()
         self._dec_grad_clean = False
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
-        L.check(lib.us_composite_bwd(P(self.raw), P(self.z), beta, R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
-                                     P(self.g_sdf), P(self.d_raw), gbeta, P(self.beta_part), st), "us_composite_bwd")
+        # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
+        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
+                                       P(self.unc), self.truncation, self.w5, P(self.stats), P(self.d_raw), gbeta, P(self.beta_part),
+                                       P(self.loss), st), "us_render_loss_bwd")
         binned = self.ws is not None
 
         def sdf_branch(q):
