@@ -698,10 +698,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
                                                            const float* __restrict__ x, int64_t n, float* __restrict__ out, int clamp,
                                                            int lm, uint32_t* __restrict__ wg_counts) {
     __shared__ uint32_t lcnt[BIN_MAX_TOTAL];
+    __shared__ uint32_t done;
     const uint32_t level = blockIdx.y;
     const BinLevel q = lv.l[level];
     const uint32_t nb = 1u << q.lg;
     for (uint32_t t = threadIdx.x; t < nb; t += BIN_THREADS) lcnt[t] = 0u;
+    if (threadIdx.x == 0) done = 0u;
     __syncthreads();
     const LevelGeom g = level_geom(tab, level);
     const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
@@ -753,9 +755,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
             }
         }
     }
-    __syncthreads();
-    uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL + q.first;
-    for (uint32_t t = threadIdx.x; t < nb; t += BIN_THREADS) row[t] = lcnt[t];
+    // No closing barrier: a wave that has finished its gathers leaves at once; the LAST wave to arrive (an LDS ticket taken after
+    // the wave's own counter atomics, which execute in order) writes the workgroup's row segment.
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&done, 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket == BIN_THREADS / 64 - 1) {
+        uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL + q.first;
+        for (uint32_t t = (uint32_t)lane; t < nb; t += 64) row[t] = lcnt[t];
+    }
 }
 
 extern "C" int us_hashgrid_fwd_counted(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out, int flags,
