@@ -16,7 +16,7 @@ fetch, write, mf = agg(load("r01_fetch")), agg(load("r01_write")), agg(load("r01
 avg = lambda v: sum(v) / max(len(v), 1)
 lines = ["# rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...), bench.py --steps 20 --warmup 5 --no-overlap, MI355X, round 1",
          "# per-launch averages. FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) and is",
-         "# uncalibrated for other widths: k_bin_accum reads exactly what k_bin<2,true> wrote, which calibrates its FETCH_SIZE (ratio in DESIGN.md).",
+         "# (raw values in this table); k_bin_accum re-reads exactly what k_bin<2,true> wrote: its raw FETCH_SIZE is 0.50 x that WRITE_SIZE, so traffic.json doubles FETCH_SIZE.",
          "# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)  (MFMA pipe busy cycles per SIMD-cycle while the CU is busy)",
          "kernel,calls,avg_us,FETCH_SIZE_KiB,WRITE_SIZE_KiB,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,SQ_INSTS_MFMA,mfma_busy_frac"]
 for k in sorted(stats, key=lambda k: -float(stats[k]["TotalDurationNs"]))[:14]:
@@ -33,13 +33,18 @@ def per_dispatch(d, counter):
 out = {}
 for grid, parity in (("color", 0), ("sdf", 1)):          # MapStep on one stream (--no-overlap) runs the colour branch first
     tot = 0.0
-    for d, c in (("r01_fetch", "FETCH_SIZE"), ("r01_write", "WRITE_SIZE")):
+    # MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE reports half of the bytes of a streaming read -> doubled.
+    # Cross-check inside this function: k_bin_accum re-reads exactly the records k_bin<write> wrote; its raw FETCH_SIZE is
+    # 0.50 x that kernel's WRITE_SIZE.  WRITE_SIZE is exact.
+    for d, c, corr in (("r01_fetch", "FETCH_SIZE", 2.0), ("r01_write", "WRITE_SIZE", 1.0)):
         rows = per_dispatch(d, c)
         for kname in ("k_bin<2, false>", "k_bin_colscan", "k_bin_scan", "k_bin<2, true>", "k_bin_accum<2>"):
             ks = [r for r in rows if kname in r["Kernel_Name"]][parity::2]
-            tot += sum(float(r["Counter_Value"]) for r in ks) / max(len(ks), 1) * 1024
+            tot += corr * sum(float(r["Counter_Value"]) for r in ks) / max(len(ks), 1) * 1024
     out[f"hashgrid_bwd_{grid}"] = tot
     print(grid, round(tot / 1e6, 1), "MB")
-json.dump({**out, "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 summed over the kernels of us_hashgrid_bwd_binned (k_bin<count>, k_bin_colscan, "
-                           "k_bin_scan, k_bin<write>, k_bin_accum), rocprofv3 --pmc in separate passes, round 1; FETCH_SIZE uncorrected (lower bound on the read side)"},
+json.dump({**out, "_note": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the kernels of us_hashgrid_bwd_binned (k_bin_colscan, "
+                           "k_bin_scan, k_bin<write>, k_bin_accum; the counting runs in the encoder's forward), rocprofv3 --pmc in separate passes, round 1; "
+                           "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a streaming read; confirmed here: k_bin_accum's raw "
+                           "FETCH_SIZE is 0.50 x the WRITE_SIZE of the records it re-reads)"},
           open(os.path.join(R, "profiles/traffic.json"), "w"), indent=1)
