@@ -221,7 +221,9 @@ def test_mapstep_single_rank_process_group_matches_plain():
     import os
     import torch.distributed as dist
     import unislam_amd as us
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()      # a free port, not a fixed one
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         outs = []
