@@ -178,6 +178,13 @@ int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals,
 int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
                       int n_samples, float* dL_do, float* dL_dd, void* stream);
 
+/* importance samples of the rays WITHOUT a depth measurement (src/utils/Renderer.py:121-130 + common.sample_pdf src/common.py:49-85):
+ * sdf_uni[R][n_uniform] of the coarse uniform pass at z_uni[R][n_uniform] -> alpha (beta: device float[1]) -> weights -> the reference's
+ * un-normalised cdf over weights[1:-1] -> inverse transform with the draws u[R][n_importance] -> z_out[R][n_uniform + n_importance],
+ * sorted.  n_uniform <= 128, n_importance <= 64. */
+int us_importance_z(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, int64_t n_rays, int n_uniform,
+                    int n_importance, float* z_out, void* stream);
+
 /* us_bbox_filter + us_sample_z + us_ray_points in ONE launch, value for value (the iteration of src/Mapper.py:396-406 +
  * src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  perturb != 0: jitter with t_rand[R][S], or,
  * when t_rand is NULL, with an in-kernel counter-based uniform generator seeded by rng_seed (the reference draws

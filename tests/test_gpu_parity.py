@@ -882,3 +882,29 @@ def test_masked_median_equals_torch_median(us, n):
     valid.zero_()
     L.check(L.lib().us_masked_median(L.ptr(a), L.ptr(b), L.ptr(valid), n, L.ptr(out), L.stream()), "median")
     assert float(out) == float("inf")
+
+
+@pytest.mark.parametrize("Su,ni", [(32, 8), (48, 8), (80, 16), (128, 64), (3, 1)])
+def test_importance_z_equals_the_reference_chain(us, Su, ni):
+    """us_importance_z (zero-depth rays: alpha -> weights -> un-normalised cdf -> inverse transform -> sort, one launch) against the
+    oracle's restatement of Renderer.py:121-130 + common.sample_pdf on the same draws"""
+    from unislam_amd import _lib as L
+    g = torch.Generator().manual_seed(Su * 100 + ni)
+    R = 777
+    z = torch.sort(torch.rand(R, Su, generator=g) * 4 + 0.05, -1)[0]
+    sdf = (torch.rand(R, Su, generator=g) * 2 - 1) * 0.5
+    sdf[::5] = torch.linspace(0.6, -0.6, Su)                         # a clean surface crossing
+    sdf[1::9] = 0.9                                                  # free space only: cdf ~ 0 -> the denom < 1e-5 branch
+    u = torch.rand(R, ni, generator=g)
+    beta = torch.tensor([7.3])
+    alpha = O.sdf2alpha(sdf, beta)
+    w = O.alpha_to_weights(alpha)
+    mids = 0.5 * (z[..., 1:] + z[..., :-1])
+    samples = O.sample_pdf(mids, w[..., 1:-1], ni, u=u) if Su > 2 else None
+    ref = torch.sort(torch.cat([z, samples], -1), -1)[0]
+    out = torch.empty(R, Su + ni, device=DEV)
+    sdf_d, z_d, beta_d, u_d = sdf.to(DEV), z.to(DEV), beta.to(DEV), u.to(DEV)        # keep the device copies alive across the launch
+    L.check(L.lib().us_importance_z(L.ptr(sdf_d), L.ptr(z_d), L.ptr(beta_d), L.ptr(u_d), R, Su, ni, L.ptr(out), L.stream()), "us_importance_z")
+    o = out.cpu()
+    assert bool((o[:, 1:] >= o[:, :-1]).all())
+    assert torch.allclose(o, ref, rtol=2e-5, atol=2e-5), float((o - ref).abs().max())

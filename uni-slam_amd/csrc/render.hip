@@ -602,6 +602,88 @@ __global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K0f: importance samples of the rays WITHOUT a depth measurement (Renderer.py:121-130 + common.sample_pdf :49-85): from the SDF
+// of a coarse uniform pass to alpha, weights, the un-normalised cdf of the reference (pdf = weights[1:-1], common.py:55-56),
+// inverse transform with the draws u, and the sort of the merged samples.  One wavefront per ray; S_u <= 128, n_imp <= 64.
+// ---------------------------------------------------------------------------------------------------------------
+#define IMP_MAX_U 128
+__global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ sdf, const float* __restrict__ z_uni,
+                                                      const float* __restrict__ beta_p, const float* __restrict__ u, int64_t n_rays,
+                                                      int Su, int n_imp, float* __restrict__ z_out) {
+    __shared__ float sh_cdf[4][IMP_MAX_U], sh_bin[4][IMP_MAX_U], sh_all[4][IMP_MAX_U + 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;                                   // wave-uniform
+    float* cdf = sh_cdf[wv]; float* bin = sh_bin[wv]; float* all = sh_all[wv];
+    const float beta = beta_p[0];
+    // weights w_j = alpha_j * prod_{i<j} (1 - alpha_i + 1e-10)   (lane owns samples 2*lane, 2*lane+1)
+    float a[2], z[2], tl[2];
+    float tprod = 1.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = lane * 2 + e;
+        a[e] = 0.f; z[e] = 0.f; tl[e] = 1.0f;
+        if (j < Su) {
+            float sg, ex;
+            a[e] = sdf_to_alpha(sdf[ray * Su + j], beta, sg, ex);
+            z[e] = z_uni[ray * Su + j];
+            tl[e] = (1.0f - a[e]) + 1e-10f;
+        }
+        tprod *= tl[e];
+    }
+    float T = wave_excl_prod(tprod, lane);
+    float w[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { w[e] = a[e] * T; T *= tl[e]; }
+    // pdf_k = w_{k+1}, k = 0 .. Su-3 ; cdf_0 = 0, cdf_k = sum_{i=1..k} w_i (k = 1 .. Su-2): inclusive scan of w with w_0 left out
+    float pw[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { const int j = lane * 2 + e; pw[e] = (j >= 1 && j <= Su - 2) ? w[e] : 0.0f; }
+    float incl = pw[0] + pw[1];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const float before = incl - (pw[0] + pw[1]);                  // sum over samples of lower lanes
+    // cdf index k corresponds to sample j = k (cdf_j = sum_{i=1..j} w_i), valid for j = 0 .. Su-2
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = lane * 2 + e;
+        if (j <= Su - 2) cdf[j] = before + (e == 0 ? pw[0] : pw[0] + pw[1]);
+        if (j < Su) all[j] = z[e];                               // the uniform samples go first into the merge buffer
+    }
+    // bins = mids of consecutive uniform samples, k = 0 .. Su-2
+    {
+        const float z_next_lane = __shfl_down(z[0], 1, 64);
+        const int j0 = lane * 2;
+        if (j0 + 1 < Su) bin[j0] = 0.5f * (z[1] + z[0]);
+        if (j0 + 2 < Su) bin[j0 + 1] = 0.5f * (z_next_lane + z[1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0): this wave's LDS writes are done
+    const int nb = Su - 1;                                        // entries of cdf and of bins
+    if (lane < n_imp) {
+        const float uu = u[ray * n_imp + lane];
+        int lo = 0, hi = nb;                                      // searchsorted(right=True): first index with cdf > uu
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+        const int below = lo - 1 > 0 ? lo - 1 : 0, above = lo < nb - 1 ? lo : nb - 1;
+        const float cb = cdf[below], ca = cdf[above], bb = bin[below], ba = bin[above];
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (uu - cb) / denom;
+        all[Su + lane] = bb + t * (ba - bb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // sort the Su + n_imp merged samples: rank by counting (ties broken by position)
+    const int S = Su + n_imp;
+    for (int i = lane; i < S; i += 64) {
+        const float v = all[i];
+        int rank = 0;
+        for (int k = 0; k < S; ++k) { const float o = all[k]; rank += (o < v || (o == v && k < i)) ? 1 : 0; }
+        z_out[ray * S + rank] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Lower median of |a - b| over the flagged elements (Tracker.py:212-214: depth_error.median() of the rays that passed the
 // pre-filter; torch.median returns the lower of the two middle values).  One workgroup; no element flagged -> +inf.
 // n <= MEDIAN_MAX.
@@ -1042,6 +1124,18 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
         hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, s, beta_partials, n_rays, d_beta);
         US_CHECK_LAUNCH("us_render_loss_bwd(beta)");
     }
+    return US_OK;
+}
+
+extern "C" int us_importance_z(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, int64_t n_rays, int n_uniform,
+                               int n_importance, float* z_out, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(sdf_uni && z_uni && beta && u && z_out, US_ERR_NULL, "us_importance_z: NULL pointer");
+    US_REQUIRE(n_uniform >= 3 && n_uniform <= IMP_MAX_U && n_importance >= 1 && n_importance <= 64, US_ERR_SHAPE,
+               "us_importance_z: n_uniform %d not in 3..%d or n_importance %d not in 1..64", n_uniform, IMP_MAX_U, n_importance);
+    hipLaunchKernelGGL(k_importance_z, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, sdf_uni, z_uni, beta, u, n_rays,
+                       n_uniform, n_importance, z_out);
+    US_CHECK_LAUNCH("us_importance_z");
     return US_OK;
 }
 

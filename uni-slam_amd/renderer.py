@@ -112,12 +112,15 @@ def zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, bound, t_uni, n_im
         pts_uni = rays_o_uni.unsqueeze(1) + rays_d_uni.unsqueeze(1) * z_vals_uni.unsqueeze(-1)
         pts_uni_nor = normalize_3d_coordinate(pts_uni.clone(), bound)
         sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(*pts_uni.shape[0:2])
-        alpha_uni = sdf2alpha(sdf_uni, decoders.beta)
-        weights_uni = alpha_uni * torch.cumprod(torch.cat([torch.ones((alpha_uni.shape[0], 1), device=device),
-                                                           (1. - alpha_uni + 1e-10)], -1), -1)[:, :-1]
-        z_vals_uni_mid = .5 * (z_vals_uni[..., 1:] + z_vals_uni[..., :-1])
-        z_samples_uni = sample_pdf(z_vals_uni_mid, weights_uni[..., 1:-1], n_importance, det=False, device=device)
-        z_vals_uni, _ = torch.sort(torch.cat([z_vals_uni, z_samples_uni], -1), -1)
+        # alpha -> weights -> un-normalised cdf -> inverse transform -> merge sort: one HIP launch (us_importance_z)
+        R0, Su = sdf_uni.shape
+        u = torch.rand([R0, n_importance], device=device)                  # the draw of common.sample_pdf (:61)
+        beta = decoders.beta
+        beta_t = L.f32(beta.detach()).reshape(1) if torch.is_tensor(beta) else torch.tensor([float(beta)], device=device)
+        out = torch.empty((R0, Su + n_importance), dtype=torch.float32, device=device)
+        L.check(L.lib().us_importance_z(L.ptr(L.f32(sdf_uni)), L.ptr(L.f32(z_vals_uni)), L.ptr(beta_t), L.ptr(u.contiguous()), R0, Su,
+                                        n_importance, L.ptr(out), L.stream()), "us_importance_z")
+        z_vals_uni = out
     return z_vals_uni
 
 
