@@ -97,7 +97,7 @@ static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
         const uint32_t lines = (hs + (1u << BIN_LINE_LOG2) - 1u) >> BIN_LINE_LOG2;
         uint32_t lg = 0;
         while (bin_n_local(hs, 0, lg) > be) ++lg;                // capacity of the f64 slice
-        if (lg < want) lg = want;                                // load
+        if (lg < want) lg = want;                                // load (fewer bins on the coarse levels: measured, no gain)
         while (lg > 0 && (1u << lg) > lines) --lg;               // never more bins than lines
         if (bin_n_local(hs, 0, lg) > be) return -1;
         bm->log2nb[l] = lg;
