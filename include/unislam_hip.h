@@ -185,6 +185,22 @@ int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bo
 int us_importance_z(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, int64_t n_rays, int n_uniform,
                     int n_importance, float* z_out, void* stream);
 
+/* The same with the pieces a sync-light mapping iteration needs around it (src/utils/Renderer.py:104-137 for the rays with gt_depth == 0):
+ *   us_zero_depth_rows   rows[k] = indices of the rays with !(gt_depth > 0), ascending, and count[0] (device int32; ONE workgroup)
+ *   us_uniform_points    the coarse pass of those rows (rows NULL: all rays): far = far_bb + 0.01 (Renderer.py:108-111), z_uni[k][j] =
+ *                        far*t_uni[j] with the jitter of :42-57 (t_rand[n_rows][n_uniform] or, NULL, the in-kernel generator), and
+ *                        pts[k][j][3] normalised to [-1,1] (common.normalize_3d_coordinate, what Renderer.py:113 feeds the encoder)
+ *   us_importance_z_rows us_importance_z on compacted inputs, written to row rows[k] of z_out[R][S] (rows NULL: row k); u NULL: draws
+ *                        from the in-kernel generator; pts_out (nullable, with rays_o / rays_d / bound_host): the unit-cube points
+ *                        of the written rows, as us_ray_points would produce them. */
+int us_zero_depth_rows(const float* gt_depth, int64_t n_rays, int32_t* rows, int32_t* count, void* stream);
+int us_uniform_points(const float* rays_o, const float* rays_d, const int32_t* rows, int64_t n_rows, const float* bound_host,
+                      const float* t_uni, int n_uniform, const float* t_rand, uint64_t rng_seed, int perturb, float* z_uni,
+                      float* pts, void* stream);
+int us_importance_z_rows(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, uint64_t rng_seed,
+                         int64_t n_rows, int n_uniform, int n_importance, const int32_t* rows, float* z_out,
+                         const float* rays_o, const float* rays_d, const float* bound_host, float* pts_out, void* stream);
+
 /* us_bbox_filter + us_sample_z + us_ray_points in ONE launch, value for value (the iteration of src/Mapper.py:396-406 +
  * src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  perturb != 0: jitter with t_rand[R][S], or,
  * when t_rand is NULL, with an in-kernel counter-based uniform generator seeded by rng_seed (the reference draws

@@ -908,3 +908,64 @@ def test_importance_z_equals_the_reference_chain(us, Su, ni):
     o = out.cpu()
     assert bool((o[:, 1:] >= o[:, :-1]).all())
     assert torch.allclose(o, ref, rtol=2e-5, atol=2e-5), float((o - ref).abs().max())
+
+
+def test_zero_depth_rows_uniform_points_and_scatter(us):
+    """the pieces of the sync-light zero-depth branch: us_zero_depth_rows (ordered compaction, several 1024-row chunks),
+    us_uniform_points against the torch chain of Renderer.py:106-114 on the same draws, us_importance_z_rows writing rows + points"""
+    from unislam_amd import _lib as L
+    from unislam_amd.common import bound_host
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    g = torch.Generator().manual_seed(5)
+    R, Su, ni = 2600, 32, 8
+    bound = torch.tensor([[-2.0, 2.5], [-1.5, 2.0], [-1.0, 3.0]])
+    bh = bound_host(bound)
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.8
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    gd = torch.rand(R, generator=g) * 2
+    gd[torch.rand(R, generator=g) < 0.3] = 0.0
+    gd[7] = float("nan")                                           # ~(gt > 0), as the reference's mask
+    o_d, d_d, gd_d = o.to(DEV), d.to(DEV), gd.to(DEV)
+    rows, cnt = torch.full((R,), -1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    L.check(lib.us_zero_depth_rows(P(gd_d), R, P(rows), P(cnt), st), "rows")
+    want = torch.nonzero(~(gd > 0)).flatten()
+    n0 = int(cnt.item())
+    assert n0 == want.numel() and torch.equal(rows[:n0].cpu().long(), want)
+    # coarse pass
+    t_uni = torch.linspace(0., 1., Su)
+    tr = torch.rand(n0, Su, generator=g)
+    far = O.bbox_far(o[want], d[want], bound).unsqueeze(-1) + 0.01
+    z = 0.0 * (1. - t_uni) + far * t_uni
+    mids = 0.5 * (z[..., 1:] + z[..., :-1])
+    upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
+    z = lower + (upper - lower) * tr
+    pts = o[want].unsqueeze(1) + d[want].unsqueeze(1) * z.unsqueeze(-1)
+    pts = ((pts - bound[:, 0]) / (bound[:, 1] - bound[:, 0])) * 2 - 1.0
+    t_uni_d, tr_d = t_uni.to(DEV), tr.to(DEV)
+    z_d, pts_d = torch.empty(n0, Su, device=DEV), torch.empty(n0, Su, 3, device=DEV)
+    L.check(lib.us_uniform_points(P(o_d), P(d_d), P(rows), n0, bh, P(t_uni_d), Su, P(tr_d), 0, 1, P(z_d), P(pts_d), st), "uniform")
+    assert torch.allclose(z_d.cpu(), z, rtol=1e-6, atol=1e-6) and torch.allclose(pts_d.cpu(), pts, rtol=1e-5, atol=1e-5)
+    # in-kernel draws: inside the strata, different from call to call with the seed
+    za, zb = torch.empty_like(z_d), torch.empty_like(z_d)
+    L.check(lib.us_uniform_points(P(o_d), P(d_d), P(rows), n0, bh, P(t_uni_d), Su, None, 11, 1, P(za), P(pts_d), st), "uniform")
+    L.check(lib.us_uniform_points(P(o_d), P(d_d), P(rows), n0, bh, P(t_uni_d), Su, None, 12, 1, P(zb), P(pts_d), st), "uniform")
+    assert bool((za >= lower.to(DEV) - 1e-6).all()) and bool((za <= upper.to(DEV) + 1e-6).all()) and not torch.equal(za, zb)
+    frac = ((za - lower.to(DEV)) / (upper - lower).to(DEV))[:, 1:-1]
+    assert abs(float(frac.mean()) - 0.5) < 0.01
+    # scatter: rows of the full matrix rewritten (z and unit-cube points), the others untouched
+    sdf = (torch.rand(n0, Su, generator=g) - 0.5)
+    u = torch.rand(n0, ni, generator=g)
+    beta = torch.tensor([6.0])
+    sdf_d, u_d, beta_d = sdf.to(DEV), u.to(DEV), beta.to(DEV)
+    S = Su + ni
+    dense = torch.empty(n0, S, device=DEV)
+    L.check(lib.us_importance_z(P(sdf_d), P(z_d), P(beta_d), P(u_d), n0, Su, ni, P(dense), st), "imp")
+    zf, pf = torch.full((R, S), -7.0, device=DEV), torch.full((R, S, 3), -7.0, device=DEV)
+    L.check(lib.us_importance_z_rows(P(sdf_d), P(z_d), P(beta_d), P(u_d), 0, n0, Su, ni, P(rows), P(zf), P(o_d), P(d_d), bh, P(pf), st), "imp rows")
+    assert torch.equal(zf[want.to(DEV)], dense)
+    keep = torch.ones(R, dtype=torch.bool); keep[want] = False
+    assert bool((zf[keep.to(DEV)] == -7.0).all()) and bool((pf[keep.to(DEV)] == -7.0).all())
+    ref_pts = torch.empty(n0, S, 3, device=DEV)
+    oc, dc = o_d[want.to(DEV)].contiguous(), d_d[want.to(DEV)].contiguous()
+    L.check(lib.us_ray_points(P(oc), P(dc), P(dense), bh, n0, S, P(ref_pts), st), "pts")
+    assert torch.equal(pf[want.to(DEV)], ref_pts)

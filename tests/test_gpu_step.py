@@ -108,14 +108,12 @@ def test_mapstep_zero_depth_rays_and_oracle():
     loss_o.backward()
     step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=64)        # forces a buffer re-allocation too
     t_rand = torch.zeros(R, S); t_rand[(gd > 0).cpu()] = tr1
-    draws = [tr0.to(DEV), u0.to(DEV)]
-    real = torch.rand
-    try:
-        torch.rand = lambda *a, **k: draws.pop(0)
-        loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV))
-    finally:
-        torch.rand = real
-    assert not draws
+    loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV), zero_depth_draws=(tr0.to(DEV), u0.to(DEV)))
+    # the branch with its own draws (in-kernel generator): sorted samples inside the box for every zero-depth ray
+    step.forward(ro, rd, gd, gc)
+    z0 = step.rendered()[5][gd <= 0]
+    assert bool((z0[:, 1:] >= z0[:, :-1]).all()) and bool((z0 >= 0).all()) and bool((z0.max(1)[0] <= far.to(DEV)[gd <= 0] + 0.011).all())
+    loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV), zero_depth_draws=(tr0.to(DEV), u0.to(DEV)))
     z = step.rendered()[5]
     np.testing.assert_allclose(z.cpu().numpy(), ret_o[5].numpy(), rtol=1e-4, atol=1e-5)
     # mask counts must agree before the loss can (a ray on the 0.99 opacity threshold would flip a count)

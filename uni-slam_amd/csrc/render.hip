@@ -607,9 +607,73 @@ __global__ __launch_bounds__(256) void k_loss_grad(int mode, const float* __rest
 // inverse transform with the draws u, and the sort of the merged samples.  One wavefront per ray; S_u <= 128, n_imp <= 64.
 // ---------------------------------------------------------------------------------------------------------------
 #define IMP_MAX_U 128
+// K0g: the rows of the rays without a depth measurement (the ~gt_mask of Renderer.py:104), in ascending order, and their number.
+// One workgroup; the order makes the compacted pass reproducible against a boolean-mask indexing of the same rays.
+__global__ __launch_bounds__(1024) void k_zero_depth_rows(const float* __restrict__ gt_depth, int64_t n_rays, int32_t* __restrict__ rows,
+                                                          int32_t* __restrict__ count) {
+    __shared__ uint32_t wave_n[16];
+    __shared__ uint32_t base_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_sh = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n_rays; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool z = i < n_rays && !(gt_depth[i] > 0.0f);
+        const uint64_t m = __ballot(z);
+        if (lane == 0) wave_n[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = base_sh;
+        for (int w = 0; w < wv; ++w) before += wave_n[w];
+        if (z) rows[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += wave_n[w]; base_sh += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = (int32_t)base_sh;
+}
+
+// K0h: the coarse uniform pass of those rays (Renderer.py:106-114): far = far_bb + 0.01, z_j = 0*(1-t_j) + far*t_j, the jitter of
+// Renderer.py:42-57, and the points normalised with common.normalize_3d_coordinate (to [-1,1], as the reference does THERE; the
+// encoder's clamp to [0,1] follows).  One thread per (ray, sample); z_{j+-1} are recomputed instead of exchanged.
+__global__ __launch_bounds__(256) void k_uniform_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const int32_t* __restrict__ rows, int64_t n_rows, Bound3x bd,
+                                                        const float* __restrict__ t_uni, int Su, const float* __restrict__ t_rand,
+                                                        unsigned long long seed, int perturb, float* __restrict__ z_uni,
+                                                        float* __restrict__ pts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * Su; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Su; const int j = (int)(i - r * Su);
+        const int64_t ray = rows ? rows[r] : r;
+        float o3[3], d3[3], far = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o3[k] = rays_o[ray * 3 + k]; d3[k] = rays_d[ray * 3 + k];
+            const float t0 = (bd.lo[k] - o3[k]) / d3[k], t1 = (bd.hi[k] - o3[k]) / d3[k];
+            far = fminf(far, fmaxf(t0, t1));
+        }
+        far += 0.01f;
+        const float zj = far * t_uni[j];
+        float out = zj;
+        if (perturb) {
+            const float lower = j > 0 ? 0.5f * (zj + far * t_uni[j - 1]) : zj;
+            const float upper = j < Su - 1 ? 0.5f * (far * t_uni[j + 1] + zj) : zj;
+            const float u = t_rand ? t_rand[i] : uniform24(seed, (uint64_t)i);
+            out = lower + (upper - lower) * u;
+        }
+        z_uni[i] = out;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p = o3[k] + d3[k] * out;
+            pts[i * 3 + k] = ((p - bd.lo[k]) / bd.span[k]) * 2.0f - 1.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ sdf, const float* __restrict__ z_uni,
-                                                      const float* __restrict__ beta_p, const float* __restrict__ u, int64_t n_rays,
-                                                      int Su, int n_imp, float* __restrict__ z_out) {
+                                                      const float* __restrict__ beta_p, const float* __restrict__ u,
+                                                      unsigned long long seed, int64_t n_rays,
+                                                      int Su, int n_imp, const int32_t* __restrict__ rows, float* __restrict__ z_out,
+                                                      const float* __restrict__ rays_o, const float* __restrict__ rays_d, Bound3x bd,
+                                                      float* __restrict__ pts_out) {
     __shared__ float sh_cdf[4][IMP_MAX_U], sh_bin[4][IMP_MAX_U], sh_all[4][IMP_MAX_U + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
@@ -661,7 +725,7 @@ __global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ 
     __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0): this wave's LDS writes are done
     const int nb = Su - 1;                                        // entries of cdf and of bins
     if (lane < n_imp) {
-        const float uu = u[ray * n_imp + lane];
+        const float uu = u ? u[ray * n_imp + lane] : uniform24(seed, (uint64_t)(ray * n_imp + lane));
         int lo = 0, hi = nb;                                      // searchsorted(right=True): first index with cdf > uu
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
         const int below = lo - 1 > 0 ? lo - 1 : 0, above = lo < nb - 1 ? lo : nb - 1;
@@ -675,11 +739,19 @@ __global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ 
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // sort the Su + n_imp merged samples: rank by counting (ties broken by position)
     const int S = Su + n_imp;
+    const int64_t dst = rows ? (int64_t)rows[ray] : ray;         // destination row in the full [R][S] sample matrix
     for (int i = lane; i < S; i += 64) {
         const float v = all[i];
         int rank = 0;
         for (int k = 0; k < S; ++k) { const float o = all[k]; rank += (o < v || (o == v && k < i)) ? 1 : 0; }
-        z_out[ray * S + rank] = v;
+        z_out[dst * S + rank] = v;
+        if (pts_out) {                                             // Renderer.py:132-137 for the row just written
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float p = rays_o[dst * 3 + k] + rays_d[dst * 3 + k] * v;
+                pts_out[(dst * S + rank) * 3 + k] = (p - bd.lo[k]) / bd.span[k];
+            }
+        }
     }
 }
 
@@ -1127,15 +1199,52 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
     return US_OK;
 }
 
-extern "C" int us_importance_z(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, int64_t n_rays, int n_uniform,
-                               int n_importance, float* z_out, void* stream) {
-    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
-    US_REQUIRE(sdf_uni && z_uni && beta && u && z_out, US_ERR_NULL, "us_importance_z: NULL pointer");
+static Bound3x make_bound3x(const float* bound_host) {
+    Bound3x bd;
+    for (int k = 0; k < 3; ++k) { bd.lo[k] = bound_host[k]; bd.hi[k] = bound_host[3 + k]; bd.span[k] = bound_host[3 + k] - bound_host[k]; }
+    return bd;
+}
+
+extern "C" int us_importance_z_rows(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, uint64_t rng_seed,
+                                    int64_t n_rows, int n_uniform, int n_importance, const int32_t* rows, float* z_out,
+                                    const float* rays_o, const float* rays_d, const float* bound_host, float* pts_out, void* stream) {
+    if (n_rows <= 0) return n_rows == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(sdf_uni && z_uni && beta && z_out, US_ERR_NULL, "us_importance_z: NULL pointer");
+    US_REQUIRE(!pts_out || (rays_o && rays_d && bound_host), US_ERR_NULL, "us_importance_z: pts_out needs rays_o, rays_d and the bound");
     US_REQUIRE(n_uniform >= 3 && n_uniform <= IMP_MAX_U && n_importance >= 1 && n_importance <= 64, US_ERR_SHAPE,
                "us_importance_z: n_uniform %d not in 3..%d or n_importance %d not in 1..64", n_uniform, IMP_MAX_U, n_importance);
-    hipLaunchKernelGGL(k_importance_z, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, sdf_uni, z_uni, beta, u, n_rays,
-                       n_uniform, n_importance, z_out);
+    Bound3x bd = {};
+    if (pts_out) bd = make_bound3x(bound_host);
+    hipLaunchKernelGGL(k_importance_z, dim3((unsigned)us_cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, sdf_uni, z_uni, beta, u,
+                       (unsigned long long)rng_seed, n_rows, n_uniform, n_importance, rows, z_out, rays_o, rays_d, bd, pts_out);
     US_CHECK_LAUNCH("us_importance_z");
+    return US_OK;
+}
+
+extern "C" int us_importance_z(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, int64_t n_rays, int n_uniform,
+                               int n_importance, float* z_out, void* stream) {
+    US_REQUIRE(u || n_rays <= 0, US_ERR_NULL, "us_importance_z: NULL pointer");
+    return us_importance_z_rows(sdf_uni, z_uni, beta, u, 0, n_rays, n_uniform, n_importance, nullptr, z_out, nullptr, nullptr, nullptr,
+                                nullptr, stream);
+}
+
+extern "C" int us_zero_depth_rows(const float* gt_depth, int64_t n_rays, int32_t* rows, int32_t* count, void* stream) {
+    US_REQUIRE(gt_depth && rows && count, US_ERR_NULL, "us_zero_depth_rows: NULL pointer");
+    US_REQUIRE(n_rays >= 0 && n_rays <= 0x7fffffff, US_ERR_SHAPE, "us_zero_depth_rows: n_rays %lld", (long long)n_rays);
+    hipLaunchKernelGGL(k_zero_depth_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, gt_depth, n_rays, rows, count);
+    US_CHECK_LAUNCH("us_zero_depth_rows");
+    return US_OK;
+}
+
+extern "C" int us_uniform_points(const float* rays_o, const float* rays_d, const int32_t* rows, int64_t n_rows, const float* bound_host,
+                                 const float* t_uni, int n_uniform, const float* t_rand, uint64_t rng_seed, int perturb, float* z_uni,
+                                 float* pts, void* stream) {
+    if (n_rows <= 0) return n_rows == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(rays_o && rays_d && bound_host && t_uni && z_uni && pts, US_ERR_NULL, "us_uniform_points: NULL pointer");
+    US_REQUIRE(n_uniform >= 1, US_ERR_SHAPE, "us_uniform_points: n_uniform %d", n_uniform);
+    hipLaunchKernelGGL(k_uniform_points, dim3(grid_1d(n_rows * n_uniform, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                       rows, n_rows, make_bound3x(bound_host), t_uni, n_uniform, t_rand, (unsigned long long)rng_seed, perturb, z_uni, pts);
+    US_CHECK_LAUNCH("us_uniform_points");
     return US_OK;
 }
 

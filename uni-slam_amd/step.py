@@ -25,7 +25,6 @@ from .common import bound_host
 from .decoders import Decoders
 from .hashgrid import HashGridEncoding
 from .network import make_mlp_desc, mlp_n_params
-from .renderer import zero_depth_z
 from .dist import dp_iterate
 
 
@@ -55,6 +54,7 @@ class MapStep:
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
+        self.zd_rows = None                                                                # scratch of the zero-depth branch, on first use
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
             raise L.UniSlamHipError("MapStep needs the model on the GPU")
@@ -203,12 +203,14 @@ class MapStep:
         self.probe.setdefault(name, []).append((e0, e1))
 
     # ------------------------------------------------------------------------------------------ the iteration
-    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None):
         """
         Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
         has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
         knows every ray carries a depth (e.g. checked once per mapped frame on the pixel pools); True -> run the
         importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
+        zero_depth_draws: (t_rand_uni [n0, n_strat], u [n0, n_imp]) for that branch's rays in row order, to replay a given random stream
+        (tests); default: the in-kernel generator.
         """
         lib, st = L.lib(), L.stream()
         self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
@@ -222,25 +224,40 @@ class MapStep:
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
         # pre-filter against the scene box (Mapper.py:396-406) as a validity flag instead of a compaction
         c_free, s_off, s_span = ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation)
-        if has_zero_depth is False:
-            # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
-            tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-            self.rng_calls += 1
-            L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
-                                         c_free, s_off, s_span, tr, (self.rng_seed + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1), None,
-                                         1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
-        else:
-            L.check(lib.us_bbox_filter(P(o), P(d), P(gd), self.bhost, R, 0, P(self.valid), None, st), "us_bbox_filter")
-            if self.perturb and t_rand is None:
-                t_rand = torch.rand((R, S), device=self.device)
-            tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-            L.check(lib.us_sample_z(P(gd), R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, c_free, s_off, s_span, tr,
-                                    P(self.z), st), "us_sample_z")
-            m0 = gd <= 0
-            if bool(m0.any()):
-                self.z[:R][m0] = zero_depth_z(([self.es], [self.ec]), self.dec, o[m0], d[m0], self.bound, self.t_uni,
-                                              self.n_imp, self.perturb, self.device)
-            L.check(lib.us_ray_points(P(o), P(d), P(self.z), self.bhost, R, S, P(self.pts), st), "us_ray_points")
+        # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
+        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
+        self.rng_calls += 1
+        seed = lambda k: (self.rng_seed + 0x9E3779B97F4A7C15 * (3 * self.rng_calls + k)) & (2 ** 64 - 1)
+        L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
+                                     c_free, s_off, s_span, tr, seed(0), None,
+                                     1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
+        fl = self.flat
+        if has_zero_depth is not False:
+            # Renderer.py:104-130 for the rays without a depth measurement, on their compacted rows: coarse uniform pass through the
+            # sdf grid + decoder, importance samples, and the rows of z / pts rewritten in place.  One host sync (the row count).
+            Su = self.n_strat
+            if self.zd_rows is None or self.zd_rows.numel() < R:
+                self.zd_rows = torch.empty(R, dtype=torch.int32, device=self.device)
+                self.zd_count = torch.empty(1, dtype=torch.int32, device=self.device)
+                self.zd_z = torch.empty(R * Su, dtype=torch.float32, device=self.device)
+                self.zd_sdf, self.zd_pts = torch.empty_like(self.zd_z), torch.empty(R * Su * 3, dtype=torch.float32, device=self.device)
+            L.check(lib.us_zero_depth_rows(P(gd), R, P(self.zd_rows), P(self.zd_count), st), "us_zero_depth_rows")
+            n0 = int(self.zd_count.item())
+            if n0:
+                tr0, u0 = zero_depth_draws if zero_depth_draws is not None else (None, None)
+                tr0 = L.f32(tr0) if (tr0 is not None and self.perturb) else None
+                u0 = L.f32(u0) if u0 is not None else None
+                assert tr0 is None or tr0.numel() == n0 * Su
+                assert u0 is None or u0.numel() == n0 * self.n_imp
+                feat = self.d_feat_s                        # free until the backward pass; n0*Su <= R*S rows
+                L.check(lib.us_uniform_points(P(o), P(d), P(self.zd_rows), n0, self.bhost, P(self.t_uni), Su, P(tr0) if tr0 is not None else None,
+                                              seed(1), 1 if self.perturb else 0, P(self.zd_z), P(self.zd_pts), st), "us_uniform_points")
+                L.check(lib.us_hashgrid_fwd(ctypes.byref(self.es.desc), off(fl, self.o_tab_s), P(self.zd_pts), n0 * Su, P(feat), None, 3, st),
+                        "us_hashgrid_fwd")
+                L.check(lib.us_mlp_fwd(ctypes.byref(self.desc_s), off(fl, self.o_dec_s), P(feat), n0 * Su, P(self.zd_sdf), 1, 1, st), "us_mlp_fwd")
+                L.check(lib.us_importance_z_rows(P(self.zd_sdf), P(self.zd_z), off(fl, self.o_beta), P(u0) if u0 is not None else None, seed(2),
+                                                 n0, Su, self.n_imp, P(self.zd_rows), P(self.z), P(o), P(d), self.bhost, P(self.pts), st),
+                        "us_importance_z_rows")
         fl = self.flat
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
@@ -350,9 +367,9 @@ class MapStep:
         self.n_rays = R
         return self.loss
 
-    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False):
+    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False, zero_depth_draws=None):
         """single-process forward + backward (no optimiser step); returns loss[1]"""
-        self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
+        self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, zero_depth_draws)
         return self.backward(ray_grads=ray_grads)
 
     def ray_gradients(self):
