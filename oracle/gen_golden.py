@@ -18,6 +18,9 @@ Fixtures:
   g8_tracking  Tracker.optimize_tracking, one full iteration (dummy self)
   g9_mapping   Mapper.optimize_mapping, two full iterations incl. Adam (dummy self)
   g10_keyframes Mapper.keyframe_selection_LC (dummy self): overlap ranking, loop-closure window, tracking-back draw
+  g11_datasets  src/utils/datasets.py: the pose parsers of Replica / ScanNet / Azure / RGBDataset and TUM_RGBD.loadtum (time-stamp
+                association, frame-rate thinning, first-frame-relative poses) on small text files written here; the image decode of
+                __getitem__ needs OpenCV, which the image lacks, and is not captured
 """
 import os
 import sys
@@ -378,6 +381,94 @@ def g10():
     npz("g10_keyframes", **out)
 
 
+def g11():
+    """src/utils/datasets.py pose parsers + TUM association on generated text files (the files' text is part of the fixture)."""
+    import tempfile
+    if not hasattr(np, "unicode_"):
+        np.unicode_ = np.str_                  # alias removed in numpy 2 (datasets.py:242 still names it)
+    import src.utils.datasets as RD
+    rng = np.random.default_rng(11)
+
+    def rand_pose():
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        M = np.eye(4); M[:3, :3] = R; M[:3, 3] = rng.normal(size=3) * 2
+        return M, q
+
+    cam = dict(H=48, W=64, fx=50.0, fy=50.0, cx=31.5, cy=23.5, png_depth_scale=1000.0, crop_edge=0)
+    out, files = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        def put(rel, text):
+            path = os.path.join(tmp, rel)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(text)
+            files[rel] = text
+
+        def run(cls, name, folder, extra=None):
+            cfg = {"dataset": name, "cam": dict(cam), "data": {"input_folder": os.path.join(tmp, folder)}}
+            cfg["data"].update(extra or {})
+            return cls(cfg, types.SimpleNamespace(input_folder=None), 1.0, device="cpu")
+
+        # Replica: 5 frames, traj.txt one matrix per line (6 lines: the reader stops at n_img)
+        n = 5
+        for k in range(n):
+            put(f"replica/results/frame{k:06d}.jpg", ""); put(f"replica/results/depth{k:06d}.png", "")
+        put("replica/traj.txt", "".join(" ".join(f"{v:.17e}" for v in rand_pose()[0].reshape(-1)) + "\n" for _ in range(n + 1)))
+        ds = run(RD.Replica, "replica", "replica")
+        out["replica_poses"] = torch.stack(ds.poses)
+        out["replica_color"] = np.array([os.path.basename(p) for p in ds.color_paths])
+        # ScanNet: numeric ordering (2 < 10), pose files of 4 single-space rows
+        for k in (0, 2, 10, 1):
+            put(f"scannet/color/{k}.jpg", ""); put(f"scannet/depth/{k}.png", "")
+            put(f"scannet/pose/{k}.txt", "".join(" ".join(f"{v:.9f}" for v in row) + "\n" for row in rand_pose()[0]))
+        ds = run(RD.ScanNet, "scannet", "scannet")
+        out["scannet_poses"] = torch.stack(ds.poses)
+        out["scannet_color"] = np.array([os.path.basename(p) for p in ds.color_paths])
+        # Azure: trajectory.log, 5-line records
+        for k in range(3):
+            put(f"azure/color/{k:04d}.jpg", ""); put(f"azure/depth/{k:04d}.png", "")
+        put("azure/scene/trajectory.log", "".join(f"{k} {k} {k + 1}\n" + "".join(" ".join(f"{v:.8f}" for v in row) + "\n" for row in rand_pose()[0])
+                                                 for k in range(3)))
+        ds = run(RD.Azure, "azure", "azure")
+        out["azure_poses"] = torch.stack(ds.poses)
+        # RGBDataset: natural file order, poses.txt with a nan block, no axis flip
+        for k in (1, 2, 10):
+            put(f"rgbd/images/img{k}.png", ""); put(f"rgbd/depth_gt/d{k}.png", "")
+        blocks = ["".join(" ".join(f"{v:.7f}" for v in row) + "\n" for row in rand_pose()[0]) for _ in range(3)]
+        blocks[1] = "nan nan nan nan\n" * 4
+        put("rgbd/poses.txt", "".join(blocks))
+        ds = run(RD.RGBDataset, "systheticrgbd", "rgbd", {"depth_folder": "depth"})
+        out["rgbd_poses"] = torch.stack([torch.as_tensor(np.asarray(p, dtype=np.float32)) for p in ds.poses])
+        out["rgbd_color"] = np.array([os.path.basename(p) for p in ds.color_paths])
+        out["rgbd_depth"] = np.array([os.path.basename(p) for p in ds.depth_paths])
+        # TUM: jittered 30 Hz colour stamps (some closer than 1/32 s), depth with a hole, 100 Hz poses with a hole
+        t0 = 1305031102.175304
+        t_img = t0 + np.cumsum(np.concatenate([[0.0], 0.0333 + rng.uniform(-0.006, 0.006, size=59)]))
+        t_dep = np.array([t for k, t in enumerate(t_img + rng.uniform(-0.02, 0.02, size=60)) if not (20 <= k < 26)])
+        t_pos = np.array([t for t in np.arange(t_img[0] - 0.05, t_img[-1] + 0.05, 0.01) if not (t_img[40] - 0.02 < t < t_img[44] + 0.1)])
+        put("tum/rgb.txt", "# color images\n# file: 'x.bag'\n# timestamp filename\n" + "".join(f"{t:.6f} rgb/{t:.6f}.png\n" for t in t_img))
+        put("tum/depth.txt", "# depth maps\n# file: 'x.bag'\n# timestamp filename\n" + "".join(f"{t:.6f} depth/{t:.6f}.png\n" for t in t_dep))
+        rows = []
+        for t in t_pos:
+            M, q = rand_pose()
+            rows.append(f"{t:.4f} " + " ".join(f"{v:.4f}" for v in list(M[:3, 3]) + list(q)) + "\n")
+        put("tum/groundtruth.txt", "# ground truth trajectory\n# file: 'x.bag'\n# timestamp tx ty tz qx qy qz qw\n" + "".join(rows))
+        ds = run(RD.TUM_RGBD, "tumrgbd", "tum")
+        out["tum_poses"] = torch.stack(ds.poses)
+        out["tum_color"] = np.array([os.path.relpath(p, os.path.join(tmp, "tum")) for p in ds.color_paths])
+        out["tum_depth"] = np.array([os.path.relpath(p, os.path.join(tmp, "tum")) for p in ds.depth_paths])
+    out["cam"] = np.array([cam[k] for k in ("H", "W", "fx", "fy", "cx", "cy", "png_depth_scale", "crop_edge")], dtype=np.float64)
+    out["file_names"] = np.array(list(files.keys()))
+    out["file_texts"] = np.array(list(files.values()))
+    npz("g11_datasets", **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
-        fn()
+    only = set(sys.argv[1:])
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+        if not only or fn.__name__ in only:
+            fn()

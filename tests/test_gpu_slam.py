@@ -81,3 +81,23 @@ def test_keyframe_selection_on_device():
     assert sel == [0, 1, 2]                                                 # "global": every keyframe joins the window
     sel, pct, loop = keyframe_selection_LC(3, 10, color, depth, c2w, 2, [0, 1, 2, 3, 4], est, cam, DEV, tracking_back=True)
     assert sorted(sel) == [0, 1]                                            # tracking back: the best-overlapping ones
+
+
+def test_slam_from_a_sequence_on_disk(tmp_path):
+    """the same loop fed by the Replica-layout reader (unislam_amd.datasets) from files written by export_sequence: JPEG colour,
+    16-bit PNG depth, traj.txt poses"""
+    import unislam_amd as us
+    from unislam_amd import datasets as D
+    from unislam_amd.slam import SLAM
+    n = 12
+    slam0, frames = _build(us, n)
+    folder = D.export_sequence(frames, str(tmp_path / "room"), layout="replica", png_depth_scale=6553.5)
+    cam = dict(H=frames.H, W=frames.W, fx=frames.fx, fy=frames.fy, cx=frames.cx, cy=frames.cy, png_depth_scale=6553.5, crop_edge=0)
+    ds = D.get_dataset({"dataset": "replica", "cam": cam, "data": {"input_folder": folder}}, None, 1.0, device=DEV)
+    assert len(ds) == n and ds[0][1].device.type == "cpu"
+    H, W, fx, fy, cx, cy = ds.intrinsics()
+    slam = SLAM(ds, (H, W, fx, fy, cx, cy), slam0.es, slam0.ec, slam0.decoders, slam0.bound, cfg=slam0.cfg)
+    slam.run()
+    ate = slam.ate_rmse()
+    print("ATE from disk", ate)
+    assert ate < 0.02, ate

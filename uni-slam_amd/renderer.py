@@ -104,16 +104,17 @@ def zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, bound, t_uni, n_im
     as in the reference) merged into the uniform ones.  No gradient.  Returns z [R0, n_strat + n_imp].
     """
     with torch.no_grad():
-        far_bb = bbox_far(rays_o_uni, rays_d_uni, bound).unsqueeze(-1)
-        far_bb += 0.01
-        z_vals_uni = 0.0 * (1. - t_uni) + far_bb * t_uni
-        if perturb:
-            z_vals_uni = _perturb(z_vals_uni)
-        pts_uni = rays_o_uni.unsqueeze(1) + rays_d_uni.unsqueeze(1) * z_vals_uni.unsqueeze(-1)
-        pts_uni_nor = normalize_3d_coordinate(pts_uni.clone(), bound)
-        sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(*pts_uni.shape[0:2])
+        # far_bb + 0.01, z = far * t_uni, jitter (the draw of Renderer.py:54), normalize_3d_coordinate: one launch (us_uniform_points)
+        o, d = L.f32(rays_o_uni.detach()), L.f32(rays_d_uni.detach())
+        R0, Su = o.shape[0], t_uni.numel()
+        tr = torch.rand((R0, Su), device=device) if perturb else None
+        z_vals_uni = torch.empty((R0, Su), dtype=torch.float32, device=device)
+        pts_uni_nor = torch.empty((R0 * Su, 3), dtype=torch.float32, device=device)
+        L.check(L.lib().us_uniform_points(L.ptr(o), L.ptr(d), None, R0, bound_host(bound), L.ptr(L.f32(t_uni)), Su,
+                                          L.ptr(L.f32(tr)) if tr is not None else None, 0, 1 if perturb else 0, L.ptr(z_vals_uni),
+                                          L.ptr(pts_uni_nor), L.stream()), "us_uniform_points")
+        sdf_uni = decoders.get_raw_sdf(pts_uni_nor, scene_rep).reshape(R0, Su)
         # alpha -> weights -> un-normalised cdf -> inverse transform -> merge sort: one HIP launch (us_importance_z)
-        R0, Su = sdf_uni.shape
         u = torch.rand([R0, n_importance], device=device)                  # the draw of common.sample_pdf (:61)
         beta = decoders.beta
         beta_t = L.f32(beta.detach()).reshape(1) if torch.is_tensor(beta) else torch.tensor([float(beta)], device=device)

@@ -251,6 +251,7 @@ class SLAM:
         n = len(self.frames) if n_frames is None else n_frames
         for idx in range(n):
             _, color, depth, gt_c2w, rays_d = self.frames[idx]
+            color, depth, gt_c2w, rays_d = (t.to(self.device, non_blocking=True) for t in (color, depth, gt_c2w, rays_d))   # disk readers yield CPU tensors (UNISLAM/Tracker.py:303-306)
             self.gt_c2w_list[idx] = gt_c2w
             if idx == 0:
                 self.estimate_c2w_list[0] = gt_c2w                                       # the first pose is given (Mapper.py:479)
