@@ -21,6 +21,7 @@ Fixtures:
   g11_datasets  src/utils/datasets.py: the pose parsers of Replica / ScanNet / Azure / RGBDataset and TUM_RGBD.loadtum (time-stamp
                 association, frame-rate thinning, first-frame-relative poses) on small text files written here; the image decode of
                 __getitem__ needs OpenCV, which the image lacks, and is not captured
+  g12_ate       src/tools/eval_ate.py: align (Horn), associate, evaluate_ate, pose_evaluation on generated trajectories
 """
 import os
 import sys
@@ -467,8 +468,64 @@ def g11():
     npz("g11_datasets", **out)
 
 
+def g12():
+    """src/tools/eval_ate.py:169-236,270-281,380-552 on generated trajectories (plots go to a temporary folder)."""
+    import tempfile
+    import contextlib, io
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import src.tools.eval_ate as E
+    # pytorch3d is absent (see the header): only the translations enter the ATE, so any quaternion serves in convert_poses
+    RC.matrix_to_quaternion = lambda R: torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(R.shape[0], 1)
+    rng = np.random.default_rng(12)
+    out = {}
+    n = 60
+    t = np.linspace(0, 1, n)
+    gt = np.stack([2 * np.sin(2 * np.pi * t), 1.5 * np.cos(2 * np.pi * t) + 0.3 * t, 0.4 * np.sin(4 * np.pi * t)], 0)      # [3,n]
+    ang = 0.3
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(0.2), -np.sin(0.2)], [0, np.sin(0.2), np.cos(0.2)]])
+    cases = {
+        "noisy": Rz @ Rx @ gt + np.array([[0.5], [-0.2], [0.1]]) + rng.normal(size=gt.shape) * 0.01,
+        "drift": gt + np.cumsum(rng.normal(size=gt.shape) * 0.002, axis=1),
+        "planar": np.concatenate([gt[:2] * 0.98 + rng.normal(size=(2, n)) * 0.005, np.zeros((1, n))], 0),       # rank-2 data: the det() branch
+    }
+    gts = {"noisy": gt, "drift": gt, "planar": np.concatenate([gt[:2], np.zeros((1, n))], 0) * np.array([[1.0], [-1.0], [1.0]])}
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        for name, est in cases.items():
+            g_ = gts[name]
+            rot, trans, err = E.align(np.matrix(est), np.matrix(g_))
+            out[f"{name}_gt"], out[f"{name}_est"] = g_, est
+            out[f"{name}_rot"], out[f"{name}_trans"], out[f"{name}_err"] = np.asarray(rot), np.asarray(trans), np.asarray(err)
+            first = {i: g_[:, i] for i in range(n)}
+            second = {i: est[:, i] for i in range(n)}
+            for pa in (False, True):
+                te, res = E.evaluate_ate(first, second, os.path.join(tmp, f"{name}_{int(pa)}.png"), _args=[], pose_alignment=pa)
+                out[f"{name}_te{int(pa)}"] = np.asarray(te)
+                out[f"{name}_res{int(pa)}"] = np.array([res["compared_pose_pairs"], res["error.rmse"], res["error.mean"], res["error.median"],
+                                                        res["error.std"], res["error.max"]], dtype=np.float64)
+        # associate: unequal stamps, an offset, one stamp out of reach, a contested match
+        a = {0.00: 0, 0.10: 1, 0.20: 2, 0.31: 3, 0.50: 4}
+        b = {0.012: 0, 0.095: 1, 0.205: 2, 0.214: 3, 0.299: 4, 0.60: 5}
+        out["assoc_a"], out["assoc_b"] = np.array(list(a.keys())), np.array(list(b.keys()))
+        out["assoc_m"] = np.array(E.associate(a, b, 0.0, 0.02))
+        out["assoc_m_off"] = np.array(E.associate(a, b, -0.01, 0.02))
+        # pose_evaluation: c2w lists with an invalid given pose (ScanNet) and scale 2
+        N = 12
+        c2w_gt = O.cam_pose_to_matrix(torch.cat([torch.nn.functional.normalize(torch.as_tensor(rng.normal(size=(N, 4)), dtype=torch.float32), dim=-1),
+                                                 torch.as_tensor(gts["noisy"][:, :N].T, dtype=torch.float32)], -1))
+        c2w_est = c2w_gt.clone()
+        c2w_est[:, :3, 3] += torch.as_tensor(rng.normal(size=(N, 3)) * 0.02, dtype=torch.float32)
+        c2w_gt[5, 0, 0] = float("inf"); c2w_gt[8, 1, 3] = float("nan")
+        out["pe_gt"], out["pe_est"] = c2w_gt.clone(), c2w_est.clone()
+        te, res = E.pose_evaluation(c2w_gt.clone(), c2w_est.clone(), torch.zeros(N), os.path.join(tmp, "pe.png"), 2.0, False)
+        out["pe_te"] = np.asarray(te)
+        out["pe_res"] = np.array([res["compared_pose_pairs"], res["error.rmse"], res["error.mean"], res["error.median"], res["error.std"],
+                                  res["error.max"]], dtype=np.float64)
+    npz("g12_ate", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()

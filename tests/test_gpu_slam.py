@@ -45,6 +45,9 @@ def test_slam_recovers_the_trajectory():
     travelled = float((gt[1:, :3, 3] - gt[:-1, :3, 3]).norm(dim=-1).sum())
     assert travelled > 0.4
     assert ate < 0.02, ate                                                  # 2 cm over ~0.5 m of motion
+    _, res = slam.evaluate()                                                # the reference's report: after Horn alignment, in cm
+    print(res)
+    assert res['compared_pose_pairs'] == n and res['error.rmse'] <= 100 * ate + 0.01
     rot_err = torch.linalg.matrix_norm(est[:, :3, :3] - gt[:, :3, :3]).max()
     assert float(rot_err) < 0.05
     m = slam.mapper

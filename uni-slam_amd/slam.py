@@ -263,6 +263,12 @@ class SLAM:
                 log(idx, self)
         return self.estimate_c2w_list[:n]
 
+    def evaluate(self, n=None, pose_alignment=False):
+        """the reference's ATE report (src/tools/eval_ate.py:270-281): Horn-aligned translational error in cm -> (errors [n], results)"""
+        from .eval_ate import pose_evaluation
+        n = self.estimate_c2w_list.shape[0] if n is None else n
+        return pose_evaluation(self.gt_c2w_list[:n].cpu(), self.estimate_c2w_list[:n].cpu(), scale=1.0, pose_alignment=pose_alignment)
+
     def ate_rmse(self, n=None):
         """translation RMSE of the estimated trajectory against the given one, no alignment (frame 0 is shared)"""
         n = self.estimate_c2w_list.shape[0] if n is None else n
