@@ -22,6 +22,8 @@ Fixtures:
                 association, frame-rate thinning, first-frame-relative poses) on small text files written here; the image decode of
                 __getitem__ needs OpenCV, which the image lacks, and is not captured
   g12_ate       src/tools/eval_ate.py: align (Horn), associate, evaluate_ate, pose_evaluation on generated trajectories
+  g13_scene     src/UNISLAM.py update_cam / load_bound / get_resolution (dummy self) and the per_level_scale line of get_encoder, and
+                src/config.py load_config, for the room0 / scene0000 / fr1_desk settings (their numbers are inputs of the fixture)
 """
 import os
 import sys
@@ -524,8 +526,48 @@ def g12():
     npz("g12_ate", **out)
 
 
+def g13():
+    """src/UNISLAM.py:168-218,241 with a dummy self + src/config.py:21-53 on the reference's own config files."""
+    from src.UNISLAM import UNISLAM as RefU
+    from src import config as RCfg
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(REF)                                  # inherit_from paths are relative to the reference root
+    try:
+        for tag, path in (("room0", "configs/Replica/room0.yaml"), ("scene0000", "configs/ScanNet/scene0000.yaml"),
+                          ("fr1_desk", "configs/TUM_RGBD/freiburg1_desk.yaml")):
+            cfg = RCfg.load_config(path, "configs/UNISLAM.yaml")
+            cam = cfg["cam"]
+            me = types.SimpleNamespace(cfg=cfg, scale=cfg["scale"], shared_decoders=types.SimpleNamespace(),
+                                       H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
+            me.get_resolution = lambda c, me=me: RefU.get_resolution(me, c)
+            RefU.update_cam(me)
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                RefU.load_bound(me, cfg)
+            out[f"{tag}_bound_in"] = np.array(cfg["mapping"]["bound"], dtype=np.float64)
+            out[f"{tag}_bound"] = me.bound
+            out[f"{tag}_res"] = np.array([me.resolution_sdf, me.resolution_color])
+            out[f"{tag}_cam_in"] = np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["crop_edge"]] +
+                                            list(cam.get("crop_size", [0, 0])), dtype=np.float64)
+            out[f"{tag}_cam"] = np.array([me.H, me.W, me.fx, me.fy, me.cx, me.cy], dtype=np.float64)
+            out[f"{tag}_voxel"] = np.array([cfg["grid"]["voxel_sdf"], cfg["grid"]["voxel_color"], cfg["planes_res"]["bound_dividable"], cfg["scale"]])
+            # the per_level_scale expression of get_encoder (UNISLAM.py:241), evaluated as written there
+            n_levels = 16
+            out[f"{tag}_pls"] = np.array([np.exp2(np.log2(r / n_levels) / (n_levels - 1)) for r in (me.resolution_sdf, me.resolution_color)])
+            # merged configuration: a few leaves from each level of the inheritance chain
+            out[f"{tag}_cfg"] = np.array([cfg["tracking"]["lr_T"], cfg["tracking"]["iters"], cfg["mapping"]["pixels"], cfg["mapping"]["iters"],
+                                          cfg["mapping"]["lr"]["hash_grids_lr"], cfg["mapping"]["lr"]["decoders_lr"], cfg["grid"]["hash_size_sdf"],
+                                          cfg["grid"]["hash_size_color"], cfg["rendering"]["n_stratified"], cfg["mapping"]["w_sdf_fs"],
+                                          cfg["tracking"]["w_sdf_tail"], cfg["tracking"]["uncertainty_ts"], float(cfg["grid"]["tcnn_network"]),
+                                          float(cfg["rendering"]["learnable_beta"])], dtype=np.float64)
+    finally:
+        os.chdir(cwd)
+    npz("g13_scene", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()

@@ -87,20 +87,35 @@ def test_keyframe_selection_on_device():
 
 
 def test_slam_from_a_sequence_on_disk(tmp_path):
-    """the same loop fed by the Replica-layout reader (unislam_amd.datasets) from files written by export_sequence: JPEG colour,
-    16-bit PNG depth, traj.txt poses"""
+    """the configured system end to end: a YAML in the reference's key layout + a Replica-layout sequence on disk (JPEG colour, 16-bit
+    PNG depth, traj.txt) written by export_sequence -> config.build_slam (bound, resolutions, encoders, decoders, reader) -> run"""
+    import yaml
     import unislam_amd as us
-    from unislam_amd import datasets as D
-    from unislam_amd.slam import SLAM
+    from unislam_amd import config as C, datasets as D
+    from unislam_amd.synthetic import SyntheticRoom
+    torch.manual_seed(0)
     n = 12
-    slam0, frames = _build(us, n)
+    frames = SyntheticRoom(n_frames=n, H=120, W=160, device=DEV)
     folder = D.export_sequence(frames, str(tmp_path / "room"), layout="replica", png_depth_scale=6553.5)
-    cam = dict(H=frames.H, W=frames.W, fx=frames.fx, fy=frames.fy, cx=frames.cx, cy=frames.cy, png_depth_scale=6553.5, crop_edge=0)
-    ds = D.get_dataset({"dataset": "replica", "cam": cam, "data": {"input_folder": folder}}, None, 1.0, device=DEV)
-    assert len(ds) == n and ds[0][1].device.type == "cpu"
-    H, W, fx, fy, cx, cy = ds.intrinsics()
-    slam = SLAM(ds, (H, W, fx, fy, cx, cy), slam0.es, slam0.ec, slam0.decoders, slam0.bound, cfg=slam0.cfg)
+    w = lambda fs, c, t, d, col: {"w_sdf_fs": fs, "w_sdf_center": c, "w_sdf_tail": t, "w_depth": d, "w_color": col}
+    cfg = {"dataset": "replica", "scale": 1, "device": DEV, "m_mask_mode": "original", "t_mask_mode": "original", "grid_mode": "hash_grid",
+           "planes_res": {"bound_dividable": 0.24},
+           "grid": {"enc": "HashGrid", "hash_size_sdf": 16, "hash_size_color": 16, "voxel_sdf": 0.02, "voxel_color": 0.02, "tcnn_network": False},
+           "tracking": dict(ignore_edge_W=8, ignore_edge_H=8, const_speed_assumption=True, lr_T=0.002, lr_R=0.001, pixels=1000, iters=10,
+                            activated_mapping_mode=True, uncertainty_ts=0.001, **w(10, 200, 50, 1, 5)),
+           "mapping": dict(every_frame=2, keyframe_every=2, joint_opt=True, joint_opt_cam_lr=0.001, mapping_window_size=20, lr_first_factor=5,
+                           lr_factor=1, pixels=2000, iters_first=300, iters=20, LC=True, LC_ts=0.95, bound=[[-0.5, 6.5], [-1.1, 3.5], [-1.7, 1.5]],
+                           lr={"decoders_lr": 0.001, "hash_grids_lr": 0.05, "c_hash_grids_lr": 0.05}, **w(5, 200, 10, 0.1, 5)),
+           "cam": dict(H=frames.H, W=frames.W, fx=frames.fx, fy=frames.fy, cx=frames.cx, cy=frames.cy, png_depth_scale=6553.5, crop_edge=0),
+           "rendering": {"n_stratified": 32, "n_importance": 8, "perturb": True, "learnable_beta": True},
+           "model": {"c_dim": 32, "truncation": 0.06}, "data": {"input_folder": folder}}
+    path = tmp_path / "room.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    slam = C.build_slam(C.load_config(str(path)))
+    assert len(slam.frames) == n and slam.frames[0][1].device.type == "cpu"
+    assert tuple(slam.bound[:, 1].tolist()) == pytest.approx((6.7, 3.7, 1.66), abs=1e-5)          # enlarged to multiples of 0.24
     slam.run()
     ate = slam.ate_rmse()
-    print("ATE from disk", ate)
+    _, res = slam.evaluate()
+    print("ATE from disk", ate, res)
     assert ate < 0.02, ate
