@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
+    ap.add_argument("--packed-records", action="store_true", help="8-byte intermediate records in the table gradient (US_GRID_BWD_PACKED)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
@@ -210,7 +211,7 @@ def main():
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
-                        grad_comm=args.grad_comm, sharded_adam=args.sharded_adam)
+                        grad_comm=args.grad_comm, sharded_adam=args.sharded_adam, packed_records=args.packed_records)
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)

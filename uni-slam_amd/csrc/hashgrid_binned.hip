@@ -76,6 +76,23 @@ static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
 template <int F> struct RecW { static constexpr int DW = 1 + F; };
 static inline uint32_t rec_dwords(uint32_t F) { return 1u + F; }
 
+// US_GRID_BWD_PACKED (F = 2): 8-byte records { local entry : 11 bits | v0 : top 26 bits of the fp32 | v1 : top 27 bits },
+// round-to-nearest on the dropped 6 / 5 mantissa bits (relative 2^-18 / 2^-19 per record; the sums stay f64).  One 8-byte
+// load / store per record instead of three dwords, a third fewer bytes through the two passes.  NaN / inf survive.
+__device__ __forceinline__ uint32_t round_drop(float v, uint32_t half) {
+    const uint32_t u = __float_as_uint(v);
+    return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? u : u + half;       // NaN payloads are left alone (the add could wrap the sign)
+}
+__device__ __forceinline__ uint2 pack_rec(uint32_t loc, float v0, float v1) {
+    const uint32_t t0 = round_drop(v0, 0x20u) >> 6, t1 = round_drop(v1, 0x10u) >> 5;
+    return make_uint2(loc | (t0 << 11), (t0 >> 21) | (t1 << 5));
+}
+__device__ __forceinline__ void unpack_rec(uint2 r, uint32_t& loc, float& v0, float& v1) {
+    loc = r.x & 0x7FFu;
+    v0 = __uint_as_float(((r.y & 31u) << 27) | ((r.x >> 11) << 6));
+    v1 = __uint_as_float(r.y & ~31u);
+}
+
 // bins per level: enough for the f64 slice to fit the LDS budget (capacity) AND enough to keep every bin near
 // BIN_TARGET_RECORDS records whatever the level's size (a 4096-entry level receives as many records as a 4 MiB one)
 #ifndef BIN_TARGET_RECORDS
@@ -165,7 +182,7 @@ static BinLevels make_bin_levels(const us_grid_desc* d, const BinMap& bm) {
 // (s_waitcnt vmcnt(0)), which would drain the record stores of the previous level twice per level; the stage protocol
 // below needs only the LDS reads/writes of all waves to have completed.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int F, bool WRITE>
+template <int F, bool WRITE, bool PACKED = false>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_levels, uint32_t TB, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
                                                      uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ wg_prefix,
@@ -358,6 +375,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             const uint32_t n_lvl = lcnt[q.first + (1u << q.lg) - 1u] - lbase;
             for (uint32_t k = threadIdx.x; k < n_lvl; k += BIN_THREADS) {
                 const uint4 e = st[k];
+                if constexpr (PACKED) {
+                    static_assert(!PACKED || F == 2, "packed records carry two values");
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(rec) + ((size_t)e.x << 3)) =
+                        pack_rec(e.y, __uint_as_float(e.z), __uint_as_float(e.w));
+                    continue;
+                }
                 struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
                 RecT r;
                 r.w[0] = e.y; r.w[1] = e.z;
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
 }
 
 // B: one workgroup per bin (+ one per extra chunk of a hot bin; those come FIRST in the grid: they are the longest jobs)
-template <int F>
+template <int F, bool PACKED = false>
 __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMap bm, uint32_t n_levels, uint32_t e_max,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ extra,
                                                            const uint32_t* __restrict__ n_extra,
@@ -537,6 +560,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
             loc[buf][u] = 0xFFFFFFFFu;
             if (r < r1) {
+                if constexpr (PACKED) {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rec) + r);
+                    unpack_rec(make_uint2(w.x, w.y), loc[buf][u], v[buf][u][0], v[buf][u][F > 1 ? 1 : 0]);
+                    continue;
+                }
                 const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
                 // every record is read exactly once: non-temporal loads keep the stream out of the caches (measured -7 us)
                 loc[buf][u] = __builtin_nontemporal_load(src);
@@ -665,6 +694,9 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     dim3 gridA(n_wg), block(BIN_THREADS);
     const uint32_t L = d->n_levels;
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0, counted = (flags & US_GRID_BWD_COUNTED) ? 1 : 0;
+    const bool packed = (flags & US_GRID_BWD_PACKED) != 0;
+    US_REQUIRE(!packed || (d->n_features == 2 && bin_entries(2) <= 2048u), US_ERR_CONFIG,
+               "us_hashgrid_bwd_binned: US_GRID_BWD_PACKED needs n_features == 2 (got %u)", d->n_features);
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #ifdef US_EXP_B_TWICE
@@ -672,17 +704,23 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
 #else
 #define US_EXP_TWICE(F)
 #endif
-#define LAUNCH_BIN(F)                                                                                                          \
+#define LAUNCH_BIN_P(F, P)                                                                                                     \
     if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
     hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
                        (uint32_t)TB, totals, grad_params, overwrite);                                                          \
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
-    hipLaunchKernelGGL((k_bin<F, true>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
-    hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
+    hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
+    hipLaunchKernelGGL((k_bin_accum<F, P>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
                        grad_params, overwrite);                                                                                \
     US_EXP_TWICE(F)
-    switch (d->n_features) { case 1: LAUNCH_BIN(1) break; case 2: LAUNCH_BIN(2) break; default: LAUNCH_BIN(4) break; }
+#define LAUNCH_BIN(F) LAUNCH_BIN_P(F, false)
+    switch (d->n_features) {
+        case 1: LAUNCH_BIN(1) break;
+        case 2: if (packed) { LAUNCH_BIN_P(2, true) } else { LAUNCH_BIN(2) } break;
+        default: LAUNCH_BIN(4) break;
+    }
 #undef LAUNCH_BIN
+#undef LAUNCH_BIN_P
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
     return US_OK;
 }

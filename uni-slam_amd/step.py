@@ -35,7 +35,8 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False):
+                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
+                 packed_records=False):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -53,6 +54,8 @@ class MapStep:
         self.count_in_forward, self._counted = True, False
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
+        # 8-byte intermediate records in the binned table gradient (US_GRID_BWD_PACKED; F = 2 grids only)
+        self._packed = L.US_GRID_BWD_PACKED if (packed_records and hash_grid_sdf.desc.n_features == 2 and hash_grid_color.desc.n_features == 2) else 0
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         self.zd_rows = None                                                                # scratch of the zero-depth branch, on first use
         dev = hash_grid_sdf.params.device
@@ -326,7 +329,7 @@ class MapStep:
                                                               P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws_s), self.ws_bytes, q))
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0) | self._packed, P(self.ws_s), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
                                                                                   off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
@@ -336,7 +339,7 @@ class MapStep:
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                    3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws), self.ws_bytes, q))
+                                                                                    3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0) | self._packed, P(self.ws), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
