@@ -38,7 +38,7 @@ for grid, parity in (("color", 0), ("sdf", 1)):          # MapStep on one stream
     # 0.50 x that kernel's WRITE_SIZE.  WRITE_SIZE is exact.
     for d, c, corr in (("r01_fetch", "FETCH_SIZE", 2.0), ("r01_write", "WRITE_SIZE", 1.0)):
         rows = per_dispatch(d, c)
-        for kname in ("k_bin<2, false>", "k_bin_colscan", "k_bin_scan", "k_bin<2, true>", "k_bin_accum<2>"):
+        for kname in ("k_bin<2, false", "k_bin_colscan", "k_bin_scan", "k_bin<2, true", "k_bin_accum<2"):
             ks = [r for r in rows if kname in r["Kernel_Name"]][parity::2]
             tot += corr * sum(float(r["Counter_Value"]) for r in ks) / max(len(ks), 1) * 1024
     out[f"hashgrid_bwd_{grid}"] = tot
