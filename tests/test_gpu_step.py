@@ -140,6 +140,45 @@ def test_mapstep_bench_shape_runs_and_decreases_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_mapstep_full_size_against_oracle():
+    """BASELINE cfg2 at its full size -- 4096 rays x 64 samples (48 + 16), room0 tables (log2T 16 / 19, res 816), 2 x 32 MLP -- one
+    mapping iteration against the CPU oracle on the same rays and jitter: rendered depth / colour within 1e-3 relative (the
+    north-star bound), loss, table and decoder gradients."""
+    import unislam_amd as us
+    torch.manual_seed(5)
+    cfg = _cfg(False, 48, 16)
+    dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
+    with torch.no_grad():                                       # features large enough for a non-trivial surface
+        es.params.copy_(torch.randn(es.params.shape) * 0.2); ec.params.copy_(torch.randn(ec.params.shape) * 0.2)
+    R, S = 4096, 64
+    ro, rd, gd, gc = _rays(R, seed=6)
+    far = O.bbox_far(ro.cpu(), rd.cpu(), BOUND)
+    gd = torch.minimum(gd, 0.9 * far.to(DEV))                    # every ray inside the box: the oracle call has no pre-filter
+    t_rand = torch.rand(R, S)
+    od = O.DecodersOracle(hidden_size=32, n_blocks=2); od.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    oes, oec = O.HashGridOracle(3, _ecfg(16)), O.HashGridOracle(3, _ecfg(19))
+    with torch.no_grad():
+        oes.params.copy_(es.params.cpu()); oec.params.copy_(ec.params.cpu())
+    ret_o = O.render_batch_ray(([oes], [oec]), od, rd.cpu(), ro.cpu(), 0.06, gd.cpu(), BOUND, 48, 16, True, {"z": t_rand})
+    loss_o = O.mapping_loss(ret_o, gd.cpu(), gc.cpu(), 0.06, W)
+    loss_o.backward()
+    step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=R)
+    loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV), has_zero_depth=False)
+    term, unc, depth, rgb = [t.cpu() for t in step.rendered()[:4]]
+    np.testing.assert_allclose(depth.numpy(), ret_o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(rgb.numpy(), ret_o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
+    m_o = (gd.cpu() > 0) & ((1 - ret_o[1].detach()) > 0.99)
+    assert abs(int(step.stats[9]) - int(m_o.sum())) <= 2          # rays sitting on the 0.99 opacity threshold may flip
+    np.testing.assert_allclose(float(loss), float(loss_o), rtol=1e-3)
+    for name, g_hip, g_o in (("sdf", es.params.grad.cpu(), oes.params.grad), ("colour", ec.params.grad.cpu(), oec.params.grad)):
+        scale = g_o.abs().max().item()
+        assert torch.allclose(g_hip, g_o, rtol=5e-3, atol=2e-4 * scale), (name, float((g_hip - g_o).abs().max()), scale)
+        assert float((g_hip - g_o).norm() / g_o.norm()) < 1e-3, name
+    for (n, pa), (_, pb) in zip(od.named_parameters(), dec.named_parameters()):
+        assert torch.allclose(pb.grad.cpu(), pa.grad, rtol=5e-3, atol=2e-4 * max(1e-3, pa.grad.abs().max().item())), n
+
+
 @pytest.mark.parametrize("mode", ["original", "no_mask"])
 def test_trackstep_reproduces_reference_tracking_iteration(golden, mode):
     """TrackStep.iterate against the fixture captured from the reference's Tracker.optimize_tracking (g8)."""
