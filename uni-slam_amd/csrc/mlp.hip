@@ -24,6 +24,9 @@
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define MLP_WAVES 4                       // forward kernel
+#ifndef MLP_FWD_MAX_WG
+#define MLP_FWD_MAX_WG 512                // 2 workgroups per CU: each wave loops over a few chunks with the next one prefetched
+#endif
 #define MLP_THREADS (MLP_WAVES * 64)
 
 __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) {
@@ -194,15 +197,25 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_FWD_END];
-    load_weights<C, false, MLP_THREADS>(lds, params, has_bias != 0);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
     const float* bias = lds + C::L_B;
     const int64_t n_chunks = (n + PTS - 1) / PTS;
-    for (int64_t chunk = (int64_t)blockIdx.x * MLP_WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * MLP_WAVES) {
+    const int64_t stride = (int64_t)gridDim.x * MLP_WAVES;
+    int64_t chunk = (int64_t)blockIdx.x * MLP_WAVES + wave;
+    // the first chunk's features are requested before the weights: the two latencies overlap; inside the loop the next chunk's
+    // loads are in flight while this one goes through the MFMAs (a workgroup runs a few chunks per wave: us_mlp_fwd caps the grid)
+    v4f xn[NQ][C::KB_IN];
+    if (chunk < n_chunks) load_inputs<NQ, NIN>(in, chunk * PTS, n, row, g, xn, lm);
+    load_weights<C, false, MLP_THREADS>(lds, params, has_bias != 0);
+    __syncthreads();
+    for (; chunk < n_chunks; chunk += stride) {
         const int64_t base = chunk * PTS;
         v4f xb[NQ][C::KB_IN];
-        load_inputs<NQ, NIN>(in, base, n, row, g, xb, lm);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int b = 0; b < C::KB_IN; ++b) xb[q][b] = xn[q][b];
+        if (chunk + stride < n_chunks) load_inputs<NQ, NIN>(in, (chunk + stride) * PTS, n, row, g, xn, lm);
         v4f h0[NQ][C::MT];
         dense<NQ, C::KB_IN, C::MT, C::S_IN>(lds + C::L_W0, bias, xb, h0, row, g);
         relu_<NQ, C::MT>(h0);
@@ -537,7 +550,10 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     const int pts = (d->width == 64 && d->precision != US_PREC_BF16) ? 32 : 64;
-    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > 2048) nb = 2048;
+    // fp32: 2 workgroups per CU, each wave loops with its next chunk prefetched (21.9 vs 23.8 us at 262144 points, MI355X); the bf16
+    // kernel is shorter than its launch ramp and prefers one chunk per wave (12.2 vs 13.0 us)
+    const int64_t cap = d->precision == US_PREC_BF16 ? 2048 : MLP_FWD_MAX_WG;
+    int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
     if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
     else MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
