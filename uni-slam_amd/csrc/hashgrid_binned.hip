@@ -520,6 +520,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ extra,
                                                            const uint32_t* __restrict__ n_extra,
                                                            const uint32_t* __restrict__ rec, float* __restrict__ grad, int overwrite) {
+    // accumulators by component: acc[f * NE + loc].  (Interleaved {f0, f1} pairs put every ds_add_f64 of a wave on a 16-byte
+    // stride, i.e. on half of the banks: PMC SQ_LDS_BANK_CONFLICT was 39 % of the LDS-active cycles.)
+    constexpr uint32_t NE = BIN_ACC_DOUBLES / F;
     __shared__ double acc[BIN_ACC_DOUBLES];
     uint32_t b, chunk = 0;
     const uint32_t CH = n_extra[1];                                    // records per workgroup (k_bin_scan)
@@ -580,15 +583,17 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             if (loc[buf][u] != 0xFFFFFFFFu) {
 #pragma unroll
 #ifdef US_EXP_B_NOATOMIC
-                for (int f = 0; f < F; ++f) acc[loc[buf][u] * F + f] = (double)v[buf][u][f];
+                for (int f = 0; f < F; ++f) acc[f * NE + loc[buf][u]] = (double)v[buf][u][f];
 #else
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[loc[buf][u] * F + f], (double)v[buf][u][f]);   // ds_add_f64
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[f * NE + loc[buf][u]], (double)v[buf][u][f]);   // ds_add_f64
 #endif
             }
         }
     };
     fetch(0, r0);
-    for (uint32_t k = threadIdx.x; k < n_local * F; k += ACC_THREADS) acc[k] = 0.0;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+        for (uint32_t k = threadIdx.x; k < n_local; k += ACC_THREADS) acc[f * NE + k] = 0.0;
     __syncthreads();
     constexpr uint32_t STEP = ACC_THREADS * ACC_UNROLL;
     for (uint32_t base = r0; base < r1; base += 2 * STEP) {
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
         if (e >= hs) continue;
         float v[F]; bool any = false;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { v[f] = (float)acc[loc * F + f]; any |= (v[f] != 0.0f); }
+        for (int f = 0; f < F; ++f) { v[f] = (float)acc[f * NE + loc]; any |= (v[f] != 0.0f); }
         float* p = gl + (size_t)e * F;
         if (split) {
 #pragma unroll
