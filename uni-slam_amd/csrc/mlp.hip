@@ -291,24 +291,27 @@ __device__ __forceinline__ void bias_acc(v4f (&db)[MT], const v4f (&dh)[NQ][MT])
 // to its row of a partials workspace (plain stores; k_mlp_reduce sums the rows in a fixed order) or, without a
 // workspace, to the gradient with ONE atomic per parameter per workgroup.
 template <int MO, int MI>
-__device__ __forceinline__ void stage_wgrad(float* stage, int poff, int K, const v4f (&acc)[MO][MI], int row, int g) {
+__device__ __forceinline__ void stage_wgrad(float* stage, int poff, int K, const v4f (&acc)[MO][MI], int row, int g, bool add = false) {
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[poff + (16 * mo + 4 * g + r) * K + 16 * mi + row] = acc[mo][mi][r];
+            for (int r = 0; r < 4; ++r) {
+                float* p = stage + poff + (16 * mo + 4 * g + r) * K + 16 * mi + row;
+                *p = add ? *p + acc[mo][mi][r] : acc[mo][mi][r];
+            }
 }
 
 template <int MT>
-__device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT], int row, int g) {
+__device__ __forceinline__ void stage_bgrad(float* stage, int poff, v4f (&db)[MT], int row, int g, bool add = false) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = db[m][r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (row == 0) stage[poff + 16 * m + 4 * g + r] = v;
+            if (row == 0) stage[poff + 16 * m + 4 * g + r] = add ? stage[poff + 16 * m + 4 * g + r] + v : v;
         }
 }
 
@@ -347,7 +350,13 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ p
     }
 }
 
-#define MLP_BWD_WAVES(WIDTH) ((WIDTH) == 64 ? 4 : 8)
+#ifndef MLP_BWD_W32
+#define MLP_BWD_W32 8
+#endif
+#ifndef MLP_BWD_NQ
+#define MLP_BWD_NQ 2
+#endif
+#define MLP_BWD_WAVES(WIDTH) ((WIDTH) == 64 ? 4 : MLP_BWD_W32)
 
 template <int NIN, int WIDTH, int NHID>
 __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const float* __restrict__ params, int has_bias, int n_out,
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
                                                          const float* __restrict__ dL_dout, int64_t dout_stride,
                                                          int64_t n, float* __restrict__ dL_din,
                                                          float* __restrict__ grad_params, int lm, float* __restrict__ partials) {
-    typedef MlpCfg<NIN, WIDTH, NHID, 2, MLP_BWD_WAVES(WIDTH)> C;
+    typedef MlpCfg<NIN, WIDTH, NHID, (WIDTH == 64 ? 2 : MLP_BWD_NQ), MLP_BWD_WAVES(WIDTH)> C;
     static_assert(C::L_TOTAL_BWD <= 40960, "MLP backward exceeds 160 KiB of LDS");
     constexpr int NQ = C::NQ, PTS = C::PTS, WAVES = C::WAVES, THREADS = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float lds[C::L_TOTAL_BWD];
@@ -491,17 +500,25 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
     if (grad_params) {
 #endif
         constexpr int NP = C::N_W + C::N_B, NPP = (NP + 3) / 4 * 4;
-        static_assert(WAVES * NPP <= C::L_TOTAL_BWD, "staging area");
+        // at most 8 regions: with more waves, wave w and wave w + 8 share region w & 7 in successive rounds (store, then add)
+        constexpr int REG = WAVES < 8 ? WAVES : 8;
+        static_assert(REG * NPP <= C::L_TOTAL_BWD && WAVES % REG == 0, "staging area");
         __syncthreads();                                           // weights and scratch images are dead now: the whole LDS is stage
-        float* stage = lds + wave * NPP;
-        stage_wgrad<C::MT, C::KB_IN>(stage, C::P_W0, NIN, gW0, row, g);
-        if (NHID == 2) stage_wgrad<C::MT, C::MT>(stage, C::P_WH, WIDTH, gWH, row, g);
-        stage_wgrad<1, C::MT>(stage, C::P_WL, WIDTH, gWL, row, g);
-        stage_bgrad<C::MT>(stage, C::P_B0, gB0, row, g);
-        if (NHID == 2) stage_bgrad<C::MT>(stage, C::P_BH, gBH, row, g);
-        stage_bgrad<1>(stage, C::P_BL, gBL, row, g);
-        __syncthreads();
-        sum_wave_regions<WAVES, NP>(lds, has_bias ? NP : C::N_W, THREADS, grad_params, partials);
+        float* stage = lds + (wave % REG) * NPP;
+#pragma unroll
+        for (int round = 0; round < WAVES / REG; ++round) {
+            if (wave / REG == round) {
+                const bool add = round > 0;
+                stage_wgrad<C::MT, C::KB_IN>(stage, C::P_W0, NIN, gW0, row, g, add);
+                if (NHID == 2) stage_wgrad<C::MT, C::MT>(stage, C::P_WH, WIDTH, gWH, row, g, add);
+                stage_wgrad<1, C::MT>(stage, C::P_WL, WIDTH, gWL, row, g, add);
+                stage_bgrad<C::MT>(stage, C::P_B0, gB0, row, g, add);
+                if (NHID == 2) stage_bgrad<C::MT>(stage, C::P_BH, gBH, row, g, add);
+                stage_bgrad<1>(stage, C::P_BL, gBL, row, g, add);
+            }
+            __syncthreads();
+        }
+        sum_wave_regions<REG, NP>(lds, has_bias ? NP : C::N_W, THREADS, grad_params, partials);
     }
 }
 
@@ -579,7 +596,7 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->precision == US_PREC_BF16;
     const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
-    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : 32) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;   // one workgroup per CU
+    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;   // one workgroup per CU
     dim3 grid((unsigned)nb), block(waves * 64);
     float* partials = nullptr;
     if (grad_params && workspace) {
