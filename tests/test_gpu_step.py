@@ -3,6 +3,7 @@ GPU: MapStep (the straight-line, autograd-free mapping iteration on preallocated
 (Renderer + Decoders + losses + torch.optim.Adam) and against the CPU oracle, on identical rays and random draws.
 """
 import copy
+import os
 import types
 
 import numpy as np
@@ -280,6 +281,50 @@ def test_mapstep_single_rank_process_group_matches_plain():
         assert float(d) < 2e-2
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["plain", "sharded", "bf16"])
+def test_mapstep_two_ranks_on_one_gpu(tmp_path, variant):
+    """world_size 2 through the real kernels: two processes (gloo, both on cuda:0) run MapStep + dist.dp_iterate on their own rays --
+    global loss counts, segment-wise gradient reduction, (sharded) Adam -- and end with the parameters of ONE process that sees the
+    concatenated batch; the replicas stay identical."""
+    import socket
+    import subprocess
+    import sys
+    import unislam_amd as us
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    out = str(tmp_path / "dp")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_two_ranks.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port), out, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0].decode()[-2000:])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["flat"], r1["flat"]) if variant != "bf16" else torch.allclose(r0["flat"], r1["flat"], rtol=0, atol=0)
+    # one process, both slices
+    dec, es, ec = _scene(us, False, seed=11)
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=512)
+    parts = [_rays(256, seed=100 + r, outside=(r == 1)) for r in range(2)]
+    ro, rd, gd, gc = (torch.cat([parts[0][k], parts[1][k]]) for k in range(4))
+    t_rand = torch.cat([torch.rand(256, 40, generator=torch.Generator().manual_seed(200 + r)) for r in range(2)]).to(DEV)
+    losses = [float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)) for _ in range(3)]
+    one = step.flat.detach().cpu()
+    if variant == "bf16":
+        assert float((r0["flat"] - one).norm() / one.norm()) < 2e-2
+        np.testing.assert_allclose(r0["losses"][0], losses[0], rtol=1e-5)          # the first loss precedes any rounded gradient
+    else:
+        np.testing.assert_allclose(r0["losses"], losses, rtol=2e-4)
+        # Adam divides by sqrt(v): an entry whose gradient is at rounding level may move by up to lr in either direction
+        close = torch.isclose(r0["flat"], one, rtol=1e-4, atol=2e-5)
+        assert float((~close).float().mean()) < 1e-3, float((~close).float().mean())
+        assert float((r0["flat"] - one).norm() / one.norm()) < 1e-3
 
 
 def test_pose_kernels_match_torch_autograd():
