@@ -189,7 +189,12 @@ def main():
 
     import unislam_amd as us
     from unislam_amd.dist import init_from_env, broadcast_parameters
-    rank, local, world = init_from_env()
+    # US_BENCH_REHEARSE=1: rehearse the N > 1 code path on a one-GPU box -- every rank on cuda:0, gloo as the transport (RCCL refuses
+    # two ranks on one device).  The numbers of such a run mean nothing; it shows that the ranks start, step, agree and report.
+    rehearse = os.environ.get("US_BENCH_REHEARSE") == "1"
+    rank, local, world = init_from_env("gloo" if rehearse else None)
+    if rehearse:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
