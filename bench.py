@@ -182,6 +182,7 @@ def main():
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
     ap.add_argument("--packed-records", action="store_true", help="8-byte intermediate records in the table gradient (US_GRID_BWD_PACKED)")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1: launch every iteration eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
@@ -235,10 +236,23 @@ def main():
         step.probe = {}                 # every 10th timed step carries HIP events around the hot kernels (and runs its two
         step.probe_every = 10 if args.steps >= 50 else max(1, args.steps // 5)   # branches on one stream: the kernels' own durations)
         step._it = 0
+    # single process: the iteration is replayed from a hipGraph (MapStep.capture; same kernels, one host call, the two branch streams
+    # scheduled by the graph); every probe_every-th step runs eagerly with HIP events around its kernels, as before
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:
+        for dst, src in zip(step.capture(args.rays), (ro, rd, gd, gc)):
+            dst.copy_(src)
+        for _ in range(3):
+            step.replay()
+        pe = step.probe_every if step.probe is not None else 0
+        step.probe_every = 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step.iterate(ro, rd, gd, gc, has_zero_depth=False)
+    for k in range(args.steps):
+        if use_graph and not (pe and k % pe == 0):
+            loss = step.replay()
+        else:
+            loss = step.iterate(ro, rd, gd, gc, has_zero_depth=False)
     barrier()
     el = time.perf_counter() - t0
     t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -261,7 +275,8 @@ def main():
                           "rays_per_gpu": args.rays, "samples_per_ray": S, "points_per_gpu": N, "n_params": int(step.n_flat),
                           "parallelism": f"dp{world} (frames/rays sharded, 1 all-reduce of {(4 if args.grad_comm == 'fp32' else 2) * step.n_flat / 1e6:.1f} MB "
                                          f"{args.grad_comm} grads per step)"},
-               "rays_per_s_per_gpu": args.rays / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss)}
+               "rays_per_s_per_gpu": args.rays / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss),
+               "launch": "hipGraph replay of MapStep.iterate (every %d-th step eager with HIP-event probes)" % pe if use_graph else "eager"}
         if step.probe:
             kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in step.probe.items()}
             rec["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
@@ -297,9 +312,13 @@ def main():
             st2 = build_step("bf16")[0]
             for _ in range(args.warmup):
                 st2.iterate(ro, rd, gd, gc, has_zero_depth=False)
+            if use_graph:
+                for dst, src in zip(st2.capture(args.rays), (ro, rd, gd, gc)):
+                    dst.copy_(src)
+                st2.replay()
             torch.cuda.synchronize(); t1 = time.perf_counter()
             for _ in range(args.steps):
-                l2 = st2.iterate(ro, rd, gd, gc, has_zero_depth=False)
+                l2 = st2.replay() if use_graph else st2.iterate(ro, rd, gd, gc, has_zero_depth=False)
             torch.cuda.synchronize()
             ms2 = 1e3 * (time.perf_counter() - t1) / args.steps
             rec["bf16_decoders"] = {"ms_per_step": ms2, "rays_per_s": args.rays / (ms2 / 1e3), "final_loss": float(l2)}

@@ -301,6 +301,11 @@ int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
 int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
                           const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
                           unsigned zero_grad_mask, void* stream);
+/* The same with the step count on the device: step_dev is float[8], 8-byte aligned, zeroed for a fresh optimiser; step_dev[0] holds the
+ * count, which this call advances by one and then uses for the bias corrections (kept in the remaining words).  No argument changes from step to step, so the launch can sit in a captured hipGraph (MapStep.capture). */
+int us_adam_step_segments_dev(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
+                              const double* seg_lr, double beta1, double beta2, double eps, float* step_dev,
+                              unsigned zero_grad_mask, void* stream);
 
 /* the same with the 1-based step count in device memory (float[1]): nothing step-dependent is baked into the launch, so the
  * call can sit inside a captured hipGraph (torch.optim.Adam(capturable=True) arithmetic: bias corrections in fp32) */

@@ -559,3 +559,59 @@ def test_mapstep_with_a_table_beyond_the_bin_budget():
     ro, rd, gd, gc = _rays(1024, seed=3)
     losses = [float(step.iterate(ro, rd, gd, gc, has_zero_depth=False)) for _ in range(12)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_mapstep_graph_replay_equals_eager():
+    """MapStep.capture / replay: the captured iteration (device-side Adam step count, in-place inputs) reproduces eager iterate()
+    calls on the same rays and jitter, can be mixed with them, leaves the state alone while capturing, and is dropped by
+    reset_optimizer."""
+    import unislam_amd as us
+    R, S = 512, 40
+    ro, rd, gd, gc = _rays(R, seed=31, outside=True)
+    t_rand = torch.rand(R, S, generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs = []
+    for mode in ("eager", "graph", "mixed"):
+        dec, es, ec = _scene(us, False, seed=30)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)               # one eager step first: moments are non-zero
+        losses = []
+        if mode != "eager":
+            before = (step.flat.clone(), step.m.clone(), step.v.clone(), float(step.step_dev[0]))
+            ins = step.capture(R, t_rand=True)
+            assert torch.equal(step.flat, before[0]) and torch.equal(step.m, before[1]) and torch.equal(step.v, before[2])
+            assert float(step.step_dev[0]) == before[3] == 1.0 and step.opt_step == 1
+            for dst, src in zip(ins, (ro, rd, gd, gc, t_rand)):
+                dst.copy_(src)
+        for k in range(5):
+            if mode == "eager" or (mode == "mixed" and k % 2 == 1):
+                losses.append(float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)))
+            else:
+                losses.append(float(step.replay()))
+        assert float(step.step_dev[0]) == 6.0 and step.opt_step == 6
+        outs.append((step.flat.clone(), losses))
+        if mode == "graph":
+            # new rays written into the static inputs are what the next replay sees
+            ro2, rd2, gd2, gc2 = _rays(R, seed=77)
+            for dst, src in zip(ins, (ro2, rd2, gd2, gc2, t_rand)):
+                dst.copy_(src)
+            l_new = float(step.replay())
+            dec_b, es_b, ec_b = _scene(us, False, seed=30)
+            ref = us.MapStep(es_b, ec_b, dec_b, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+            for _ in range(6):
+                ref.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+            np.testing.assert_allclose(l_new, float(ref.iterate(ro2, rd2, gd2, gc2, t_rand=t_rand, has_zero_depth=False)), rtol=1e-5)
+            step.reset_optimizer()
+            with pytest.raises(us.UniSlamHipError):
+                step.replay()
+    for flat, losses in outs[1:]:
+        np.testing.assert_allclose(losses, outs[0][1], rtol=1e-6)
+        assert torch.allclose(flat, outs[0][0], rtol=1e-6, atol=1e-8)
+    # without t_rand the in-kernel generator draws differently in every replay (device-side counter)
+    dec, es, ec = _scene(us, False, seed=30)
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+    ins = step.capture(R)
+    for dst, src in zip(ins, (ro, rd, gd, gc)):
+        dst.copy_(src)
+    step.replay(); z1 = step.rendered()[5].clone()
+    step.replay(); z2 = step.rendered()[5].clone()
+    assert not torch.equal(z1, z2) and bool((z1[:, 1:] >= z1[:, :-1]).all())

@@ -830,12 +830,30 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // the same over up to ADAM_MAX_SEG segments of one flat parameter buffer, each with its own learning rate: one launch
 #define ADAM_MAX_SEG 8
 struct AdamSegs { int64_t off[ADAM_MAX_SEG]; int64_t n[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; };
+// step_dev != NULL: the (1-based) step count lives on the device -- k_step_inc advances step_dev[0] and leaves the bias corrections
+// beside it, formed with the host path's double arithmetic; sg.step_size then carries the plain learning rates.
+// A launch with its step count in the arguments cannot be replayed from a hipGraph; this one can.
+// step_dev: float[8] = { count, -, bc1 (double), sqrt(bc2) (double), -, - }: one thread advances the count and forms the corrections
+__global__ void k_step_inc(float* step_dev, double beta1, double beta2) {
+    const float t = step_dev[0] + 1.0f;
+    step_dev[0] = t;
+    double* aux = reinterpret_cast<double*>(step_dev + 2);
+    aux[0] = 1.0 - pow(beta1, (double)t);
+    aux[1] = sqrt(1.0 - pow(beta2, (double)t));
+}
+
 __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, AdamSegs sg, float one_minus_b1, float b2,
-                                                   float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask) {
+                                                   float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask,
+                                                   const float* __restrict__ step_dev) {
     const int64_t n = sg.n[blockIdx.y], o = sg.off[blockIdx.y];
     const bool zero = (zero_mask >> blockIdx.y) & 1u;            // optimizer.zero_grad() of this segment, folded in
-    const float step_size = sg.step_size[blockIdx.y];
+    float step_size = sg.step_size[blockIdx.y];
+    if (step_dev) {
+        const double* aux = reinterpret_cast<const double*>(step_dev + 2);
+        step_size = (float)((double)step_size / aux[0]);
+        bc2_sqrt = (float)aux[1];
+    }
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = o + k;
         // g, m, v are streamed once per step: non-temporal, so that the tables (p), which the next forward gathers from, stay cached
@@ -1277,13 +1295,13 @@ extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_
     return US_OK;
 }
 
-extern "C" int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
-                                     const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
-                                     unsigned zero_grad_mask, void* stream) {
+static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
+                         const double* seg_lr, double beta1, double beta2, double eps, int step, float* step_dev,
+                         unsigned zero_grad_mask, void* stream) {
     US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr, US_ERR_NULL, "us_adam_step_segments: NULL pointer");
     US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_segments: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
-    US_REQUIRE(step >= 1, US_ERR_SHAPE, "us_adam_step_segments: step %d (1-based)", step);
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    US_REQUIRE(step_dev || step >= 1, US_ERR_SHAPE, "us_adam_step_segments: step %d (1-based)", step);
+    const double bc1 = step_dev ? 1.0 : 1.0 - pow(beta1, (double)step), bc2 = step_dev ? 1.0 : 1.0 - pow(beta2, (double)step);
     AdamSegs sg;
     memset(&sg, 0, sizeof(sg));
     int64_t n_max = 0;
@@ -1293,11 +1311,26 @@ extern "C" int us_adam_step_segments(float* p, float* g, float* m, float* v, int
         sg.off[k] = seg_off[k]; sg.n[k] = seg_n[k]; sg.step_size[k] = (float)(seg_lr[k] / bc1);
         if (seg_n[k] > n_max) n_max = seg_n[k];
     }
+    if (step_dev) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2);      // also when no element is owned
     if (n_max == 0) return US_OK;
     hipLaunchKernelGGL(k_adam_segs, dim3(grid_1d(n_max, 256, 4096), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
+                       (const float*)step_dev);
     US_CHECK_LAUNCH("us_adam_step_segments");
     return US_OK;
+}
+
+extern "C" int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+                                     const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, int step,
+                                     unsigned zero_grad_mask, void* stream) {
+    return adam_segments(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, step, nullptr, zero_grad_mask, stream);
+}
+
+extern "C" int us_adam_step_segments_dev(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
+                                         const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps,
+                                         float* step_dev, unsigned zero_grad_mask, void* stream) {
+    US_REQUIRE(step_dev && ((uintptr_t)step_dev & 7u) == 0, US_ERR_NULL, "us_adam_step_segments_dev: step_dev is NULL or not 8-byte aligned");
+    return adam_segments(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, 0, step_dev, zero_grad_mask, stream);
 }
 
 extern "C" int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* intr_host4, int W0, int H0, int crop_w,
