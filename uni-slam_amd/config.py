@@ -18,30 +18,32 @@ from .hashgrid import HashGridEncoding
 
 
 # ---- src/config.py ------------------------------------------------------------------------------------------------
-def update_recursive(dict1, dict2):
-    """config.py:56-70: entries of dict2 override dict1, dictionaries merged level by level"""
-    for k, v in dict2.items():
-        if k not in dict1:
-            dict1[k] = dict()
-        if isinstance(v, dict):
-            update_recursive(dict1[k], v)
+def update_recursive(base, override):
+    """config.py:56-70: leaves of `override` replace those of `base`; nested dictionaries are merged level by level (in place)"""
+    for key, value in override.items():
+        if isinstance(value, dict):
+            node = base.setdefault(key, {})
+            if not isinstance(node, dict):              # a scalar in the parent gives way to a section in the child
+                node = base[key] = {}
+            update_recursive(node, value)
         else:
-            dict1[k] = v
+            base[key] = value
 
 
 def load_config(path, default_path=None):
-    """config.py:21-53: a file may name a parent (`inherit_from`), loaded first; without one `default_path` is the base"""
+    """config.py:21-53: a file may name a parent (`inherit_from`), which is loaded first (recursively); a file without a parent starts
+    from `default_path`, if one is given"""
     with open(path, "r") as f:
-        special = yaml.full_load(f)
-    parent = special.get("inherit_from")
+        own = yaml.full_load(f) or {}
+    parent = own.get("inherit_from")
     if parent is not None:
         cfg = load_config(parent, default_path)
     elif default_path is not None:
         with open(default_path, "r") as f:
-            cfg = yaml.full_load(f)
+            cfg = yaml.full_load(f) or {}
     else:
-        cfg = dict()
-    update_recursive(cfg, special)
+        cfg = {}
+    update_recursive(cfg, own)
     return cfg
 
 
