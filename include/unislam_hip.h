@@ -75,6 +75,9 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
 /* US_GRID_BWD_COUNTED (us_hashgrid_bwd_binned only): the workspace already holds the binning counts of these x, written
  * by us_hashgrid_fwd_counted with the same desc / n / clamp flag; the counting pass is skipped. */
 #define US_GRID_BWD_COUNTED 16
+/* US_GRID_BWD_SCANNED (with US_GRID_BWD_COUNTED): us_hashgrid_bwd_scan has already run on this workspace, the gradient call starts at
+ * its record pass. */
+#define US_GRID_BWD_SCANNED 64
 /* US_GRID_BWD_PACKED (us_hashgrid_bwd_binned, n_features == 2 only): the intermediate records of the binned pass are kept in 8 bytes
  * { local entry, the two contributions rounded to 26 / 27 significant fp32 bits } instead of 12; the sums are still formed in f64.
  * Relative rounding per contribution <= 2^-18: far inside the 1e-3 parity bound, but not bit-equal to the unpacked pass.
@@ -111,6 +114,13 @@ size_t us_hashgrid_bwd_workspace_bytes(const us_grid_desc* desc_host, int64_t n)
 int us_hashgrid_bwd_binned_supported(const us_grid_desc* desc_host, int64_t n);
 int us_hashgrid_bwd_binned(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n,
                            float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* The two scan passes of us_hashgrid_bwd_binned, run ahead of the gradient call on a workspace whose counts are in place
+ * (us_hashgrid_fwd_counted of the same x): they depend on the counts only, so the mapping step issues them right after the encoder, off
+ * the backward pass's critical path.  flags / grad_params as in the gradient call that follows (with US_GRID_BWD_OVERWRITE the entries
+ * of bins that several workgroups will add into are cleared HERE: grad_params must not be read between this call and the gradient
+ * call).  Then call us_hashgrid_bwd_binned with US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED. */
+int us_hashgrid_bwd_scan(const us_grid_desc* d, int64_t n, float* grad_params, int flags, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* us_hashgrid_fwd (without dy_dx) that also leaves the counts of the binned backward in `workspace` (the buffer later given to
  * us_hashgrid_bwd_binned together with US_GRID_BWD_COUNTED; same size).  The encoder is bound by its gathers, so the counting

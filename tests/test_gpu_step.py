@@ -615,3 +615,20 @@ def test_mapstep_graph_replay_equals_eager():
     step.replay(); z1 = step.rendered()[5].clone()
     step.replay(); z2 = step.rendered()[5].clone()
     assert not torch.equal(z1, z2) and bool((z1[:, 1:] >= z1[:, :-1]).all())
+
+
+def test_mapstep_scans_in_forward_option():
+    """scan_in_forward: the binning's scan passes issued right after the encoders give the same iteration"""
+    import unislam_amd as us
+    R, S = 300, 40
+    ro, rd, gd, gc = _rays(R, seed=41)
+    t_rand = torch.rand(R, S, generator=torch.Generator().manual_seed(4)).to(DEV)
+    outs = []
+    for early in (False, True):
+        dec, es, ec = _scene(us, False, seed=40)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        step.scan_in_forward = early
+        losses = [float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)) for _ in range(3)]
+        assert step._scanned == early
+        outs.append((step.flat.clone(), losses))
+    assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0])

@@ -18,6 +18,7 @@ US_GRID_BWD_OVERWRITE = 4
 US_GRID_ACCUMULATE = 8
 US_GRID_BWD_COUNTED = 16
 US_GRID_BWD_PACKED = 32
+US_GRID_BWD_SCANNED = 64
 US_MLP_LEVEL_MAJOR = 1
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
@@ -59,6 +60,7 @@ SIGNATURES = {
     "us_hashgrid_bwd_binned_supported": (c_int, [_GP, c_i64]),
     "us_hashgrid_bwd_binned": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_fwd_counted": (c_int, [_GP, c_f, c_f, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_bwd_scan": (c_int, [_GP, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_hashgrid_bwd_input_gather": (c_int, [_GP, c_f, c_f, c_f, c_i64, c_f, c_int, c_f]),
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),

@@ -659,8 +659,8 @@ extern "C" int us_hashgrid_bwd_binned_supported(const us_grid_desc* d, int64_t n
     return (TB > 0 && TB <= BIN_MAX_TOTAL) ? 1 : 0;
 }
 
-extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
-                                      int flags, void* workspace, size_t workspace_bytes, void* stream) {
+static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
+                      int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only) {
     US_REQUIRE(d, US_ERR_NULL, "us_hashgrid_bwd_binned: desc is NULL");
     US_REQUIRE(d->n_levels >= 1 && d->n_levels <= US_MAX_LEVELS && (d->n_features == 1 || d->n_features == 2 || d->n_features == 4) &&
                d->n_params == d->offset[d->n_levels] * d->n_features, US_ERR_CONFIG, "us_hashgrid_bwd_binned: bad descriptor");
@@ -672,7 +672,7 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
         }
         return US_OK;
     }
-    US_REQUIRE(x && dL_dy && grad_params && workspace, US_ERR_NULL, "us_hashgrid_bwd_binned: NULL pointer");
+    US_REQUIRE((scan_only || (x && dL_dy)) && grad_params && workspace, US_ERR_NULL, "us_hashgrid_bwd_binned: NULL pointer");
     US_REQUIRE(((uintptr_t)grad_params & 15u) == 0 && ((uintptr_t)workspace & 15u) == 0, US_ERR_SHAPE,
                "us_hashgrid_bwd_binned: grad_params and workspace must be 16-byte aligned");
     US_REQUIRE((uint64_t)n * 8ull * d->n_levels < 0xFFFFFFFFull, US_ERR_SHAPE, "us_hashgrid_bwd_binned: n too large for 32-bit record ranks");
@@ -699,7 +699,9 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
     dim3 gridA(n_wg), block(BIN_THREADS);
     const uint32_t L = d->n_levels;
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0, counted = (flags & US_GRID_BWD_COUNTED) ? 1 : 0;
-    const bool packed = (flags & US_GRID_BWD_PACKED) != 0;
+    const bool packed = (flags & US_GRID_BWD_PACKED) != 0, scanned = (flags & US_GRID_BWD_SCANNED) != 0;
+    US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
+               "us_hashgrid_bwd_binned: the scan passes can only run ahead on counts left by us_hashgrid_fwd_counted (US_GRID_BWD_COUNTED)");
     US_REQUIRE(!packed || (d->n_features == 2 && bin_entries(2) <= 2048u), US_ERR_CONFIG,
                "us_hashgrid_bwd_binned: US_GRID_BWD_PACKED needs n_features == 2 (got %u)", d->n_features);
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
@@ -711,9 +713,12 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
 #endif
 #define LAUNCH_BIN_P(F, P)                                                                                                     \
     if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
-    hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
-                       (uint32_t)TB, totals, grad_params, overwrite);                                                          \
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);                  \
+    if (!scanned) {                                                                                                            \
+        hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
+                           (uint32_t)TB, totals, grad_params, overwrite);                                                      \
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);              \
+    }                                                                                                                          \
+    if (scan_only) break;                                                                                                      \
     hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
     hipLaunchKernelGGL((k_bin_accum<F, P>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
                        grad_params, overwrite);                                                                                \
@@ -728,6 +733,17 @@ extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, con
 #undef LAUNCH_BIN_P
     US_CHECK_LAUNCH("us_hashgrid_bwd_binned");
     return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
+                                      int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    return bwd_binned(d, x, dL_dy, n, grad_params, flags, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int us_hashgrid_bwd_scan(const us_grid_desc* d, int64_t n, float* grad_params, int flags, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    return bwd_binned(d, nullptr, nullptr, n, grad_params, (flags | US_GRID_BWD_COUNTED) & ~US_GRID_BWD_SCANNED, workspace, workspace_bytes, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
