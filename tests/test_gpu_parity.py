@@ -810,13 +810,14 @@ def test_forward_counted_feeds_the_binned_backward(us, log2T, n):
         L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g1), flags | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st),
                 "bwd counted")
         assert torch.allclose(g1, g0, rtol=1e-6, atol=1e-7 * float(g0.abs().max()))
-        # the scan passes ahead of the gradient call (us_hashgrid_bwd_scan, then COUNTED | SCANNED): the same gradient, bit for bit
+        # the scan passes ahead of the gradient call (us_hashgrid_bwd_scan, then COUNTED | SCANNED): the same gradient (split bins are
+        # summed with float atomics, so up to their order)
         L.check(lib.us_hashgrid_fwd_counted(d, P(p), P(x), n, P(out), flags, P(ws), nbytes, st), "fwd counted")
         g2 = torch.full((enc.desc.n_params,), -3.0, device=DEV)
         L.check(lib.us_hashgrid_bwd_scan(d, n, P(g2), flags | L.US_GRID_BWD_OVERWRITE, P(ws), nbytes, st), "scan")
         L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g2), flags | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED,
                                            P(ws), nbytes, st), "bwd scanned")
-        assert torch.equal(g2, g1)
+        assert torch.allclose(g2, g1, rtol=1e-6, atol=1e-7 * float(g1.abs().max()))
         # SCANNED without COUNTED is a configuration error
         assert lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(g2), flags | L.US_GRID_BWD_SCANNED, P(ws), nbytes, st) == L.US_ERR_CONFIG
 

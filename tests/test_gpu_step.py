@@ -631,4 +631,6 @@ def test_mapstep_scans_in_forward_option():
         losses = [float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)) for _ in range(3)]
         assert step._scanned == early
         outs.append((step.flat.clone(), losses))
-    assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0])
+    # (bins hot enough to be split are summed with float atomics: equal up to their order)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
