@@ -1,5 +1,5 @@
 """
-Helper of tests/test_gpu_step.py::test_mapstep_two_ranks_on_one_gpu (not a test module): one data-parallel rank.
+Helper of tests/test_gpu_step.py::test_mapstep_ranks_on_one_gpu (not a test module): one data-parallel rank.
 argv: rank world port out_path variant.  Both ranks use cuda:0 and the gloo backend (RCCL refuses two ranks on one device); the
 MapStep / dist.dp_iterate code path is the one bench.py runs under torch.distributed.run.
 """
@@ -27,11 +27,11 @@ def main():
         R = 256
         step = us.MapStep(es, ec, dec, T.BOUND, 32, 8, 0.06, T.W, T.LR, max_rays=R, group=True, **kw)
         broadcast_parameters(step.flat)
-        ro, rd, gd, gc = T._rays(R, seed=100 + rank, outside=(rank == 1))        # rank 1 also has rays the pre-filter drops
+        ro, rd, gd, gc = T._rays(R, seed=100 + rank, outside=(rank % 2 == 1))    # odd ranks also have rays the pre-filter drops
         t_rand = torch.rand(R, 40, generator=torch.Generator().manual_seed(200 + rank)).to(T.DEV)
         losses = [float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)) for _ in range(3)]
         torch.cuda.synchronize()
-        torch.save({"flat": step.flat.detach().cpu(), "losses": losses}, f"{out}.{rank}")
+        torch.save({"flat": step.flat.detach().cpu(), "losses": losses, "step_dev": float(step.step_dev[0])}, f"{out}.{rank}")
     finally:
         dist.destroy_process_group()
 

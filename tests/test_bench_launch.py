@@ -1,0 +1,49 @@
+"""
+bench.py's launch contract: `python bench.py --gpus N` from a plain shell starts the N rank processes itself (the driver's
+command, BENCH_rNN.json "cmd"), the launching process never touches the GPU (it does not import torch), rank 0's JSON line is
+relayed and a failing rank makes the command fail.  BASELINE config 4 (8 ranks, RCCL) cannot run on a one-GPU box: the -m gpu
+test rehearses the same code path with every rank on cuda:0 over gloo (US_BENCH_REHEARSE=1), which shows that the ranks start,
+rendezvous, step in lock-step and report -- its numbers mean nothing.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_launcher_does_not_import_torch():
+    code = "import sys; sys.argv=['bench.py']; import bench; assert bench.torch is None; assert 'torch' not in sys.modules; print('ok')"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the failure path of a box without a GPU")
+def test_plain_multi_gpu_command_spawns_ranks_and_propagates_failure():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0                                        # no GPU here: every rank refuses, the launcher reports it
+    assert out.stderr.count("needs the MI355X") == 2, out.stderr[-2000:]   # ... and two ranks were started and rendezvoused
+    assert out.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,extra", [(2, []), (2, ["--sharded-adam"]), (4, []), (2, ["--grad-comm", "bf16"])])
+def test_plain_command_rehearsal_on_one_gpu(n, extra):
+    """n ranks on cuda:0 over gloo through bench.py's own launcher.  (At most 6 processes may use the card of a test box at once:
+    4 ranks + this process is the largest rehearsal that fits; the 8-rank protocol itself runs on the CPU in test_dist_gloo.py.)"""
+    env = dict(os.environ, US_BENCH_REHEARSE="1")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "3", "--warmup", "1", "--rays", "512", "--probe-steps", "1",
+                          "--no-tracking", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["config"]["rays_per_gpu"] == 512 and "roofline" in rec and rec["roofline"]["frac"] > 0
+    assert abs(rec["value"] - n * 512 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    assert rec["final_loss"] == rec["final_loss"]                     # not NaN

@@ -9,6 +9,7 @@ import socket
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,11 +75,12 @@ class ShardedOracleEngine(OracleEngine):
     """the same engine with flat parameter / moment buffers and adam_step(ranges): what dist._finish_sharded drives"""
     sharded_adam = True
 
-    def __init__(self):
+    def __init__(self, world=2):
         super().__init__()
         n = sum(p.numel() for p in self.params)
         self.n = n
-        self.n_pad = (n + 3) // 4 * 4                                  # two announced halves, each divisible by 2 ranks
+        q = 2 * world
+        self.n_pad = (n + q - 1) // q * q                              # two announced halves, each divisible by the ranks
         self.flat = torch.zeros(self.n_pad); self.flat[:n] = super().flat()
         self.m, self.v, self.t = torch.zeros(self.n_pad), torch.zeros(self.n_pad), 0
         self.lr = torch.zeros(self.n_pad); o = 0
@@ -117,10 +119,10 @@ class ShardedOracleEngine(OracleEngine):
 
 def _worker_sharded(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(1)
     from unislam_amd.dist import dp_iterate, init_from_env
     init_from_env(backend="gloo")
-    eng = ShardedOracleEngine()
+    eng = ShardedOracleEngine(world)
     losses = []
     for it in range(3):
         full = make_batch(48, 100 + it)
@@ -129,22 +131,24 @@ def _worker_sharded(rank, world, port, out_path):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        assert torch.equal(gathered[0], gathered[1])                  # replicas stay bit-identical
-        # the moments of the other rank's shard were never touched
-        h, q = eng.n_pad // 2, eng.n_pad // 4
+        assert all(torch.equal(gathered[0], g) for g in gathered[1:])  # replicas stay bit-identical
+        # the moments of the other ranks' shards were never touched
+        h, q = eng.n_pad // 2, eng.n_pad // (2 * world)
         assert float(eng.m[h + q:].abs().max()) == 0.0 and float(eng.m[q:h].abs().max()) == 0.0
         np.savez(out_path, flat=flat.numpy(), losses=np.array(losses))
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharded_adam_equal_one_process():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_sharded_adam_equal_one_process(world):
     """reduce-scatter + Adam on the rank's shard + all-gather (dist._finish_sharded; gloo: all-reduce stands in for the
-    reduce-scatter) gives the parameters of one process with a dense torch.optim.Adam on the concatenated batch"""
+    reduce-scatter) gives the parameters of one process with a dense torch.optim.Adam on the concatenated batch.
+    world 8 = BASELINE config 4's rank count, rehearsed on the CPU."""
     from unislam_amd.dist import dp_iterate
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "r0.npz")
-        mp.spawn(_worker_sharded, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_worker_sharded, args=(world, port, out), nprocs=world, join=True)
         res = np.load(out)
     eng = OracleEngine()
     losses = [float(dp_iterate(eng, make_batch(48, 100 + it), group=None)) for it in range(3)]
@@ -164,7 +168,7 @@ def make_batch(R, seed):
 
 def _worker(rank, world, port, out_path, grad_comm=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(1)
     from unislam_amd.dist import dp_iterate, init_from_env, shard_frames
     r, _, w = init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and shard_frames(5, rank, world) == list(range(rank, 5, world))
@@ -178,17 +182,19 @@ def _worker(rank, world, port, out_path, grad_comm=None):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        assert torch.equal(gathered[0], gathered[1])                  # replicas stay bit-identical
+        assert all(torch.equal(gathered[0], g) for g in gathered[1:])  # replicas stay bit-identical
         np.savez(out_path, flat=flat.numpy(), losses=np.array(losses))
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_equal_one_process(world):
+    """world 8 = BASELINE config 4's rank count (8 frames per step, one per rank), rehearsed on the CPU"""
     from unislam_amd.dist import dp_iterate
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "r0.npz")
-        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = np.load(out)
     eng = OracleEngine()
     losses = []

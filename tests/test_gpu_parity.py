@@ -450,6 +450,47 @@ def test_gather_rays_golden(us, golden):
     close(us.common.bbox_far(o.to(DEV), d.to(DEV), BOUND), far, 1e-6, 1e-6)
 
 
+def test_get_samples_golden(us, golden, monkeypatch):
+    """common.get_samples -> get_sample_uv -> select_uv -> get_rays_from_uv (src/common.py:168-180,133-150,109-131,95-107) on the
+    GPU against the reference's own outputs (fixture g1: s1 = one frame with a crop region, s3 = three frames, whole image).  The
+    only random draw of the chain, torch.randint at common.py:116, is replaced by the draw the fixture recorded."""
+    g = golden("g1_rays")
+    H, W, fx, fy, cx, cy = g["intr"]; H, W = int(H), int(W)
+    dev = lambda k: T(g[k]).to(DEV)
+    for tag, (H0, H1, W0, W1), n, b in (("s1", (2, H - 2, 3, W - 3), 7, 1), ("s3", (0, H, 0, W), 5, 3)):
+        idx = dev(tag + "_idx")
+        monkeypatch.setattr(torch, "randint", lambda *a, **k: idx)
+        out = us.common.get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, dev("c2w")[:b], dev("depths")[:b], dev("colors")[:b], DEV)
+        monkeypatch.undo()
+        for a, k in zip(out, ("o", "d", "depth", "color")):
+            assert a.is_cuda
+            close(a, g[f"{tag}_{k}"], 1e-6, 1e-6)
+
+
+def test_g4_decoders_on_the_fused_mlp(us, golden):
+    """the reference's torch-MLP Decoders (src/networks/decoders.py:74-84,122-128,147-153: 32 -> 16 -> 16 -> out, biases, tanh /
+    sigmoid) with its own state_dict: outputs, input gradients and every parameter gradient of fixture g4, reproduced by the
+    fused kernels (us_mlp_fwd / us_mlp_bwd through Decoders.get_raw_sdf / get_raw_rgb)."""
+    g = golden("g4_decoders")
+    dec = us.Decoders(_cfg(), c_dim=32, truncation=0.06, learnable_beta=True)
+    sd = {k.replace("__", "."): T(g[k]) for k in g if (k.startswith(("linears", "c_linears", "output_linear", "c_output_linear")) or k == "beta")}
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV)
+    fs = T(g["feat_s"]).to(DEV).requires_grad_(True); fc = T(g["feat_c"]).to(DEV).requires_grad_(True)
+    sr = ([lambda p: fs], [lambda p: fc])
+    p = torch.rand(fs.shape[0], 3, device=DEV)
+    sdf = dec.get_raw_sdf(p, sr); rgb = dec.get_raw_rgb(p, sr)
+    close(sdf, g["sdf"], 2e-5, 1e-6); close(rgb, g["rgb"], 2e-5, 1e-6)
+    ((sdf * T(g["probe_s"]).to(DEV)).sum() + (rgb * T(g["probe_c"]).to(DEV)).sum()).backward()
+    close(fs.grad, g["dfeat_s"], 1e-4, 1e-6); close(fc.grad, g["dfeat_c"], 1e-4, 1e-6)
+    n_checked = 0
+    for n, p_ in dec.named_parameters():
+        k = "grad__" + n.replace(".", "__")
+        if k in g:
+            close(p_.grad, g[k], 1e-4, 1e-5); n_checked += 1
+    assert n_checked == 12
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def _grid(us, params, log2T=10, res=64):
     enc = us.HashGridEncoding(3, enc_cfg(log2T, res)).to(DEV)

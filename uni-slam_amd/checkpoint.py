@@ -28,12 +28,16 @@ def save_checkpoint(path, slam, idx, tracking_rendered_weight_list=None, addtion
     return path
 
 
-def load_checkpoint(path, decoders, hash_grid_sdf=None, hash_grid_color=None, map_location="cpu"):
+def load_checkpoint(path, decoders, hash_grid_sdf=None, hash_grid_color=None, map_location="cpu", trusted=False):
     """
     Restores the decoders (Tracker.py:254-style `load_state_dict`) and, when present, the tables IN PLACE (the parameters may be
     views of MapStep's flat buffer).  Returns the checkpoint dict (poses, keyframe list, idx).
+    Everything save_checkpoint writes (tensors, lists, ints, plain dicts) loads under torch's weights_only unpickler, which is the
+    default here: a `.tar` from an unknown source cannot run code.  trusted=True falls back to the full unpickler, which a
+    REFERENCE checkpoint carrying arbitrary objects in tracking_rendered_weight_list / addtional_map_records needs (the
+    reference itself always loads that way).
     """
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    ck = torch.load(path, map_location=map_location, weights_only=not trusted)
     decoders.load_state_dict(ck["decoder_state_dict"])
     with torch.no_grad():
         for key, enc in (("hash_grid_sdf", hash_grid_sdf), ("hash_grid_color", hash_grid_color)):

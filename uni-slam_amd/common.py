@@ -90,10 +90,12 @@ def get_sample_uv(H0, H1, W0, W1, n, b, depths, colors, device='cuda:0'):
     return select_uv(i.t(), j.t(), n, b, depths, colors, device=device)
 
 
-def get_samples_all(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws, depths, colors, device, rays_d, indices=None):
+def get_samples_all(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws, depths, colors, device, rays_d, indices=None, out=None):
     """
     common.py:152-166.  depths [b,P], colors [b,P,3], rays_d [b,P,3] are per-frame pixel pools.
     `indices` ([b,n] int64, optional) replaces the torch.randint draw of :155 (parity tests).
+    `out` (optional): (rays_o [b*n,3], rays_d [b*n,3], depth [b*n], color [b*n,3]) fp32 tensors the kernel writes into -- the
+    static inputs of a captured iteration (MapStep.capture) are refilled this way without a copy.
     """
     b, P = depths.shape
     if indices is None:
@@ -111,9 +113,15 @@ def get_samples_all(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws, depths, color
         return ro.reshape(-1, 3), rd.reshape(-1, 3), sd.reshape(-1), sc.reshape(-1, 3)
     n_per = indices.shape[1]
     tot = b * n_per
-    ro = torch.empty((tot, 3), dtype=torch.float32, device=depths.device)
-    rd = torch.empty_like(ro); sc = torch.empty_like(ro)
-    sd = torch.empty((tot,), dtype=torch.float32, device=depths.device)
+    if out is not None:
+        ro, rd, sd, sc = out
+        if not (ro.shape == (tot, 3) and rd.shape == (tot, 3) and sd.shape == (tot,) and sc.shape == (tot, 3)
+                and all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in out)):
+            raise L.UniSlamHipError(f"get_samples_all: `out` must be contiguous fp32 GPU tensors of {tot} rays")
+    else:
+        ro = torch.empty((tot, 3), dtype=torch.float32, device=depths.device)
+        rd = torch.empty_like(ro); sc = torch.empty_like(ro)
+        sd = torch.empty((tot,), dtype=torch.float32, device=depths.device)
     c = L.f32(c2ws.detach()); pd = L.f32(depths); pc = L.f32(colors); pr = L.f32(rays_d); ix = indices.contiguous()
     L.check(L.lib().us_gather_rays(L.ptr(c), L.ptr(pd), L.ptr(pc), L.ptr(pr), L.ptr(ix), b, P, n_per, L.ptr(ro),
                                    L.ptr(rd), L.ptr(sd), L.ptr(sc), L.stream()), "us_gather_rays")
@@ -220,15 +228,14 @@ def bbox_far(rays_o, rays_d, bound):
     return far
 
 
-_bound_cache = {}
-
-
 def bound_host(bound):
-    """[3,2] tensor -> host float[6] = lo[3], hi[3] (cached: bound.cpu() would synchronise every call)."""
-    key = (bound.data_ptr(), bound.device)
-    hit = _bound_cache.get(key)
-    if hit is None:
-        b = bound.detach().float().cpu()
-        hit = L.host_floats([b[0, 0], b[1, 0], b[2, 0], b[0, 1], b[1, 1], b[2, 1]])
-        _bound_cache[key] = hit
-    return hit
+    """
+    [3,2] tensor -> host float[6] = lo[3], hi[3].  No cache: a cache keyed on data_ptr() handed a later scene's bound tensor,
+    allocated at the same address, the old scene's values.  A GPU tensor costs one synchronising copy per call, so the
+    long-lived callers (MapStep, TrackStep, Renderer) convert once in __init__ and pass the host array on; an array made by
+    this function passes through unchanged.
+    """
+    if isinstance(bound, ctypes.Array):
+        return bound
+    b = bound.detach().float().cpu()
+    return L.host_floats([b[0, 0], b[1, 0], b[2, 0], b[0, 1], b[1, 1], b[2, 1]])

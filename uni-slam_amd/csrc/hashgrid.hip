@@ -232,15 +232,10 @@ __global__ __launch_bounds__(US_SLICE_THREADS) void k_bwd_sliced(LevelTable tab,
         float pos[3] = {0.f, 0.f, 0.f}; uint32_t cell[3] = {0u, 0u, 0u};
         if (live) {
             bool any = false;
-#if defined(US_EXP_NO_LOADS)
-            for (int f = 0; f < F; ++f) { dy[f] = 1.0f; any = true; }
-            for (int k = 0; k < 3; ++k) pos_fract((float)((uint32_t)(i * 2654435761u + k * 40503u) >> 8) * (1.0f / 16777216.0f), g.scale, pos[k], cell[k]);
-#else
 #pragma unroll
             for (int f = 0; f < F; ++f) { dy[f] = dL_dy[feat_index(lm, i, n, level, C, F) + f]; any |= (dy[f] != 0.0f); }
 #pragma unroll
             for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
-#endif
             live = any;                                       // adding zeros changes nothing
         }
         if (!COMPACT && !live) continue;                      // whole waves of zero-gradient samples skip the hashing
@@ -253,13 +248,7 @@ __global__ __launch_bounds__(US_SLICE_THREADS) void k_bwd_sliced(LevelTable tab,
                     const float w = corner_weight(c, pos);
 #pragma unroll
                     for (int f = 0; f < F; ++f) {
-#if defined(US_EXP_NO_LDS_ATOMIC)
-                        acc[e * F + f] = w * dy[f];
-#elif defined(US_EXP_INT_ATOMIC)
-                        atomicAdd(reinterpret_cast<unsigned*>(&acc[e * F + f]), __float_as_uint(w * dy[f]));
-#else
                         atomicAdd(&acc[e * F + f], w * dy[f]);      // ds_add_f32: ~3 cycles per active lane
-#endif
                     }
                 }
                 continue;

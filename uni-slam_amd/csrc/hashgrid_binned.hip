@@ -25,7 +25,6 @@
 //                     the bin's lines of the gradient table are written (OVERWRITE), added to, or -- split bins -- added
 //                     with float atomics.
 // Sums are formed in double precision; the only global float atomics are those of split bins.
-// The US_EXP_* macros are measurement hooks of tools/ablate.sh (what a pass costs without its stores, atomics, sweep ...).
 #include "hashgrid_dev.h"
 #include <string.h>
 
@@ -157,11 +156,7 @@ static BinLevels make_bin_levels(const us_grid_desc* d, const BinMap& bm) {
         for (int dim = 0; dim < 3; ++dim) { if (stride <= q.hs) stride *= q.res; else early = true; }
         q.hashed = (early || q.hs < stride) ? 1u : 0u;
         q.lg = bm.log2nb[l]; q.first = bm.first[l];
-#ifdef US_EXP_NO_COMBINE
-        q.packable = 0;
-#else
         q.packable = q.res <= 1023u ? 1u : 0u;
-#endif
     }
     return r;
 }
@@ -345,11 +340,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    uint4 e;
-                    e.x = cur[c] + gd[c];
-                    e.y = idx[c];
-                    e.z = __float_as_uint(val[c][0]);
-                    e.w = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
+                    uint4 e;                                     // {local entry, values, global slot}: the record's dwords lead,
+                    e.x = idx[c];                                // so the copy-out stores v[0:2] of the ds_read_b128 as they are
+                    e.y = __float_as_uint(val[c][0]);
+                    e.z = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
+                    e.w = cur[c] + gd[c];
                     st[cur[c] - lbase] = e;
                 }
             } else {
@@ -373,24 +368,27 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             //      consecutive, so consecutive threads write consecutive 12-byte records: contiguous runs per bin.
             lds_barrier();
             const uint32_t n_lvl = lcnt[q.first + (1u << q.lg) - 1u] - lbase;
-            for (uint32_t k = threadIdx.x; k < n_lvl; k += BIN_THREADS) {
-                const uint4 e = st[k];
+            auto put = [&](const uint4 e) {
                 if constexpr (PACKED) {
                     static_assert(!PACKED || F == 2, "packed records carry two values");
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(rec) + ((size_t)e.x << 3)) =
-                        pack_rec(e.y, __uint_as_float(e.z), __uint_as_float(e.w));
-                    continue;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(rec) + ((size_t)e.w << 3)) =
+                        pack_rec(e.x, __uint_as_float(e.y), __uint_as_float(e.z));
+                } else {
+                    struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
+                    RecT r;
+                    r.w[0] = e.x; r.w[1] = e.y;
+                    if (F > 1) r.w[F > 1 ? 2 : 1] = e.z;
+                    const uint32_t byte_off = RecW<F>::DW == 3 ? (e.w << 3) + (e.w << 2) : e.w * (uint32_t)(RecW<F>::DW * 4);   // < 2^32 (host check)
+                    *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;     // (non-temporal stores: 127 vs 78 us)
                 }
-                struct __attribute__((packed, aligned(4))) RecT { uint32_t w[RecW<F>::DW]; };
-                RecT r;
-                r.w[0] = e.y; r.w[1] = e.z;
-                if (F > 1) r.w[F > 1 ? 2 : 1] = e.w;
-                const uint32_t byte_off = RecW<F>::DW == 3 ? (e.x << 3) + (e.x << 2) : e.x * (uint32_t)(RecW<F>::DW * 4);   // < 2^32 (host check)
-#ifdef US_EXP_A_NOSTORE
-                if (e.x == 0xFFFFFFF0u)
-#endif
-                *reinterpret_cast<RecT*>(reinterpret_cast<char*>(rec) + byte_off) = r;     // (non-temporal stores: 127 vs 78 us)
+            };
+            // two stage reads in flight per thread (one per iteration left every store waiting for its own LDS round trip)
+            uint32_t k = threadIdx.x;
+            for (; k + BIN_THREADS < n_lvl; k += 2 * BIN_THREADS) {
+                const uint4 e0 = st[k], e1 = st[k + BIN_THREADS];
+                put(e0); put(e1);
             }
+            if (k < n_lvl) put(st[k]);
         }
     }
     if (!WRITE) {
@@ -557,19 +555,21 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
     // Software-pipelined record stream: the loads of batch k+1 are in flight while batch k goes through the LDS atomics;
     // the first batch is requested before the accumulators are cleared.
     uint32_t loc[2][ACC_UNROLL]; float v[2][ACC_UNROLL][F];
+    // The loads are UNCONDITIONAL (a rank beyond the range re-reads the range's last record and is marked dead afterwards): a load
+    // inside `if (r < r1)` sits in its own exec-masked block, and the compiler ends every such block with s_waitcnt vmcnt(0) --
+    // one record in flight per thread instead of 2 x ACC_UNROLL (seen in the ISA of round 1's kernel).
+    const uint32_t r_last = r1 - 1u;                                  // r1 > r0 here
     auto fetch = [&](int buf, uint32_t base) {
 #pragma unroll
         for (int u = 0; u < ACC_UNROLL; ++u) {
             const uint32_t r = base + u * ACC_THREADS + threadIdx.x;
-            loc[buf][u] = 0xFFFFFFFFu;
-            if (r < r1) {
-                if constexpr (PACKED) {
-                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rec) + r);
-                    unpack_rec(make_uint2(w.x, w.y), loc[buf][u], v[buf][u][0], v[buf][u][F > 1 ? 1 : 0]);
-                    continue;
-                }
-                const uint32_t* src = rec + (size_t)r * RecW<F>::DW;
+            const uint32_t rc = min(r, r_last);
+            if constexpr (PACKED) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rec) + rc);
+                unpack_rec(make_uint2(w.x, w.y), loc[buf][u], v[buf][u][0], v[buf][u][F > 1 ? 1 : 0]);
+            } else {
+                const uint32_t* src = rec + (size_t)rc * RecW<F>::DW;
                 // every record is read exactly once: non-temporal loads keep the stream out of the caches (measured -7 us)
                 loc[buf][u] = __builtin_nontemporal_load(src);
 #pragma unroll
@@ -577,16 +577,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
             }
         }
     };
-    auto add = [&](int buf) {
+    auto add = [&](int buf, uint32_t base) {                          // the loaded registers are first touched HERE
 #pragma unroll
         for (int u = 0; u < ACC_UNROLL; ++u) {
-            if (loc[buf][u] != 0xFFFFFFFFu) {
+            if (base + u * ACC_THREADS + threadIdx.x <= r_last) {
 #pragma unroll
-#ifdef US_EXP_B_NOATOMIC
-                for (int f = 0; f < F; ++f) acc[f * NE + loc[buf][u]] = (double)v[buf][u][f];
-#else
                 for (int f = 0; f < F; ++f) atomicAdd(&acc[f * NE + loc[buf][u]], (double)v[buf][u][f]);   // ds_add_f64
-#endif
             }
         }
     };
@@ -596,18 +592,19 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
         for (uint32_t k = threadIdx.x; k < n_local; k += ACC_THREADS) acc[f * NE + k] = 0.0;
     __syncthreads();
     constexpr uint32_t STEP = ACC_THREADS * ACC_UNROLL;
-    for (uint32_t base = r0; base < r1; base += 2 * STEP) {
-        if (base + STEP < r1) fetch(1, base + STEP);
-        add(0);
-        if (base + STEP < r1) {
-            if (base + 2 * STEP < r1) fetch(0, base + 2 * STEP);
-            add(1);
-        }
+    // two buffers, the loop unrolled by two so that neither needs a register move; every fetch is unconditional (past the end it
+    // re-reads the last record, one cached line) so that no load sits behind a branch of its own
+    for (uint32_t base = r0;;) {
+        fetch(1, base + STEP);
+        add(0, base);
+        base += STEP;
+        if (base >= r1) break;
+        fetch(0, base + STEP);
+        add(1, base);
+        base += STEP;
+        if (base >= r1) break;
     }
     __syncthreads();
-#ifdef US_EXP_B_NOSWEEP
-    if (n_local != 0xFFFFFFF0u) return;
-#endif
     for (uint32_t loc = threadIdx.x; loc < n_local; loc += ACC_THREADS) {
         const uint32_t e = entry_of(loc, bl, lg);
         if (e >= hs) continue;
@@ -706,11 +703,6 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
                "us_hashgrid_bwd_binned: US_GRID_BWD_PACKED needs n_features == 2 (got %u)", d->n_features);
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
-#ifdef US_EXP_B_TWICE
-#define US_EXP_TWICE(F) hipLaunchKernelGGL((k_bin_accum<F>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, grad_params, overwrite);
-#else
-#define US_EXP_TWICE(F)
-#endif
 #define LAUNCH_BIN_P(F, P)                                                                                                     \
     if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
     if (!scanned) {                                                                                                            \
@@ -721,8 +713,7 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
     if (scan_only) break;                                                                                                      \
     hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
     hipLaunchKernelGGL((k_bin_accum<F, P>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
-                       grad_params, overwrite);                                                                                \
-    US_EXP_TWICE(F)
+                       grad_params, overwrite);
 #define LAUNCH_BIN(F) LAUNCH_BIN_P(F, false)
     switch (d->n_features) {
         case 1: LAUNCH_BIN(1) break;
@@ -816,8 +807,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
     }
     // No closing barrier: a wave that has finished its gathers leaves at once; the LAST wave to arrive (an LDS ticket taken after
     // the wave's own counter atomics, which execute in order) writes the workgroup's row segment.
+    // acq_rel at workgroup scope: the wave's counter atomics happen-before its ticket (release), and the last wave's reads of
+    // lcnt[] happen-after every ticket it observed (acquire).  At LDS scope this costs an s_waitcnt, no cache operation.
     uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&done, 1u);
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket == BIN_THREADS / 64 - 1) {
         uint32_t* row = wg_counts + (size_t)blockIdx.x * BIN_MAX_TOTAL + q.first;

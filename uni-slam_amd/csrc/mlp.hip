@@ -246,9 +246,6 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict
 template <int NQ, int MT>
 __device__ __forceinline__ void scratch_store(float* buf, const v4f (&t)[NQ][MT], int row, int g) {
     constexpr int SCR_STRIDE = 16 * NQ + 4;
-#ifdef US_EXP_MLP_NOSCRATCH
-    if (row != 12345) return;
-#endif
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -494,11 +491,7 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
             }
         }
     }
-#ifdef US_EXP_MLP_NOEPI
-    if (grad_params && n == -12345) {
-#else
     if (grad_params) {
-#endif
         constexpr int NP = C::N_W + C::N_B, NPP = (NP + 3) / 4 * 4;
         // at most 8 regions: with more waves, wave w and wave w + 8 share region w & 7 in successive rounds (store, then add)
         constexpr int REG = WAVES < 8 ? WAVES : 8;
@@ -609,11 +602,7 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     else MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                       dout_stride, n, dL_din, grad_params, lm, partials);
     US_CHECK_LAUNCH("us_mlp_bwd");
-#ifdef US_EXP_MLP_NOEPI
-    if (partials && n == -12345) {
-#else
     if (partials) {
-#endif
         const int np = (int)us_mlp_n_params(d);
         hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, s, partials, (int)nb, np, grad_params);
         US_CHECK_LAUNCH("us_mlp_bwd(reduce)");

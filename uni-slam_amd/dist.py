@@ -40,12 +40,15 @@ def dp_iterate(engine, batch, group=None, grad_comm=None):
     engine.forward(*batch)
     if group is not None:
         dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
-    if group is not None and getattr(engine, "sharded_adam", False):
-        return _finish_sharded(engine, group)
-    works = []
     if grad_comm is None:
         grad_comm = getattr(engine, "grad_comm", None)
     narrow = grad_comm in ("bf16", torch.bfloat16)
+    if group is not None and getattr(engine, "sharded_adam", False):
+        if narrow:
+            raise ValueError("dp_iterate: a bf16 gradient payload and sharded Adam are exclusive (the reduce-scatter works in place "
+                             "on the fp32 gradient buffer)")
+        return _finish_sharded(engine, group)
+    works = []
 
     def on_ready(view):
         if group is not None:

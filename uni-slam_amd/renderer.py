@@ -156,7 +156,7 @@ class Renderer(object):
         return sdf2alpha(sdf, beta)
 
     def _zero_depth_z(self, scene_rep, decoders, rays_o_uni, rays_d_uni, device):
-        return zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, self.bound, self._t_uni, self.n_importance,
+        return zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, self._bhost, self._t_uni, self.n_importance,
                             self.perturb, device)
 
     def render_batch_ray(self, scene_rep, decoders, rays_d, rays_o, device, truncation, gt_depth=None, t_rand=None):

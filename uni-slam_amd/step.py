@@ -57,6 +57,9 @@ class MapStep:
         self.scan_in_forward, self._scanned = False, False
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
+        if self.sharded_adam and grad_comm in ("bf16", torch.bfloat16):
+            raise L.UniSlamHipError("MapStep: grad_comm='bf16' and sharded_adam=True are exclusive (the reduce-scatter runs in place on "
+                                    "the fp32 gradient buffer); choose one")
         # 8-byte intermediate records in the binned table gradient (US_GRID_BWD_PACKED; F = 2 grids only)
         self._packed = L.US_GRID_BWD_PACKED if (packed_records and hash_grid_sdf.desc.n_features == 2 and hash_grid_color.desc.n_features == 2) else 0
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
@@ -144,6 +147,7 @@ class MapStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
+        self._graph = None              # a captured iteration holds the old buffers' addresses: capture() again after a reallocation
         self.z, self.pts = f(R, S), f(R, S, 3)
         self.feat_s, self.feat_c = f(N, 32), f(N, 32)
         self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
@@ -418,8 +422,8 @@ class MapStep:
                         segs.append((a, b - a, lr))
             self._dec_grad_clean = False
         if not segs:
-            return
-        k = len(segs)
+            segs = [(0, 0, 0.0)]        # a rank that owns only padding still advances the device-side step count (k_step_inc), so the
+        k = len(segs)                   # bias corrections and the sampler's jitter salt stay in lock-step over the ranks
         I64, DBL = ctypes.c_int64 * k, ctypes.c_double * k
         # the step count lives on the device (advanced by the launch itself): nothing in the arguments changes between iterations
         L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), k, I64(*[g[0] for g in segs]),
