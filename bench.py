@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="N = 1: launch every iteration eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--fixed-batch", action="store_true", help="re-render one fixed batch every step (round 1's bench) instead of a fresh draw")
     ap.add_argument("--probe-steps", type=int, default=10, help="eager iterations with HIP events around the hot kernels, after the timed region")
+    ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed iterations before the W warm-up steps (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
@@ -321,6 +322,13 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     nxt, ins = make_runner(step)
+    # set-up, before the W warm-up steps: keep the GPU busy for a fixed wall time so that the timed region does not start on a card
+    # that is still ramping its clocks after the CPU-side scene construction (a 20-step region lasts 14 ms)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(20):
+            nxt()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss = nxt()
     barrier()

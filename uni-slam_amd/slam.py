@@ -269,6 +269,20 @@ class SLAM:
         n = self.estimate_c2w_list.shape[0] if n is None else n
         return pose_evaluation(self.gt_c2w_list[:n].cpu(), self.estimate_c2w_list[:n].cpu(), scale=1.0, pose_alignment=pose_alignment)
 
+    def evaluate_rendering(self, n=None, stride=5, truncation=None):
+        """the reference's render-quality report (src/tools/eval_recon.py:235-307): PSNR and depth L1 of frames re-rendered at
+        their estimated poses -> {"avg_psnr", "depth_l1_render", "frames"}"""
+        from .eval_render import eval_rendering
+        from .renderer import Renderer
+        H, W, fx, fy, cx, cy = self.cam
+        r = self.cfg["rendering"] if "rendering" in self.cfg else {"n_stratified": 32, "n_importance": 8}
+        rend = Renderer({"rendering": {"perturb": False, "n_stratified": r["n_stratified"], "n_importance": r["n_importance"]}, "scale": 1,
+                         "grid_mode": "hash_grid"},
+                        type("U", (), dict(bound=self.bound, device=self.device, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy))())
+        n = self.estimate_c2w_list.shape[0] if n is None else n
+        tr = self.cfg["truncation"] if truncation is None else truncation
+        return eval_rendering(n, self.frames, self.estimate_c2w_list, rend, ([self.es], [self.ec]), self.decoders, tr, self.device, stride)
+
     def ate_rmse(self, n=None):
         """translation RMSE of the estimated trajectory against the given one, no alignment (frame 0 is shared)"""
         n = self.estimate_c2w_list.shape[0] if n is None else n
