@@ -128,6 +128,25 @@ int us_hashgrid_bwd_scan(const us_grid_desc* d, int64_t n, float* grad_params, i
 int us_hashgrid_fwd_counted(const us_grid_desc* desc_host, const float* params, const float* x, int64_t n, float* out,
                             int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- both grids of Uni-SLAM in one pass per direction (csrc/hashgrid_joint.hip).  src/networks/decoders.py:118,143 encode the SAME
+ * points with the sdf and the colour table, which src/UNISLAM.py:241-253 builds from one base resolution and one per-level scale:
+ * cells, fractional positions, the runs of a ray's samples and the vertex hashes coincide, only log2_hashmap_size differs.
+ * `a` / `b`: the two descriptors (F = 2, <= 16 levels, equal scale[] / resolution[]); levels where both tables are dense with equal
+ * size, or both hashed with a's size <= b's, share one 20-byte record and one bin per vertex contribution; other levels (one dense,
+ * one hashed) keep one 12-byte record per grid.  Results are those of us_hashgrid_fwd / us_hashgrid_bwd_binned on each grid. */
+int us_hashgrid_joint_supported(const us_grid_desc* a, const us_grid_desc* b, int64_t n);
+size_t us_hashgrid_joint_workspace_bytes(const us_grid_desc* a, const us_grid_desc* b, int64_t n);
+/* outA / outB = encode(x) with table a / b.  flags: US_GRID_CLAMP01, US_GRID_LEVEL_MAJOR.  workspace (nullable): when given
+ * (us_hashgrid_joint_workspace_bytes), the binning counts of these points are left in it for us_hashgrid_bwd_joint + US_GRID_BWD_COUNTED. */
+int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB, const float* x,
+                          int64_t n, float* outA, float* outB, int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* gradA / gradB (+)= scatter(dL_dyA / dL_dyB): the table gradients of both grids (autograd backward of the two encoders at
+ * src/Mapper.py:444).  dL_dy*: level-major planes [L][N][2] (US_GRID_LEVEL_MAJOR is required).  flags: US_GRID_CLAMP01,
+ * US_GRID_LEVEL_MAJOR, US_GRID_BWD_OVERWRITE, US_GRID_BWD_COUNTED.  Every point counts as carrying a gradient (zero gradients
+ * produce zero records), so the counts depend on x only. */
+int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
+                          int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
 int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,
                           float* dL_dx, void* stream);

@@ -719,3 +719,38 @@ def test_mapstep_scans_in_forward_option():
     # (bins hot enough to be split are summed with float atomics: equal up to their order)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("pair", [(14, 15), (16, 19), (16, 16)])
+def test_mapstep_joint_grids_equal_separate_grids(pair):
+    """MapStep(joint=True) -- both encoders in one launch, both table gradients in one binned pass (csrc/hashgrid_joint.hip) -- against
+    MapStep(joint=False) on the same rays and draws: bit-identical rendering, gradients equal up to one f64 -> f32 rounding, the same
+    parameters after three Adam steps; rays the pre-filter drops and rays without depth included."""
+    import unislam_amd as us
+    R, S = 700, 40
+    ro, rd, gd, gc = _rays(R, seed=21, zero_depth=True, outside=True)
+    t_rand = torch.rand(R, S, device=DEV)
+    res = {}
+    for joint in (False, True):
+        torch.manual_seed(4)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(pair[0])).to(DEV), us.HashGridEncoding(3, _ecfg(pair[1])).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, joint=joint)
+        assert step.joint == joint
+        n0 = int((gd <= 0).sum())
+        draws = (torch.rand(n0, 32, generator=torch.Generator().manual_seed(1)).to(DEV), torch.rand(n0, 8, generator=torch.Generator().manual_seed(2)).to(DEV))
+        loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, zero_depth_draws=draws)
+        out = [t.clone() for t in step.rendered()] + [step.grad.clone(), loss.clone()]
+        step.adam_step()
+        for _ in range(2):
+            step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, zero_depth_draws=draws); step.adam_step()
+        res[joint] = out + [step.flat.clone()]
+    for k in range(7):
+        assert torch.equal(res[True][k], res[False][k]), k                    # rendering: bit-identical
+    ga, gb = res[True][7], res[False][7]
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-7 * float(gb.abs().max()))
+    assert torch.equal(res[True][8], res[False][8])
+    close = torch.isclose(res[True][9], res[False][9], rtol=1e-5, atol=1e-6)
+    assert float((~close).float().mean()) < 1e-4

@@ -25,7 +25,7 @@
 //                     the bin's lines of the gradient table are written (OVERWRITE), added to, or -- split bins -- added
 //                     with float atomics.
 // Sums are formed in double precision; the only global float atomics are those of split bins.
-#include "hashgrid_dev.h"
+#include "binned_dev.h"
 #include <string.h>
 
 #ifndef BIN_THREADS
@@ -42,31 +42,11 @@
 // of f64 LDS atomics at 4.9 TB/s; 256 x 8 reaches 3.8, the LDS footprint caps the resident waves)
 #define ACC_THREADS 512
 #define ACC_UNROLL 4
-#ifndef ACC_CHUNK
-#define ACC_CHUNK 16384                  // records per accumulate workgroup: hotter bins are split (see k_bin_accum)
-#endif
-#define BIN_LINE_LOG2 4                  // bins interleave LINES of 16 entries (128 B of F = 2 gradients)
 
 struct BinMap {
     uint32_t first[US_MAX_LEVELS + 1];   // prefix sum of bins per level
     uint32_t log2nb[US_MAX_LEVELS];      // bins per level = 1 << log2nb
 };
-
-// bin = (entry / 16) mod n_bins: a bin owns every n_bins-th 128-byte line of the level's gradient slab.  Interleaving spreads
-// the hot places of the geometry (dense levels) and of the hash (whose high bits depend on y, z only) over all bins; whole
-// lines keep the final sweep of the accumulate kernel coalesced.
-__device__ __forceinline__ uint32_t bin_of(uint32_t e, uint32_t lg) { return (e >> BIN_LINE_LOG2) & ((1u << lg) - 1u); }
-__device__ __forceinline__ uint32_t local_of(uint32_t e, uint32_t lg) {
-    return ((e >> (BIN_LINE_LOG2 + lg)) << BIN_LINE_LOG2) | (e & ((1u << BIN_LINE_LOG2) - 1u));
-}
-__device__ __forceinline__ uint32_t entry_of(uint32_t loc, uint32_t bl, uint32_t lg) {
-    return ((loc >> BIN_LINE_LOG2) << (BIN_LINE_LOG2 + lg)) | (bl << BIN_LINE_LOG2) | (loc & ((1u << BIN_LINE_LOG2) - 1u));
-}
-// local entries (multiple of 16; the last line of the slab may be partial) owned by bin bl of a level with hs entries
-__host__ __device__ __forceinline__ uint32_t bin_n_local(uint32_t hs, uint32_t bl, uint32_t lg) {
-    const uint32_t lines = (hs + (1u << BIN_LINE_LOG2) - 1u) >> BIN_LINE_LOG2;
-    return bl < lines ? ((((lines - 1u - bl) >> lg) + 1u) << BIN_LINE_LOG2) : 0u;
-}
 
 static inline uint32_t bin_entries(uint32_t F) { return BIN_ACC_DOUBLES / F; }
 
@@ -124,16 +104,6 @@ static int make_binmap(const us_grid_desc* d, int64_t n, BinMap* bm) {
     return (int)total;
 }
 
-// ---- DPP row shifts (within rows of 16 lanes): shr: lane i <- lane i-n ; shl: lane i <- lane i+n
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
-    return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
-}
-#define DPP_ROW_SHL1 0x101
-#define DPP_ROW_SHR(n) (0x110 + (n))
-
 // Per-level constants of the binning passes, precomputed on the host: one s_load_dwordx8 per level.
 struct BinLevel {
     float    scale;
@@ -173,10 +143,6 @@ static BinLevels make_bin_levels(const us_grid_desc* d, const BinMap& bm) {
 //                       returning LDS atomic IS the record's final slot; the 12-byte record is stored at once.
 #define BIN_STAGE_RECORDS (BIN_THREADS * 8)   // records one workgroup emits per level at most
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
-// (s_waitcnt vmcnt(0)), which would drain the record stores of the previous level twice per level; the stage protocol
-// below needs only the LDS reads/writes of all waves to have completed.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int F, bool WRITE, bool PACKED = false>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_levels, uint32_t TB, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
@@ -466,7 +432,6 @@ __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab,
 // a bin with c > chunk records is accumulated by ceil(c / chunk) workgroups; chunk 0 belongs to the bin's own workgroup,
 // chunks 1.. are listed in extra[] as bin | chunk << 16.  chunk = ACC_CHUNK, or the multiple of it that keeps the list within
 // ACC_EXTRA_MAX entries (hdr[0] = number of extras, hdr[1] = chunk).
-#define ACC_EXTRA_MAX 256
 __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
                                                    uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr) {
     __shared__ uint32_t sh[1024];

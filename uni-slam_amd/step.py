@@ -36,12 +36,16 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False):
+                 packed_records=False, joint=None):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
         lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
         group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
+        joint: encode both grids in one launch and form both table gradients in one binned pass (us_hashgrid_fwd_joint /
+                 us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes for a single process when the pair of
+                 grids qualifies; no with a process group, where the colour table's gradient is finished FIRST so that its all-reduce
+                 hides behind the sdf branch (a joint pass would finish both tables at the same moment, with nothing left to hide behind).
         overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch;
                  default: yes for a single process; no with a process group, where the branches run one after the other so that
                  the all-reduce of the colour-table gradient hides behind the sdf branch.
@@ -51,6 +55,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
         self._dec_grad_clean = False
+        self._joint_wanted = (group is None) if joint is None else bool(joint)
         self.count_in_forward, self._counted = True, False
         # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
         # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
@@ -164,9 +169,16 @@ class MapStep:
         if self.bwd_mode == -1 and not (lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.es.desc), N) and
                                         lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.ec.desc), N)):
             self.bwd_mode = 1               # a table / batch beyond the binned path's budget: LDS-sliced kernels
+        self.joint = bool(self._joint_wanted and self.bwd_mode in (-1, 3) and not self._packed and
+                          lib.us_hashgrid_joint_supported(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
+        if self.joint:                                     # one scratch set: counts of both grids, joint records
+            self.ws_bytes = int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
+            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            self.ws_s = self.ws
         # one scratch set per branch (sdf / colour): the two branches run on two streams
         mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
-        self.ws, self.ws_s = mk_ws(), mk_ws()              # the forward pass leaves each branch's binning counts in its own
+        if not self.joint:
+            self.ws, self.ws_s = mk_ws(), mk_ws()          # the forward pass leaves each branch's binning counts in its own
         self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
                                 int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
@@ -285,6 +297,16 @@ class MapStep:
         scan = counted and self.scan_in_forward and not self._probing
         self._scanned = scan
         bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed
+        if self.joint:
+            # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
+            # then the two decoders side by side
+            self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
+                                                                                P(self.feat_s), P(self.feat_c), 3, P(self.ws), self.ws_bytes, st))
+            with self._branch() as st2:
+                self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
+            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
+            self._join()
+            return self._finish_forward(o, d, gd, gc, R)
         with self._branch() as st2:
             if counted:
                 self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd_counted(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), 3,
@@ -303,7 +325,11 @@ class MapStep:
             self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
         self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
         self._join()
-        beta = off(fl, self.o_beta)
+        return self._finish_forward(o, d, gd, gc, R)
+
+    def _finish_forward(self, o, d, gd, gc, R):
+        lib, st, P, S, fl = L.lib(), L.stream(), L.ptr, self.S, self.flat
+        beta = ctypes.c_void_p(fl.data_ptr() + 4 * self.o_beta)
         # compositing + the loss's sums and counts in one launch (+ the fixed-order reduction)
         L.check(lib.us_render_loss_fwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), self.truncation,
                                        P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.stats), st),
@@ -364,7 +390,22 @@ class MapStep:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
 
-        if self.overlap and not self._probing:
+        if self.joint:
+            # the two decoder backward passes side by side, then ONE binned pass for both tables
+            mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
+                                                                                off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                                                P(self.mlp_ws_s), self.mlp_ws_bytes, q))
+            with self._branch() as st2:
+                mlp_s(st2)
+            self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
+                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
+            self._join()
+            self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
+                                                                                off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                                                3 | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(self.ws), self.ws_bytes, st))
+            if on_ready is not None:
+                on_ready(self.grad[self.o_tab_c:])
+        elif self.overlap and not self._probing:
             with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
                 sdf_branch(st2)
             color_branch(st)
