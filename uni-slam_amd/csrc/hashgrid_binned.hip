@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         for (uint32_t t = threadIdx.x; t < TB; t += BIN_THREADS) lcnt[t] = 0u;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    const int lane = threadIdx.x & 63, lg16 = lane & (RUN_GROUP - 1);
     const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
     const bool in = i < n;
     float xv[3] = {0.f, 0.f, 0.f};
@@ -195,36 +195,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         for (int k = 0; k < 3; ++k) xv[k] = load_x(x, i, k, clamp);
     }
     typedef typename Feat<F>::T FT;
-    // The gradients of all levels of this point are fetched up front ([L][N][F] planes or rows of [N][L*F]) and held in
-    // registers, indexed by the wave-uniform level: the level loop of the writing pass must not wait on loads, because on
-    // gfx9 a wait for a load also waits for every record store issued before it (one vmcnt for both).
+    // The gradient of level l+1 is requested while level l is worked on, and CONSUMED before level l's first record store: on gfx9 a
+    // wait for a load also waits for every store issued before it (one vmcnt counter), so a load must never be waited for behind
+    // this level's stores.  (Round 1 held all levels' gradients in 2 x 32 registers instead; the vertex runs need those registers.)
     const int64_t dy_base = lm ? i * F : i * (int64_t)(n_levels * F), dy_step = lm ? n * F : (int64_t)F;
-    float dyv[US_MAX_LEVELS * F];
+    auto load_dy = [&](uint32_t level, float (&d)[F]) {
 #pragma unroll
-    for (int l = 0; l < US_MAX_LEVELS; ++l) {
-        float t[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) t[f] = 0.0f;
-        if (in && (uint32_t)l < n_levels) feat_to_array<F>(*reinterpret_cast<const FT*>(dL_dy + dy_base + (int64_t)l * dy_step), t);
-#pragma unroll
-        for (int f = 0; f < F; ++f) dyv[l * F + f] = t[f];
-    }
+        for (int f = 0; f < F; ++f) d[f] = 0.0f;
+        if (in) feat_to_array<F>(*reinterpret_cast<const FT*>(dL_dy + dy_base + (int64_t)level * dy_step), d);
+    };
+    float dn[F];
+    load_dy(0, dn);
     for (uint32_t level = 0; level < n_levels; ++level) {
         const BinLevel q = lv.l[level];
         float dy[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) dy[f] = 0.0f;
-        // static register indexing behind a scalar jump: the empty asm keeps the compiler from turning the (wave-uniform)
-        // switch into a chain of 32 x F selects, and from moving the array to scratch memory
-#define US_DY_CASE(Q) case Q: { asm volatile("" ::: "memory"); _Pragma("unroll") for (int f = 0; f < F; ++f) dy[f] = dyv[(Q) * F + f]; } break;
-        switch (level) {
-            US_DY_CASE(0) US_DY_CASE(1) US_DY_CASE(2) US_DY_CASE(3) US_DY_CASE(4) US_DY_CASE(5) US_DY_CASE(6) US_DY_CASE(7)
-            US_DY_CASE(8) US_DY_CASE(9) US_DY_CASE(10) US_DY_CASE(11) US_DY_CASE(12) US_DY_CASE(13) US_DY_CASE(14) US_DY_CASE(15)
-            US_DY_CASE(16) US_DY_CASE(17) US_DY_CASE(18) US_DY_CASE(19) US_DY_CASE(20) US_DY_CASE(21) US_DY_CASE(22) US_DY_CASE(23)
-            US_DY_CASE(24) US_DY_CASE(25) US_DY_CASE(26) US_DY_CASE(27) US_DY_CASE(28) US_DY_CASE(29) US_DY_CASE(30) US_DY_CASE(31)
-            default: break;
-        }
-#undef US_DY_CASE
+        for (int f = 0; f < F; ++f) dy[f] = dn[f];
         bool live = all_live && in;
 #pragma unroll
         for (int f = 0; f < F; ++f) live |= (dy[f] != 0.0f);
@@ -233,89 +219,67 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         // copy-out: the VALU phase of one wave overlaps the store phase of the others.
         uint32_t idx[8];
         float val[8][F];
-        bool tail = false;
+        uint32_t tail = 0u;                                      // bit p: the lane ends a run of slot p and emits its record
         if (__ballot(live) != 0ull) {                            // a wave whose samples all have zero gradient skips the level
         // ---- cell and position
         float pos[3]; uint32_t cell[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) pos_fract(xv[k], q.scale, pos[k], cell[k]);
-        // ---- runs
-        uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
-        if (!live || !q.packable) key = 0xC0000000u | (uint32_t)lane;   // never equals a packed cell, unique per lane
-        const uint32_t kprev = dpp_u32<DPP_ROW_SHR(1)>(key), knext = dpp_u32<DPP_ROW_SHL1>(key);
-        bool flag = (l8 == 0) | (kprev != key);                                  // head of a run
-        tail = live & ((l8 == 7) | (knext != key));
-        // ---- entry indices
-        if (q.hashed) {                                          // wave-uniform
-            const uint32_t hx[2] = {cell[0], cell[0] + 1u};
-            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
-            const uint32_t hy[2] = {hy0, hy0 + 2654435761u}, hz[2] = {hz0, hz0 + 805459861u};
-            const uint32_t mask = q.hs - 1u;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) idx[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask;
-        } else {
-            const uint32_t base = cell[0] + __umul24(cell[1], q.res) + __umul24(cell[2], q.res2);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t e = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? q.res : 0u) + ((c & 4) ? q.res2 : 0u);
-                idx[c] = min(e, e - q.hs);                       // e < 2*hs: one conditional subtraction == e % hs
-            }
-        }
-        // ---- corner products and their segmented scan (only the writing pass needs the values)
+        // ---- vertex runs (binned_dev.h): contributions by parity slot, runs of equal vertices over adjacent lanes
+        uint32_t key[8];
+        slot_keys(cell, live && q.packable, lane, key);
+        const uint2 ht = slot_run_masks(key, lg16);
+        uint32_t head = ht.x;
+        tail = live ? ht.y : 0u;
+        slot_entries(q.hashed != 0u, q.hs, q.res, q.res2, cell, idx);
+        // ---- slot products and their segmented scan (only the writing pass needs the values)
         if (WRITE) {
-            const float a0[2] = {1.0f - pos[0], pos[0]}, a1[2] = {1.0f - pos[1], pos[1]}, a2[2] = {1.0f - pos[2], pos[2]};
-            float wxy[4];
+            float w[8];
+            slot_weights(pos, cell, w);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wxy[c] = a0[c & 1] * a1[c >> 1];              // tcnn's order: ((1*a0)*a1)*a2
+            for (int p = 0; p < 8; ++p)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float w = wxy[c & 3] * a2[c >> 2];
-#pragma unroll
-                for (int f = 0; f < F; ++f) val[c][f] = w * dy[f];                     // dy == 0 on dead lanes
-            }
-#define US_SCAN_STEP(O)                                                                                              \
-            if (__ballot(!flag && (l8 >= (O))) != 0ull) {        /* wave-uniform: nothing left to merge -> skip the step */ \
-                const float takef = (!flag && (l8 >= (O))) ? 1.0f : 0.0f;                                            \
-                const bool fprev = dpp_u32<DPP_ROW_SHR(O)>(flag ? 1u : 0u) != 0u;                                    \
-                _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                       \
-                    _Pragma("unroll") for (int f = 0; f < F; ++f)                                                   \
-                        val[c][f] = fmaf(dpp_f32<DPP_ROW_SHR(O)>(val[c][f]), takef, val[c][f]);   /* t*1+v == t+v */  \
-                flag = flag | ((l8 >= (O)) & fprev);                                                                 \
-            }
-            US_SCAN_STEP(1)
-            US_SCAN_STEP(2)
-            US_SCAN_STEP(4)
-#undef US_SCAN_STEP
+                for (int f = 0; f < F; ++f) val[p][f] = w[p] * dy[f];                  // dy == 0 on dead lanes
+            SLOT_SCAN(F)
         }
         }   // wave has live samples
+        if (level + 1 < n_levels) load_dy(level + 1, dn);
+        auto consume_next = [&]() {                              // forces the wait for dn here, ahead of the stores that follow
+#pragma unroll
+            for (int f = 0; f < F; ++f) asm volatile("" : "+v"(dn[f]));
+        };
+        if (!STAGED) consume_next();
         if (STAGED) lds_barrier();                               // the previous level's copy-out has left the stage
-        // ---- emit: every corner of every live run tail (a corner whose weight is exactly 0 becomes a zero record, so the
-        //      counted ranges are exact)
-        if (tail) {
+        // ---- emit: one record per run end (a vertex whose weight is exactly 0 becomes a zero record, so the counted ranges are exact)
+        if (tail != 0u) {
             const uint32_t nbm = (1u << q.lg) - 1u;
             if (STAGED) {
-                // all 8 cursor atomics (and the bins' slot offsets) are in flight before the first record is staged: one LDS
+                // all cursor atomics (and the bins' slot offsets) are in flight before the first record is staged: one LDS
                 // round trip per level instead of eight
                 uint32_t cur[8], gd[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
-                    cur[c] = atomicAdd(&lcnt[b], 1u);
-                    gd[c] = gdelta[b];
-                    idx[c] = local_of(idx[c], q.lg);
+                    if ((tail >> c) & 1u) {
+                        const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
+                        cur[c] = atomicAdd(&lcnt[b], 1u);
+                        gd[c] = gdelta[b];
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    uint4 e;                                     // {local entry, values, global slot}: the record's dwords lead,
-                    e.x = idx[c];                                // so the copy-out stores v[0:2] of the ds_read_b128 as they are
-                    e.y = __float_as_uint(val[c][0]);
-                    e.z = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
-                    e.w = cur[c] + gd[c];
-                    st[cur[c] - lbase] = e;
+                    if ((tail >> c) & 1u) {
+                        uint4 e;                                 // {local entry, values, global slot}: the record's dwords lead,
+                        e.x = local_of(idx[c], q.lg);            // so the copy-out stores v[0:2] of the ds_read_b128 as they are
+                        e.y = __float_as_uint(val[c][0]);
+                        e.z = F > 1 ? __float_as_uint(val[c][F > 1 ? 1 : 0]) : 0u;
+                        e.w = cur[c] + gd[c];
+                        st[cur[c] - lbase] = e;
+                    }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
+                    if (!((tail >> c) & 1u)) continue;
                     const uint32_t b = q.first + ((idx[c] >> BIN_LINE_LOG2) & nbm);
                     if (WRITE) {
                         const uint32_t slot = atomicAdd(&lcnt[b], 1u);
@@ -332,6 +296,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
         if (STAGED) {
             // ---- copy the level's records out.  The stage holds them sorted by bin, and inside a bin the global slots are
             //      consecutive, so consecutive threads write consecutive 12-byte records: contiguous runs per bin.
+            consume_next();
             lds_barrier();
             const uint32_t n_lvl = lcnt[q.first + (1u << q.lg) - 1u] - lbase;
             auto put = [&](const uint4 e) {
@@ -723,7 +688,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
     const LevelGeom g = level_geom(tab, level);
     const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
     const uint32_t C = n_levels * F;
-    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    const int lane = threadIdx.x & 63, lg16 = lane & (RUN_GROUP - 1);
     const int64_t i = (int64_t)blockIdx.x * BIN_THREADS + threadIdx.x;
     const bool in = i < n;
     float pos[3]; uint32_t cell[3];
@@ -747,28 +712,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = res[f];
     }
-    // ---- the counts of k_bin<COUNT> with every point live (same key, same tails, same bins)
-    uint32_t key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
-    if (!in || !q.packable) key = 0xC0000000u | (uint32_t)lane;
-    const uint32_t knext = dpp_u32<DPP_ROW_SHL1>(key);               // whole wave active here
-    const bool tail = in & ((l8 == 7) | (knext != key));
-    if (tail) {
+    // ---- the counts of k_bin<COUNT> with every point live (same vertex runs, same bins)
+    uint32_t key[8];
+    slot_keys(cell, in && q.packable, lane, key);
+    const uint32_t tail = in ? slot_run_masks(key, lg16).y : 0u;     // whole wave active here
+    if (tail != 0u) {
         const uint32_t nbm = nb - 1u;
-        if (q.hashed) {
-            const uint32_t hx[2] = {cell[0], cell[0] + 1u};
-            const uint32_t hy0 = cell[1] * 2654435761u, hz0 = cell[2] * 805459861u;
-            const uint32_t hy[2] = {hy0, hy0 + 2654435761u}, hz[2] = {hz0, hz0 + 805459861u};
-            const uint32_t mask = q.hs - 1u;
+        uint32_t idx[8];
+        slot_entries(q.hashed != 0u, q.hs, q.res, q.res2, cell, idx);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) atomicAdd(&lcnt[(((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask) >> BIN_LINE_LOG2) & nbm], 1u);
-        } else {
-            const uint32_t base = cell[0] + __umul24(cell[1], q.res) + __umul24(cell[2], q.res2);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t e = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? q.res : 0u) + ((c & 4) ? q.res2 : 0u);
-                atomicAdd(&lcnt[(min(e, e - q.hs) >> BIN_LINE_LOG2) & nbm], 1u);
-            }
-        }
+        for (int c = 0; c < 8; ++c)
+            if ((tail >> c) & 1u) atomicAdd(&lcnt[(idx[c] >> BIN_LINE_LOG2) & nbm], 1u);
     }
     // No closing barrier: a wave that has finished its gathers leaves at once; the LAST wave to arrive (an LDS ticket taken after
     // the wave's own counter atomics, which execute in order) writes the workgroup's row segment.
