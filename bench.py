@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
+    ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
+                    help="both grids in one encoder launch and one binned table-gradient pass (csrc/hashgrid_joint.hip); auto = MapStep's default")
     ap.add_argument("--packed-records", action="store_true", help="8-byte intermediate records in the table gradient (US_GRID_BWD_PACKED)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: launch every iteration eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--fixed-batch", action="store_true", help="re-render one fixed batch every step (round 1's bench) instead of a fresh draw")
@@ -282,7 +284,8 @@ def run_rank(args):
                 es.params.normal_(0.0, table_std); ec.params.normal_(0.0, table_std)
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
-                        grad_comm=comm, sharded_adam=sharded, packed_records=args.packed_records)
+                        grad_comm=comm, sharded_adam=sharded, packed_records=args.packed_records,
+                        joint=None if args.joint == "auto" else args.joint == "1")
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)

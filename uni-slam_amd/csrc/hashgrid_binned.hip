@@ -510,8 +510,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_accum(LevelTable tab, BinMa
     auto add = [&](int buf, uint32_t base) {                          // the loaded registers are first touched HERE
 #pragma unroll
         for (int u = 0; u < ACC_UNROLL; ++u) {
-            if (base + u * ACC_THREADS + threadIdx.x <= r_last) {
-#pragma unroll
+            if (base + u * ACC_THREADS + threadIdx.x <= r_last && loc[buf][u] < n_local) {   // (records are always in range: the
+#pragma unroll                                                                                      //  compare keeps a bug from writing LDS out of bounds)
                 for (int f = 0; f < F; ++f) atomicAdd(&acc[f * NE + loc[buf][u]], (double)v[buf][u][f]);   // ds_add_f64
             }
         }

@@ -55,7 +55,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
         self._dec_grad_clean = False
-        self._joint_wanted = (group is None) if joint is None else bool(joint)
+        self._joint_wanted = False if joint is None else bool(joint)
         self.count_in_forward, self._counted = True, False
         # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
         # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
