@@ -35,6 +35,17 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
 #define DPP_ROW_SHL1 0x101
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
+// inclusive scan over the 64 lanes of a wave, DPP only (row scans, then row_bcast:15 / row_bcast:31 carry the row sums over)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += dpp_u32<DPP_ROW_SHR(1)>(v);
+    v += dpp_u32<DPP_ROW_SHR(2)>(v);
+    v += dpp_u32<DPP_ROW_SHR(4)>(v);
+    v += dpp_u32<DPP_ROW_SHR(8)>(v);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // rows 1, 3 += last lane of rows 0, 2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // rows 2, 3 += lane 31
+    return v;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
 // (s_waitcnt vmcnt(0)), which would drain the record stores of the previous level twice per level; the stage protocol
 // below needs only the LDS reads/writes of all waves to have completed.
@@ -139,3 +150,33 @@ __device__ __forceinline__ uint2 slot_run_masks(const uint32_t (&key)[8], int lg
         head |= (lg16 >= (O)) ? hprev : 0u;                                                                          \
     }
 #define SLOT_SCAN(NV) SLOT_SCAN_STEP(1, NV) SLOT_SCAN_STEP(2, NV) SLOT_SCAN_STEP(4, NV) SLOT_SCAN_STEP(8, NV)
+
+// The same scan in two parts, for kernels that run it for several value sets over the SAME runs (hashgrid_joint.hip: two grids):
+// SLOT_SCAN_PRE evolves the head masks once and records, per step s, which slots take from the lane O = 1 << s below (take_all, 8 bits
+// per step) and whether any lane of the wave takes at all (steps, wave-uniform); SLOT_SCAN_APPLY replays that on NV values per slot.
+#define SLOT_SCAN_PRE(head, take_all, steps)                                                                         \
+    {                                                                                                                \
+        uint32_t h_ = (head);                                                                                        \
+        (take_all) = 0u; (steps) = 0u;                                                                               \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                          \
+            const int O_ = 1 << s_;                                                                                  \
+            const uint32_t take_ = (lg16 >= O_) ? (~h_ & 0xFFu) : 0u;                                                \
+            uint32_t hp_;                                                                                            \
+            if (s_ == 0) hp_ = dpp_u32<DPP_ROW_SHR(1)>(h_); else if (s_ == 1) hp_ = dpp_u32<DPP_ROW_SHR(2)>(h_);      \
+            else if (s_ == 2) hp_ = dpp_u32<DPP_ROW_SHR(4)>(h_); else hp_ = dpp_u32<DPP_ROW_SHR(8)>(h_);              \
+            (take_all) |= take_ << (8 * s_);                                                                         \
+            if (__ballot(take_ != 0u) != 0ull) (steps) |= 1u << s_;                                                  \
+            h_ |= (lg16 >= O_) ? hp_ : 0u;                                                                           \
+        }                                                                                                            \
+    }
+#define SLOT_SCAN_APPLY_STEP(S, O, NV, take_all, steps)                                                              \
+    if ((steps) & (1u << (S))) {                                 /* wave-uniform */                                  \
+        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                             \
+            const float takef = ((take_all) >> (8 * (S) + p)) & 1u ? 1.0f : 0.0f;                                    \
+            _Pragma("unroll") for (int f = 0; f < (NV); ++f)                                                        \
+                val[p][f] = fmaf(dpp_f32<DPP_ROW_SHR(O)>(val[p][f]), takef, val[p][f]);                              \
+        }                                                                                                            \
+    }
+#define SLOT_SCAN_APPLY(NV, take_all, steps)                                                                         \
+    SLOT_SCAN_APPLY_STEP(0, 1, NV, take_all, steps) SLOT_SCAN_APPLY_STEP(1, 2, NV, take_all, steps)                  \
+    SLOT_SCAN_APPLY_STEP(2, 4, NV, take_all, steps) SLOT_SCAN_APPLY_STEP(3, 8, NV, take_all, steps)
