@@ -202,24 +202,34 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
 // scans
 // ---------------------------------------------------------------------------------------------------------------
 struct JBin { uint32_t level, kind, bl; };                       // kind: 0 joint (both grids), 1 grid A only, 2 grid B only
+// (every level is visited with a compile-time index: the level table is a kernel argument, and indexing it with a run-time value
+//  costs dependent scalar loads -- in k_jscan 128 of them per thread)
 __device__ __forceinline__ JBin j_bin_of(const JLevels& lv, uint32_t n_levels, uint32_t b) {
     JBin r;
-    r.level = 0;
-    for (uint32_t l = 1; l < n_levels; ++l) r.level += (lv.l[l].first <= b) ? 1u : 0u;
-    const JLevel& q = lv.l[r.level];
-    const uint32_t rel = b - q.first;
-    if (q.flags & J_SPLIT) {
-        const uint32_t nbA = 1u << q.lgA;
-        r.kind = rel < nbA ? 1u : 2u;
-        r.bl = rel < nbA ? rel : rel - nbA;
-    } else {
-        r.kind = 0u; r.bl = rel;
+    r.level = 0; r.kind = 0; r.bl = b;
+#pragma unroll
+    for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
+        const JLevel& q = lv.l[l];
+        if (l < n_levels && q.first <= b) {                      // the last level that starts at or before b
+            const uint32_t rel = b - q.first, nbA = 1u << q.lgA;
+            const bool split = (q.flags & J_SPLIT) != 0u;
+            r.level = l;
+            r.kind = split ? (rel < nbA ? 1u : 2u) : 0u;
+            r.bl = (split && rel >= nbA) ? rel - nbA : rel;
+        }
     }
     return r;
 }
+// the level's constants for a run-time level, by selects over compile-time indices
+__device__ __forceinline__ JLevel j_level(const JLevels& lv, uint32_t level) {
+    JLevel q = lv.l[0];
+#pragma unroll
+    for (uint32_t l = 1; l < J_MAX_LEVELS; ++l) if (l == level) q = lv.l[l];
+    return q;
+}
 
 __device__ __forceinline__ void j_clear_bin(const JLevels& lv, const JBin jb, float* gradA, float* gradB, uint32_t tid, uint32_t nthreads) {
-    const JLevel& q = lv.l[jb.level];
+    const JLevel q = j_level(lv, jb.level);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if ((s == 0 && jb.kind == 2u) || (s == 1 && jb.kind == 1u)) continue;
@@ -233,56 +243,62 @@ __device__ __forceinline__ void j_clear_bin(const JLevels& lv, const JBin jb, fl
     }
 }
 
-// column scan over the count rows: prefix[r][b] = sum of counts[r'][b] over the rows ordered before r; totals[b] = column sum.
-// 16 lanes per bin; lane j takes the rows j, j + 16, ... (the order of the rows inside a bin is lane-major: any fixed order serves).
-// In OVERWRITE mode the entries of bins that will be split over several accumulate workgroups (added with float atomics) are cleared
-// here, two kernels ahead of the first add.
-#define JCS_THREADS 64
-#define JCS_LANES 16
-#define JCS_BINS (JCS_THREADS / JCS_LANES)
+// column scan over the count rows: prefix[r][b] = sum of counts[r'][b] over the rows r' < r; totals[b] = column sum.
+// One 1024-thread workgroup per tile of 16 bins: a wave reads 4 rows x 16 bins (four 64-byte segments) per load, wave w owns a
+// contiguous block of rows and keeps its counts in registers; the blocks' sums are scanned through LDS, then every lane turns its
+// counts into prefixes (scan over the 4 rows of a load with two shuffles, running sum over the loads) and stores them the way it
+// loaded them.  One read and one write of the matrix.  In OVERWRITE mode the entries of bins that will be split over several
+// accumulate workgroups (added with float atomics) are cleared here, two kernels ahead of the first add.
+#define JCS_THREADS 1024
+#define JCS_BINS 16
+#define JCS_ITERS 8                      // loads per lane: a workgroup covers 16 waves x 8 loads x 4 rows = 512 rows per pass
 __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n_levels, const uint32_t* __restrict__ counts,
                                                           uint32_t* __restrict__ prefix, uint32_t n_rows, uint32_t row_stride, uint32_t TB,
                                                           uint32_t* __restrict__ totals, float* __restrict__ gradA, float* __restrict__ gradB,
                                                           int overwrite) {
-    const uint32_t j = threadIdx.x & (JCS_LANES - 1);
-    const uint32_t b = blockIdx.x * JCS_BINS + (threadIdx.x / JCS_LANES);
-    const bool ok = b < TB;
-    uint32_t sum = 0;
-    if (ok) {
-        uint32_t w = j;
-        for (; w + 7 * JCS_LANES < n_rows; w += 8 * JCS_LANES) {
-            uint32_t v[8];
+    __shared__ uint32_t part[JCS_THREADS / 64][JCS_BINS];
+    __shared__ uint32_t carry[JCS_BINS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, rsub = lane >> 4, bcol = lane & 15u;
+    const uint32_t b = blockIdx.x * JCS_BINS + bcol;
+    const bool okb = b < TB;
+    if (threadIdx.x < JCS_BINS) carry[threadIdx.x] = 0u;
+    constexpr uint32_t PASS_ROWS = (JCS_THREADS / 64) * JCS_ITERS * 4;
+    for (uint32_t row0 = 0; row0 < n_rows; row0 += PASS_ROWS) {      // one pass for up to 512 rows (262 144 points)
+        const uint32_t rbase = row0 + wave * (JCS_ITERS * 4) + rsub;
+        uint32_t v[JCS_ITERS], sum = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = counts[(size_t)(w + JCS_LANES * k) * row_stride + b];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sum += v[k];
+        for (int k = 0; k < JCS_ITERS; ++k) {
+            const uint32_t r = rbase + 4u * k;
+            v[k] = (okb && r < n_rows) ? counts[(size_t)r * row_stride + b] : 0u;
         }
-        for (; w < n_rows; w += JCS_LANES) sum += counts[(size_t)w * row_stride + b];
-    }
-    uint32_t incl = sum;
 #pragma unroll
-    for (int o = 1; o < JCS_LANES; o <<= 1) { const uint32_t t = __shfl_up(incl, o, JCS_LANES); if ((int)j >= o) incl += t; }
-    const uint32_t total = __shfl(incl, JCS_LANES - 1, JCS_LANES);
-    if (ok) {
-        uint32_t run = incl - sum;
-        uint32_t w = j;
-        for (; w + 7 * JCS_LANES < n_rows; w += 8 * JCS_LANES) {
-            uint32_t v[8];
+        for (int k = 0; k < JCS_ITERS; ++k) sum += v[k];
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);         // over the 4 rows of a load: the wave's block sum per bin
+        __syncthreads();                                                        // carry[] of the previous pass is in place / consumed
+        if (rsub == 0) part[wave][bcol] = sum;
+        __syncthreads();
+        uint32_t before = carry[bcol];
+        for (uint32_t w = 0; w < wave; ++w) before += part[w][bcol];
+        // prefixes: rows of one load are r, r+1, r+2, r+3 in the lanes rsub = 0..3
+        uint32_t run = before;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = counts[(size_t)(w + JCS_LANES * k) * row_stride + b];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { prefix[(size_t)(w + JCS_LANES * k) * row_stride + b] = run; run += v[k]; }
+        for (int k = 0; k < JCS_ITERS; ++k) {
+            const uint32_t up1 = __shfl_up(v[k], 16, 64), up2 = __shfl_up(v[k], 32, 64), up3 = __shfl_up(v[k], 48, 64);
+            const uint32_t excl = (rsub >= 1 ? up1 : 0u) + (rsub >= 2 ? up2 : 0u) + (rsub >= 3 ? up3 : 0u);
+            const uint32_t r = rbase + 4u * k;
+            if (okb && r < n_rows) prefix[(size_t)r * row_stride + b] = run + excl;
+            const uint32_t all4 = __shfl(excl + v[k], (int)(48u + bcol), 64);      // the 4 rows' sum sits in the lane rsub = 3
+            run += all4;
         }
-        for (; w < n_rows; w += JCS_LANES) { const uint32_t v = counts[(size_t)w * row_stride + b]; prefix[(size_t)w * row_stride + b] = run; run += v; }
-        if (j == 0) totals[b] = total;
+        __syncthreads();
+        if (wave == JCS_THREADS / 64 - 1 && rsub == 0) carry[bcol] = run;        // the last wave's running sum = everything so far
     }
+    __syncthreads();
+    if (threadIdx.x < JCS_BINS && blockIdx.x * JCS_BINS + threadIdx.x < TB) totals[blockIdx.x * JCS_BINS + threadIdx.x] = carry[threadIdx.x];
     if (!overwrite) return;
-    unsigned long long hot = __ballot(ok && j == 0 && total > ACC_CHUNK);
-    while (hot) {                                                // wave-uniform loop (one wave per workgroup)
-        const int src = __ffsll((long long)hot) - 1;
-        hot &= hot - 1ull;
-        const uint32_t hb = blockIdx.x * JCS_BINS + ((uint32_t)src / JCS_LANES);
-        j_clear_bin(lv, j_bin_of(lv, n_levels, hb), gradA, gradB, threadIdx.x, JCS_THREADS);
+    for (uint32_t k = 0; k < JCS_BINS; ++k) {                                    // workgroup-uniform
+        const uint32_t hb = blockIdx.x * JCS_BINS + k;
+        if (hb < TB && carry[k] > ACC_CHUNK) j_clear_bin(lv, j_bin_of(lv, n_levels, hb), gradA, gradB, threadIdx.x, JCS_THREADS);
     }
 }
 
@@ -569,7 +585,7 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
     }
     const JBin jb = j_bin_of(lv, n_levels, b);
     if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) return;     // a single-grid bin has no records of the other grid
-    const JLevel q = lv.l[jb.level];
+    const JLevel q = j_level(lv, jb.level);
     const uint32_t hs = side ? q.hsB : q.hsA, lg = side ? q.lgB : q.lgA;
     const uint32_t nl = bin_n_local(hs, jb.bl, lg);
     float* gl = (side ? gradB : gradA) + (size_t)(side ? q.offB : q.offA) * 2u;
