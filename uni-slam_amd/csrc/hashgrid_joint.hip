@@ -220,16 +220,13 @@ __device__ __forceinline__ JBin j_bin_of(const JLevels& lv, uint32_t n_levels, u
     }
     return r;
 }
-// the level's constants for a run-time level, by selects over compile-time indices
-__device__ __forceinline__ JLevel j_level(const JLevels& lv, uint32_t level) {
-    JLevel q = lv.l[0];
-#pragma unroll
-    for (uint32_t l = 1; l < J_MAX_LEVELS; ++l) if (l == level) q = lv.l[l];
-    return q;
+// the level's constants for a WAVE-UNIFORM run-time level: one scalar load from the kernel-argument segment
+__device__ __forceinline__ const JLevel& j_level(const JLevels& lv, uint32_t level) {
+    return lv.l[__builtin_amdgcn_readfirstlane(level)];
 }
 
 __device__ __forceinline__ void j_clear_bin(const JLevels& lv, const JBin jb, float* gradA, float* gradB, uint32_t tid, uint32_t nthreads) {
-    const JLevel q = j_level(lv, jb.level);
+    const JLevel& q = j_level(lv, jb.level);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if ((s == 0 && jb.kind == 2u) || (s == 1 && jb.kind == 1u)) continue;
@@ -263,13 +260,18 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
     const bool okb = b < TB;
     if (threadIdx.x < JCS_BINS) carry[threadIdx.x] = 0u;
     constexpr uint32_t PASS_ROWS = (JCS_THREADS / 64) * JCS_ITERS * 4;
-    for (uint32_t row0 = 0; row0 < n_rows; row0 += PASS_ROWS) {      // one pass for up to 512 rows (262 144 points)
-        const uint32_t rbase = row0 + wave * (JCS_ITERS * 4) + rsub;
+    const uint32_t n_rows8 = (n_rows + 7u) / 8u, n_order = n_rows8 * 8u;
+    for (uint32_t row0 = 0; row0 < n_order; row0 += PASS_ROWS) {     // one pass for up to 512 rows (262 144 points)
+        // position o in the bin's ORDER <-> row: the rows of one XCD class (row % 8: workgroup w of k_jwrite runs on XCD w % 8) are
+        // neighbours inside a bin, so the ~200-byte segments written through one XCD's L2 share their lines with that XCD only
+        // (row order instead: k_jwrite 131 -> 180 us)
+        const uint32_t obase = row0 + wave * (JCS_ITERS * 4) + rsub;
+        auto row_of = [&](uint32_t o) { return (o % n_rows8) * 8u + (o / n_rows8); };
         uint32_t v[JCS_ITERS], sum = 0;
 #pragma unroll
         for (int k = 0; k < JCS_ITERS; ++k) {
-            const uint32_t r = rbase + 4u * k;
-            v[k] = (okb && r < n_rows) ? counts[(size_t)r * row_stride + b] : 0u;
+            const uint32_t o = obase + 4u * k, r = row_of(o);
+            v[k] = (okb && o < n_order && r < n_rows) ? counts[(size_t)r * row_stride + b] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < JCS_ITERS; ++k) sum += v[k];
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
         for (int k = 0; k < JCS_ITERS; ++k) {
             const uint32_t up1 = __shfl_up(v[k], 16, 64), up2 = __shfl_up(v[k], 32, 64), up3 = __shfl_up(v[k], 48, 64);
             const uint32_t excl = (rsub >= 1 ? up1 : 0u) + (rsub >= 2 ? up2 : 0u) + (rsub >= 3 ? up3 : 0u);
-            const uint32_t r = rbase + 4u * k;
-            if (okb && r < n_rows) prefix[(size_t)r * row_stride + b] = run + excl;
+            const uint32_t o = obase + 4u * k, r = row_of(o);
+            if (okb && o < n_order && r < n_rows) prefix[(size_t)r * row_stride + b] = run + excl;
             const uint32_t all4 = __shfl(excl + v[k], (int)(48u + bcol), 64);      // the 4 rows' sum sits in the lane rsub = 3
             run += all4;
         }
