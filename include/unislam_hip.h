@@ -147,6 +147,13 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The two scan passes of us_hashgrid_bwd_joint, run ahead of the gradient call on a workspace whose counts us_hashgrid_fwd_joint left
+ * (they depend on the counts only, so the mapping step issues them beside the decoders' forward pass).  flags / gradA / gradB as in the
+ * gradient call that follows, which then carries US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED.  With US_GRID_BWD_OVERWRITE the entries of
+ * bins that several workgroups will add into are cleared HERE: the gradient tables must not be read in between. */
+int us_hashgrid_joint_scan(const us_grid_desc* a, const us_grid_desc* b, int64_t n, float* gradA, float* gradB, int flags,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* dL_dx[N][3] = sum_k dL_dy[N][k] * dy_dx[N][k][:]   (tcnn kernel_grid_backward_input) */
 int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uint32_t n_out_features,
                           float* dL_dx, void* stream);

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
 // exclusive scans of totals[0..TB): rec_off (records per grid) and dw_off (dwords: a joint bin holds its A records, then its B
 // records: 6 dwords per count; a single-grid bin 3), and the list of extra chunks of hot bins (as k_bin_scan).  8 elements per
 // thread; wave scans + one fix-up over the 16 wave totals (two barriers).
-__global__ __launch_bounds__(1024) void k_jscan(JLevels lv, uint32_t n_levels, const uint32_t* __restrict__ totals, uint32_t TB,
+struct JSingle { uint32_t lo[J_MAX_LEVELS], len[J_MAX_LEVELS]; };     // bin ranges of the split levels (bins that serve one grid only)
+__global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __restrict__ totals, uint32_t TB,
                                                 uint32_t* __restrict__ rec_off, uint32_t* __restrict__ dw_off,
                                                 uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr) {
     __shared__ uint32_t ws[3][16];
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(1024) void k_jscan(JLevels lv, uint32_t n_levels, c
     for (int k = 0; k < E; ++k) {
         const uint32_t b = E * t + k;
         c[k] = b < TB ? totals[b] : 0u;
-        dwn[k] = b < TB ? (j_bin_of(lv, n_levels, b).kind == 0u ? 6u : 3u) : 0u;
+        bool single = false;
+#pragma unroll
+        for (int l = 0; l < J_MAX_LEVELS; ++l) single |= (b - sg.lo[l]) < sg.len[l];
+        dwn[k] = b < TB ? (single ? 3u : 6u) : 0u;
         s += c[k]; d += c[k] * dwn[k]; xs += c[k] > ACC_CHUNK ? (c[k] - 1u) / ACC_CHUNK : 0u;
     }
     auto block_scan = [&](uint32_t v, int slot, uint32_t& total) {    // inclusive scan over the 1024 threads
@@ -733,9 +737,8 @@ extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* 
     return US_OK;
 }
 
-extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
-                                     const float* dL_dyB, int64_t n, float* gradA, float* gradB, int flags, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
+                     float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -749,10 +752,13 @@ extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* 
         }
         return US_OK;
     }
-    US_REQUIRE(x && dL_dyA && dL_dyB && gradA && gradB && workspace, US_ERR_NULL, "us_hashgrid_bwd_joint: NULL pointer");
+    const bool scanned = (flags & US_GRID_BWD_SCANNED) != 0;
+    US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint: the scan passes can only run ahead on counts left by us_hashgrid_fwd_joint (US_GRID_BWD_COUNTED)");
+    US_REQUIRE((scan_only || (x && dL_dyA && dL_dyB)) && gradA && gradB && workspace, US_ERR_NULL, "us_hashgrid_bwd_joint: NULL pointer");
     US_REQUIRE(flags & US_GRID_LEVEL_MAJOR, US_ERR_CONFIG, "us_hashgrid_bwd_joint: the gradients must be level-major planes (US_GRID_LEVEL_MAJOR)");
     US_REQUIRE(((uintptr_t)gradA & 15u) == 0 && ((uintptr_t)gradB & 15u) == 0 && ((uintptr_t)workspace & 15u) == 0 &&
-               ((uintptr_t)dL_dyA & 7u) == 0 && ((uintptr_t)dL_dyB & 7u) == 0, US_ERR_SHAPE,
+               (scan_only || (((uintptr_t)dL_dyA & 7u) == 0 && ((uintptr_t)dL_dyB & 7u) == 0)), US_ERR_SHAPE,
                "us_hashgrid_bwd_joint: gradient tables and workspace must be 16-byte aligned, dL_dy 8-byte aligned");
     US_REQUIRE(workspace_bytes >= us_hashgrid_joint_workspace_bytes(a, b, n), US_ERR_WORKSPACE,
                "us_hashgrid_bwd_joint: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
@@ -762,13 +768,33 @@ extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* 
     if (!counted)
         hipLaunchKernelGGL((k_jfwd<false, true>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
                            (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
-    hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,
-                       (uint32_t)TB, w.totals, gradA, gradB, overwrite);
-    hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, lv, L, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr);
+    if (!scanned) {
+        hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,
+                           (uint32_t)TB, w.totals, gradA, gradB, overwrite);
+        JSingle sg;
+        memset(&sg, 0, sizeof(sg));
+        for (uint32_t l = 0; l < L; ++l)
+            if (lv.l[l].flags & J_SPLIT) { sg.lo[l] = lv.l[l].first; sg.len[l] = j_level_bins(lv.l[l]); }
+        hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr);
+    }
+    if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
     hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
                        w.stride, w.rec, w.rec_cap_dw);
     hipLaunchKernelGGL(k_jaccum, dim3(2u * (ACC_EXTRA_MAX + (uint32_t)TB)), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
                        w.extra, w.hdr, w.rec, gradA, gradB, overwrite);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
+                                     const float* dL_dyB, int64_t n, float* gradA, float* gradB, int flags, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int us_hashgrid_joint_scan(const us_grid_desc* a, const us_grid_desc* b, int64_t n, float* gradA, float* gradB, int flags,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    return bwd_joint(a, b, nullptr, nullptr, nullptr, n, gradA, gradB, (flags | US_GRID_BWD_COUNTED | US_GRID_LEVEL_MAJOR) & ~US_GRID_BWD_SCANNED,
+                     workspace, workspace_bytes, stream, true);
 }

@@ -53,7 +53,7 @@ class MapStep:
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
-        self.overlap, self.side = (group is None) if overlap is None else bool(overlap), None
+        self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
         self._dec_grad_clean = False
         self._joint_wanted = False if joint is None else bool(joint)
         self.count_in_forward, self._counted = True, False
@@ -229,7 +229,7 @@ class MapStep:
         self.probe.setdefault(name, []).append((e0, e1))
 
     # ------------------------------------------------------------------------------------------ the iteration
-    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None):
+    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None, backward_follows=True):
         """
         Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
         has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
@@ -237,6 +237,7 @@ class MapStep:
         importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
         zero_depth_draws: (t_rand_uni [n0, n_strat], u [n0, n_imp]) for that branch's rays in row order, to replay a given random stream
         (tests); default: the in-kernel generator.
+        backward_follows: False for a render-only call (the encoders then skip the bookkeeping they do for the table gradient).
         """
         lib, st = L.lib(), L.stream()
         self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
@@ -290,7 +291,7 @@ class MapStep:
         # the sdf and the colour branch are independent between the sample points and the compositing: two streams
         # with the binned backward the encoder also leaves the binning counts of these points in the branch's workspace
         # (us_hashgrid_fwd_counted: the gathers bound the kernel, the counting rides along), and the backward skips its count pass
-        counted = self.ws is not None and self.count_in_forward
+        counted = self.ws is not None and self.count_in_forward and backward_follows
         self._counted = counted
         # ... and, if asked for, the two scan passes of the binning, which depend on those counts only, follow the encoder at once (a
         # probed step keeps them inside the timed gradient call)
@@ -300,8 +301,26 @@ class MapStep:
         if self.joint:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
             # then the two decoders side by side
+            if self.scan_stream is not None:                     # a scan of the previous call may still read the workspace
+                torch.cuda.current_stream().wait_stream(self.scan_stream)
+            self._jcounted = bool(backward_follows)
             self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                P(self.feat_s), P(self.feat_c), 3, P(self.ws), self.ws_bytes, st))
+                                                                                P(self.feat_s), P(self.feat_c), 3, P(self.ws) if self._jcounted else None,
+                                                                                self.ws_bytes if self._jcounted else 0, st))
+            # the binning's scan passes depend on the counts only: they run beside the decoders (own stream; the backward pass waits for
+            # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
+            scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                             3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, q)
+            if not self._jcounted:
+                pass
+            elif self._probing or not self.overlap:
+                self._timed("hashgrid_scan_joint", lambda: scan_call(st))
+            else:
+                if self.scan_stream is None:
+                    self.scan_stream = torch.cuda.Stream(device=self.device)
+                self.scan_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.scan_stream):
+                    L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
             with self._branch() as st2:
                 self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
             self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
@@ -400,9 +419,12 @@ class MapStep:
             self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
             self._join()
+            if self.scan_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.scan_stream)
             self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                 off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                                                3 | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED, P(self.ws), self.ws_bytes, st))
+                                                                                3 | L.US_GRID_BWD_OVERWRITE | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0),
+                                                                                P(self.ws), self.ws_bytes, st))
             if on_ready is not None:
                 on_ready(self.grad[self.o_tab_c:])
         elif self.overlap and not self._probing:
