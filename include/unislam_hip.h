@@ -169,7 +169,11 @@ int us_hashgrid_bwd_input_gather(const us_grid_desc* desc_host, const float* par
  * and the nn.Linear stacks src/networks/decoders.py:74-84,125-128,150-153)
  * ---------------------------------------------------------------------------------------------- */
 enum { US_ACT_NONE = 0, US_ACT_TANH = 1, US_ACT_SIGMOID = 2 };
-enum { US_PREC_F32 = 0, US_PREC_BF16 = 1 };   /* MFMA operand type; accumulation is always fp32 */
+/* MFMA operand type; accumulation, parameters and parameter gradients are always fp32.
+ * US_PREC_BF16: bf16 MFMA (v_mfma_f32_16x16x32_bf16) with SPLIT operands in the forward products (x = hi + lo, W x = W_hi x_hi +
+ * W_hi x_lo + W_lo x_hi: operands good to 2^-16), plain bf16 operands in the gradient products; US_PREC_BF16_PLAIN: one MFMA per
+ * product everywhere (operands good to 2^-8: rendered colour deviates 1.4e-3 from the fp32 decoders). */
+enum { US_PREC_F32 = 0, US_PREC_BF16 = 1, US_PREC_BF16_PLAIN = 2 };
 
 typedef struct us_mlp_desc {
     uint32_t n_in;        /* 32 */

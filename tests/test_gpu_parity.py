@@ -283,10 +283,14 @@ def _bf(x):
 @pytest.mark.parametrize("width,n_hidden,n_out,act,bias,n", [
     (16, 1, 1, "tanh", False, 1000), (16, 2, 3, "sigmoid", True, 4099), (32, 2, 1, "tanh", True, 8192 + 17),
     (32, 2, 3, "sigmoid", True, 70001), (32, 1, 3, "sigmoid", False, 333), (64, 2, 3, "sigmoid", True, 5000), (64, 1, 1, "none", True, 31)])
-def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n):
-    """US_PREC_BF16: against a torch emulation that rounds every MFMA operand to bf16 (tight) and against fp32 (loose)."""
+@pytest.mark.parametrize("prec", ["bf16", "bf16_plain"])
+def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n, prec):
+    """bf16 MFMA decoders against a torch emulation that rounds the MFMA operands to bf16 (tight) and against fp32.
+    bf16_plain: every operand of every product rounded once.  bf16 (US_PREC_BF16, the default): the forward products carry split
+    operands (hi + lo), so outputs and activations are fp32-accurate (1e-4) and only the gradient products see bf16 operands."""
     g = torch.Generator().manual_seed(width * 7 + n_hidden)
-    desc = us.make_mlp_desc(32, width, n_hidden, n_out, act, bias, "bf16")
+    desc = us.make_mlp_desc(32, width, n_hidden, n_out, act, bias, prec)
+    assert desc.precision == {"bf16": 1, "bf16_plain": 2}[prec]
     shapes = [(width, 32)] + [(width, width)] * (n_hidden - 1) + [(16, width)]
     n_p = us.network.mlp_n_params(desc)
     params = (torch.rand(n_p, generator=g) * 2 - 1) * 0.4
@@ -297,24 +301,26 @@ def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n):
         ws.append(params[o:o + a * b].view(a, b)); o += a * b
     for (a, _) in shapes:
         bs.append(params[o:o + a] if bias else torch.zeros(a)); o += a
-    def run(rnd):
-        hs, h = [rnd(x)], rnd(x)
+    def run(rnd, rnd_fwd=None):
+        rf = rnd if rnd_fwd is None else rnd_fwd                  # operand rounding of the forward products
+        hs, h = [rf(x)], rf(x)
         for W, b in zip(ws[:-1], bs[:-1]):
-            h = rnd(torch.relu(h @ rnd(W).T + b)); hs.append(h)
-        ypre = (h @ rnd(ws[-1]).T + bs[-1])[:, :n_out]
+            h = rf(torch.relu(h @ rf(W).T + b)); hs.append(h)
+        ypre = (h @ rf(ws[-1]).T + bs[-1])[:, :n_out]
         y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda t: t}[act](ypre)
         dact = {"tanh": 1 - y * y, "sigmoid": y * (1 - y), "none": torch.ones_like(y)}[act]
         d = torch.zeros(n, 16); d[:, :n_out] = dy * dact
         gw, gb = [], []
         for i in range(len(ws) - 1, -1, -1):
-            gw.append(rnd(d).T @ hs[i]); gb.append(d.sum(0))
+            gw.append(rnd(d).T @ rnd(hs[i])); gb.append(d.sum(0))
             d = rnd(d) @ rnd(ws[i])
             if i > 0:
                 d = d * (hs[i] > 0)
         gp = torch.cat([t.reshape(-1) for t in gw[::-1]] + ([t for t in gb[::-1]] if bias else []))
         return y, d, gp
-    y_e, dx_e, gp_e = run(_bf)
-    y_f, dx_f, gp_f = run(lambda t: t)
+    ident = lambda t: t
+    y_e, dx_e, gp_e = run(_bf) if prec == "bf16_plain" else run(_bf, ident)
+    y_f, dx_f, gp_f = run(ident)
     pg = params.to(DEV).requires_grad_(True); xg = x.to(DEV).requires_grad_(True)
     y = us.fused_mlp(xg, pg, desc)
     (y * dy.to(DEV)).sum().backward()
@@ -322,9 +328,14 @@ def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n):
     def rel(a, b):
         return ((a.cpu() - b).norm() / (b.norm() + 1e-12)).item()
     assert rel(y, y_e) < 2e-3 and rel(xg.grad, dx_e) < 3e-3 and rel(pg.grad, gp_e) < 3e-3, (rel(y, y_e), rel(xg.grad, dx_e), rel(pg.grad, gp_e))
-    # vs fp32: ReLU masks of neurons whose pre-activation is within bf16 rounding of 0 flip, so gradients differ by a few %
-    assert rel(y, y_f) < 2e-2 and rel(xg.grad, dx_f) < 0.15 and rel(pg.grad, gp_f) < 0.08, (rel(y, y_f), rel(xg.grad, dx_f), rel(pg.grad, gp_f))
-    assert (y.cpu() - y_e).abs().max().item() < 2e-2
+    if prec == "bf16":
+        # split operands: the forward pass is fp32-accurate; the gradients carry one bf16 rounding per operand of their products
+        assert rel(y, y_f) < 1e-4 and (y.cpu() - y_f).abs().max().item() < 2e-4, (rel(y, y_f), (y.cpu() - y_f).abs().max().item())
+        assert rel(xg.grad, dx_f) < 1e-2 and rel(pg.grad, gp_f) < 1e-2, (rel(xg.grad, dx_f), rel(pg.grad, gp_f))
+    else:
+        # vs fp32: ReLU masks of neurons whose pre-activation is within bf16 rounding of 0 flip, so gradients differ by a few %
+        assert rel(y, y_f) < 2e-2 and rel(xg.grad, dx_f) < 0.15 and rel(pg.grad, gp_f) < 0.08, (rel(y, y_f), rel(xg.grad, dx_f), rel(pg.grad, gp_f))
+        assert (y.cpu() - y_e).abs().max().item() < 2e-2
 
 
 def test_mlp_rejects_unsupported(us):

@@ -550,8 +550,9 @@ def test_mapstep_config3_shape_scannet():
 
 @pytest.mark.parametrize("tcnn,hidden", [(False, 32), (True, 16)])
 def test_mapstep_bf16_decoders_track_fp32(tcnn, hidden):
-    """mlp_precision = bf16 (MFMA bf16 operands, fp32 accumulation and parameters): same rays and draws as the fp32 step.
-    Rendered depth / colour stay within 1e-2 relative (norm-wise) of the fp32 path and the optimisation behaves the same."""
+    """mlp_precision = bf16 (bf16 MFMA with split operands in the forward products, fp32 accumulation and parameters): same rays and
+    draws as the fp32 step.  Rendered depth / colour stay within the north star's 1e-3 relative of the fp32 path -- element-wise --
+    and the optimisation behaves the same."""
     import unislam_amd as us
     R, S = 1024, 64
     ro, rd, gd, gc = _rays(R, seed=5)
@@ -574,8 +575,10 @@ def test_mapstep_bf16_decoders_track_fp32(tcnn, hidden):
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     term_b, unc_b, depth_b, rgb_b, gs_b, gc_b = outs["bf16"]
     term_f, unc_f, depth_f, rgb_f, gs_f, gc_f = outs["fp32"]
-    assert rel(depth_b, depth_f) < 1e-2 and rel(rgb_b, rgb_f) < 1e-2, (rel(depth_b, depth_f), rel(rgb_b, rgb_f))
-    assert rel(gs_b, gs_f) < 0.15 and rel(gc_b, gc_f) < 0.15, (rel(gs_b, gs_f), rel(gc_b, gc_f))
+    assert rel(depth_b, depth_f) < 1e-4 and rel(rgb_b, rgb_f) < 1e-4, (rel(depth_b, depth_f), rel(rgb_b, rgb_f))
+    np.testing.assert_allclose(depth_b.cpu().numpy(), depth_f.cpu().numpy(), rtol=1e-3, atol=1e-5)       # the north-star bound, per ray
+    np.testing.assert_allclose(rgb_b.cpu().numpy(), rgb_f.cpu().numpy(), rtol=1e-3, atol=1e-5)
+    assert rel(gs_b, gs_f) < 2e-2 and rel(gc_b, gc_f) < 2e-2, (rel(gs_b, gs_f), rel(gc_b, gc_f))
     assert abs(losses["bf16"][0] - losses["fp32"][0]) < 2e-2 * abs(losses["fp32"][0])
     assert losses["bf16"][-1] < losses["bf16"][0] and abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * abs(losses["fp32"][-1])
 

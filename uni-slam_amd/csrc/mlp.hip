@@ -527,7 +527,7 @@ static int check_mlp(const char* fn, const us_mlp_desc* d) {
     US_REQUIRE(d->n_hidden == 1 || d->n_hidden == 2, US_ERR_CONFIG, "%s: n_hidden %u not in {1,2}", fn, d->n_hidden);
     US_REQUIRE(d->n_out >= 1 && d->n_out <= 16, US_ERR_CONFIG, "%s: n_out %u not in 1..16", fn, d->n_out);
     US_REQUIRE(d->out_act <= US_ACT_SIGMOID, US_ERR_CONFIG, "%s: out_act %u", fn, d->out_act);
-    US_REQUIRE(d->precision == US_PREC_F32 || d->precision == US_PREC_BF16, US_ERR_CONFIG, "%s: precision %u", fn, d->precision);
+    US_REQUIRE(d->precision <= US_PREC_BF16_PLAIN, US_ERR_CONFIG, "%s: precision %u", fn, d->precision);
     return US_OK;
 }
 
@@ -559,13 +559,15 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int pts = (d->width == 64 && d->precision != US_PREC_BF16) ? 32 : 64;
+    const bool bf = d->precision != US_PREC_F32;
+    const int pts = (d->width == 64 && !bf) ? 32 : 64;
     // fp32: 2 workgroups per CU, each wave loops with its next chunk prefetched (21.9 vs 23.8 us at 262144 points, MI355X); the bf16
     // kernel is shorter than its launch ramp and prefers one chunk per wave (12.2 vs 13.0 us)
-    const int64_t cap = d->precision == US_PREC_BF16 ? 2048 : MLP_FWD_MAX_WG;
+    const int64_t cap = bf ? 2048 : MLP_FWD_MAX_WG;
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
-    if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
+    if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
+    else if (bf) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
     else MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
     US_CHECK_LAUNCH("us_mlp_fwd");
     return US_OK;
@@ -587,7 +589,7 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
     if (!dL_din && !grad_params) return US_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf = d->precision == US_PREC_BF16;
+    const bool bf = d->precision != US_PREC_F32;
     const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
     int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;   // one workgroup per CU
     dim3 grid((unsigned)nb), block(waves * 64);
@@ -597,8 +599,10 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
                    workspace_bytes, us_mlp_bwd_workspace_bytes(d));
         partials = (float*)workspace;
     }
-    if (bf) MLP_DISPATCH(k_mlp_bwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
-                         dout_stride, n, dL_din, grad_params, lm, partials);
+    if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_bwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
+                                                   dout_stride, n, dL_din, grad_params, lm, partials);
+    else if (bf) MLP_DISPATCH(k_mlp_bwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
+                              dout_stride, n, dL_din, grad_params, lm, partials);
     else MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                       dout_stride, n, dL_din, grad_params, lm, partials);
     US_CHECK_LAUNCH("us_mlp_bwd");

@@ -46,6 +46,9 @@ class MapStep:
                  us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes for a single process when the pair of
                  grids qualifies; no with a process group, where the colour table's gradient is finished FIRST so that its all-reduce
                  hides behind the sdf branch (a joint pass would finish both tables at the same moment, with nothing left to hide behind).
+                 Measured at 4096 x 64 (room0 tables): the iteration takes the same 0.66 ms either way -- the two one-grid chains overlap on
+                 two streams -- but the table gradient itself is 276 us for both grids against 157 + 147; render-only calls
+                 (backward_follows=False) always use the one-grid encoders on two streams (0.19 against 0.21 ms).
         overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch;
                  default: yes for a single process; no with a process group, where the branches run one after the other so that
                  the all-reduce of the colour-table gradient hides behind the sdf branch.
@@ -55,7 +58,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
         self._dec_grad_clean = False
-        self._joint_wanted = False if joint is None else bool(joint)
+        self._joint_wanted = (group is None) if joint is None else bool(joint)
         self.count_in_forward, self._counted = True, False
         # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
         # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
@@ -298,12 +301,13 @@ class MapStep:
         scan = counted and self.scan_in_forward and not self._probing
         self._scanned = scan
         bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed
-        if self.joint:
+        self._jcounted = False
+        if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
             # then the two decoders side by side
             if self.scan_stream is not None:                     # a scan of the previous call may still read the workspace
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
-            self._jcounted = bool(backward_follows)
+            self._jcounted = True
             self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
                                                                                 P(self.feat_s), P(self.feat_c), 3, P(self.ws) if self._jcounted else None,
                                                                                 self.ws_bytes if self._jcounted else 0, st))
