@@ -50,8 +50,10 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--hidden", type=int, default=32, help="MLP width (32 = BASELINE '2x32'; 16 = reference decoders.py default)")
     ap.add_argument("--bwd-mode", type=int, default=-1)
-    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
-                    help="MFMA operand type of the decoders; the headline (parity-tested to 1e-3) is fp32")
+    ap.add_argument("--mlp-precision", default="bf16", choices=["fp32", "bf16", "bf16_plain"],
+                    help="MFMA operand type of the decoders.  bf16 (headline): v_mfma_f32_16x16x32_bf16 with split operands (hi + lo) in the "
+                         "forward products -- rendered depth / colour within 4e-5 of the fp32 decoders on identical parameters "
+                         "(tools/bf16_deviation.py; bound 1e-3), bf16 operands in the gradient products; fp32: f32-input MFMA throughout")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="payload type of the gradient all-reduce (N > 1); bf16 halves the xGMI bytes, not bit-faithful to one process")
     ap.add_argument("--sharded-adam", action="store_true",
@@ -370,7 +372,9 @@ def run_rank(args):
         rec = {"metric": "rays/s (64 samples, L=16 hash, 2x32 MLP), Replica room0 mapping iteration",
                "value": world * R / (ms / 1e3), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32" if args.mlp_precision == "fp32" else "f32 tables/accumulation, bf16 MFMA operands in the decoders",
+               "vs_baseline": None,
+               "dtype": "f32" if args.mlp_precision == "fp32" else "bf16 MFMA operands in the decoders (split hi + lo in the forward products), f32 tables, "
+                                                                   "accumulation, parameters and optimiser",
                "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: Replica room0, 4096 rays x 64 samples (48 stratified + 16 surface), "
                                       "L=16 F=2 hash grids log2T 16 (sdf) / 19 (colour) res 816, 2 hidden x %d MLP decoders with bias, "
@@ -429,9 +433,9 @@ def run_rank(args):
                 torch.cuda.synchronize()
                 m2 = 1e3 * (time.perf_counter() - t1) / args.steps
                 return {"ms_per_step": m2, "rays_per_s": R / (m2 / 1e3), "final_loss": float(l2)}
-            if args.mlp_precision == "fp32":
-                # the same iteration with bf16 MFMA operands in the two decoders; not the headline
-                rec["bf16_decoders"] = side_run(build_step("bf16")[0])
+            if args.mlp_precision != "fp32":
+                # the same iteration with f32-input MFMA decoders (exact fmaf chains, what the fixture comparisons run)
+                rec["fp32_decoders"] = side_run(build_step("fp32")[0])
             # tables with "trained-like" N(0, 0.1) entries: alpha is no longer degenerate, the gradients are dense in value
             rec["trained_like_tables"] = side_run(build_step(args.mlp_precision, table_std=0.1)[0])
         if world == 1 and not args.no_tracking:

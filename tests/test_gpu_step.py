@@ -141,13 +141,15 @@ def test_mapstep_bench_shape_runs_and_decreases_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-def test_mapstep_full_size_against_oracle():
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mapstep_full_size_against_oracle(prec):
     """BASELINE cfg2 at its full size -- 4096 rays x 64 samples (48 + 16), room0 tables (log2T 16 / 19, res 816), 2 x 32 MLP -- one
     mapping iteration against the CPU oracle on the same rays and jitter: rendered depth / colour within 1e-3 relative (the
-    north-star bound), loss, table and decoder gradients."""
+    north-star bound), loss, table and decoder gradients.  prec = bf16: the bench's headline decoders (bf16 MFMA, split-operand forward
+    products): the same bounds on everything rendered and on the loss; the gradients, whose products see bf16 operands, norm-wise 2e-2."""
     import unislam_amd as us
     torch.manual_seed(5)
-    cfg = _cfg(False, 48, 16)
+    cfg = dict(_cfg(False, 48, 16), model={"mlp_precision": prec})
     dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
     es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
     with torch.no_grad():                                       # features large enough for a non-trivial surface
@@ -174,10 +176,14 @@ def test_mapstep_full_size_against_oracle():
     np.testing.assert_allclose(float(loss), float(loss_o), rtol=1e-3)
     for name, g_hip, g_o in (("sdf", es.params.grad.cpu(), oes.params.grad), ("colour", ec.params.grad.cpu(), oec.params.grad)):
         scale = g_o.abs().max().item()
-        assert torch.allclose(g_hip, g_o, rtol=5e-3, atol=2e-4 * scale), (name, float((g_hip - g_o).abs().max()), scale)
-        assert float((g_hip - g_o).norm() / g_o.norm()) < 1e-3, name
+        if prec == "fp32":
+            assert torch.allclose(g_hip, g_o, rtol=5e-3, atol=2e-4 * scale), (name, float((g_hip - g_o).abs().max()), scale)
+        assert float((g_hip - g_o).norm() / g_o.norm()) < (1e-3 if prec == "fp32" else 2e-2), (name, float((g_hip - g_o).norm() / g_o.norm()))
     for (n, pa), (_, pb) in zip(od.named_parameters(), dec.named_parameters()):
-        assert torch.allclose(pb.grad.cpu(), pa.grad, rtol=5e-3, atol=2e-4 * max(1e-3, pa.grad.abs().max().item())), n
+        if prec == "fp32":
+            assert torch.allclose(pb.grad.cpu(), pa.grad, rtol=5e-3, atol=2e-4 * max(1e-3, pa.grad.abs().max().item())), n
+        else:
+            assert float((pb.grad.cpu() - pa.grad).norm() / pa.grad.norm()) < 2e-2, n
 
 
 @pytest.mark.parametrize("mode", ["original", "no_mask"])
