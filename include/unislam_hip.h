@@ -84,6 +84,12 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * Measured on MI355X (4096 x 64 points, room0 tables): 186 -> 179 us per colour-table gradient -- the two passes are bound by LDS
  * atomics and per-workgroup latency, not by their bytes, so the default keeps the exact 12-byte records. */
 #define US_GRID_BWD_PACKED 32
+/* US_GRID_BWD_DETERMINISTIC (us_hashgrid_bwd_binned, us_hashgrid_bwd_joint, and their scan calls): no bin is split over several
+ * accumulate workgroups, so no float atomic takes part: every table-gradient entry is ONE f64 sum of its fp32 contributions, rounded
+ * to fp32 once.  The order in which LDS atomics add the terms can then only move the sum at the 2^-53 level, which the final rounding
+ * does not see: results repeat bit for bit from run to run (tests/test_gpu_joint.py).  Slower when the batch concentrates on few
+ * cells (one workgroup then walks a hot bin alone); meant for diffing runs. */
+#define US_GRID_BWD_DETERMINISTIC 128
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 

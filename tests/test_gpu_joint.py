@@ -150,3 +150,35 @@ def test_joint_rejects_grids_of_different_geometry(us):
     assert lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(ea.desc), ctypes.byref(eb.desc), 1000) == 0
     rc = lib.us_hashgrid_bwd_joint(ctypes.byref(ea.desc), ctypes.byref(eb.desc), None, None, None, 1000, None, None, 3, None, 0, None)
     assert rc == L.US_ERR_CONFIG
+
+
+@pytest.mark.parametrize("joint", [True, False])
+def test_deterministic_table_gradient_repeats_bit_for_bit(us, joint):
+    """US_GRID_BWD_DETERMINISTIC: no bin is split, no float atomic takes part -- two runs on a batch that concentrates 55000 points in
+    one coarse cell give bit-identical gradients (the default mode sums the chunks of such bins with float atomics, in arrival order),
+    and they equal the default mode's up to that order."""
+    from unislam_amd import _lib as L
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    g = torch.Generator(device=DEV).manual_seed(6)
+    n = 60000
+    x = (0.41 + 0.02 * torch.rand((n, 3), device=DEV, generator=g)).contiguous()
+    x[:5000] = torch.rand((5000, 3), device=DEV, generator=g)
+    ea, eb = _pair(us, 16, 19, 816, g)
+    da, db = ctypes.byref(ea.desc), ctypes.byref(eb.desc)
+    dya, dyb = torch.randn((16, n, 2), device=DEV, generator=g), torch.randn((16, n, 2), device=DEV, generator=g)
+    outs = []
+    for flags in (L.US_GRID_BWD_DETERMINISTIC, L.US_GRID_BWD_DETERMINISTIC, 0):
+        ga, gb = torch.full((ea.desc.n_params,), 3.0, device=DEV), torch.full((eb.desc.n_params,), 3.0, device=DEV)
+        if joint:
+            nbytes = int(lib.us_hashgrid_joint_workspace_bytes(da, db, n))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+            L.check(lib.us_hashgrid_bwd_joint(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), 3 | L.US_GRID_BWD_OVERWRITE | flags, P(ws), nbytes, st), "bwd joint")
+        else:
+            for d, dy, gg in ((da, dya, ga), (db, dyb, gb)):
+                nbytes = int(lib.us_hashgrid_bwd_workspace_bytes(d, n))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+                L.check(lib.us_hashgrid_bwd_binned(d, P(x), P(dy), n, P(gg), 3 | L.US_GRID_BWD_OVERWRITE | flags, P(ws), nbytes, st), "bwd")
+        outs.append((ga, gb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in range(2):
+        assert torch.allclose(outs[0][k], outs[2][k], rtol=1e-4, atol=2e-6 * float(outs[2][k].abs().max()))

@@ -327,7 +327,8 @@ def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n, prec):
     # last-matrix rows >= n_out receive no gradient in either implementation
     def rel(a, b):
         return ((a.cpu() - b).norm() / (b.norm() + 1e-12)).item()
-    assert rel(y, y_e) < 2e-3 and rel(xg.grad, dx_e) < 5e-3 and rel(pg.grad, gp_e) < 5e-3, (rel(y, y_e), rel(xg.grad, dx_e), rel(pg.grad, gp_e))
+    gtol = 3e-3 if prec == "bf16_plain" else 1e-2                # (the emulation of the mixed path does not model where its sums round)
+    assert rel(y, y_e) < 2e-3 and rel(xg.grad, dx_e) < gtol and rel(pg.grad, gp_e) < gtol, (rel(y, y_e), rel(xg.grad, dx_e), rel(pg.grad, gp_e))
     if prec == "bf16":
         # split operands: the forward pass is fp32-accurate; the gradients carry one bf16 rounding per operand of their products
         assert rel(y, y_f) < 1e-4 and (y.cpu() - y_f).abs().max().item() < 2e-4, (rel(y, y_f), (y.cpu() - y_f).abs().max().item())

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
 template <int F>
 __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab, BinMap bm, uint32_t n_levels, const uint32_t* __restrict__ wg_counts,
                                                                  uint32_t* __restrict__ wg_prefix, uint32_t n_wg, uint32_t TB,
-                                                                 uint32_t* __restrict__ totals, float* __restrict__ grad, int overwrite) {
+                                                                 uint32_t* __restrict__ totals, float* __restrict__ grad, int overwrite, uint32_t chunk0) {
     const uint32_t xcd = threadIdx.x & 7u;
     const uint32_t b = blockIdx.x * COLSCAN_BINS + (threadIdx.x >> 3);
     const bool ok = b < TB;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab,
         if (xcd == 0) totals[b] = total;
     }
     if (!overwrite) return;
-    unsigned long long hot = __ballot(ok && xcd == 0 && total > ACC_CHUNK);
+    unsigned long long hot = __ballot(ok && xcd == 0 && total > chunk0);
     while (hot) {                                                // wave-uniform loop (one wave per workgroup)
         const int src = __ffsll((long long)hot) - 1;
         hot &= hot - 1ull;
@@ -398,13 +398,14 @@ __global__ __launch_bounds__(COLSCAN_THREADS) void k_bin_colscan(LevelTable tab,
 // chunks 1.. are listed in extra[] as bin | chunk << 16.  chunk = ACC_CHUNK, or the multiple of it that keeps the list within
 // ACC_EXTRA_MAX entries (hdr[0] = number of extras, hdr[1] = chunk).
 __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t TB, uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr) {
+                                                   uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr, uint32_t chunk0) {
+    // chunk0 = ACC_CHUNK, or 0xFFFFFFFF (US_GRID_BWD_DETERMINISTIC): no bin is split, every sum is formed by one workgroup in f64
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t sx[1024];
     const uint32_t t = threadIdx.x;
     uint32_t c[4], s4 = 0, x4 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c[k] = (4 * t + k < TB) ? counts[4 * t + k] : 0u; s4 += c[k]; x4 += c[k] > ACC_CHUNK ? (c[k] - 1u) / ACC_CHUNK : 0u; }
+    for (int k = 0; k < 4; ++k) { c[k] = (4 * t + k < TB) ? counts[4 * t + k] : 0u; s4 += c[k]; x4 += c[k] > chunk0 ? (c[k] - 1u) / chunk0 : 0u; }
     sh[t] = s4; sx[t] = x4;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
@@ -413,10 +414,10 @@ __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ 
         sh[t] += v; sx[t] += w;
         __syncthreads();
     }
-    uint32_t chunk = ACC_CHUNK;
+    uint32_t chunk = chunk0;
     const uint32_t x_all = sx[1023];
     if (x_all > ACC_EXTRA_MAX) {                                 // wave-uniform, rare: coarser chunks, scanned again
-        chunk = ACC_CHUNK * ((x_all + ACC_EXTRA_MAX - 1u) / ACC_EXTRA_MAX);
+        chunk = chunk0 * ((x_all + ACC_EXTRA_MAX - 1u) / ACC_EXTRA_MAX);
         x4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) x4 += c[k] > chunk ? (c[k] - 1u) / chunk : 0u;
@@ -627,6 +628,7 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
     const uint32_t L = d->n_levels;
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0, counted = (flags & US_GRID_BWD_COUNTED) ? 1 : 0;
     const bool packed = (flags & US_GRID_BWD_PACKED) != 0, scanned = (flags & US_GRID_BWD_SCANNED) != 0;
+    const uint32_t chunk0 = (flags & US_GRID_BWD_DETERMINISTIC) ? 0xFFFFFFFFu : (uint32_t)ACC_CHUNK;
     US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
                "us_hashgrid_bwd_binned: the scan passes can only run ahead on counts left by us_hashgrid_fwd_counted (US_GRID_BWD_COUNTED)");
     US_REQUIRE(!packed || (d->n_features == 2 && bin_entries(2) <= 2048u), US_ERR_CONFIG,
@@ -637,8 +639,8 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
     if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
     if (!scanned) {                                                                                                            \
         hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
-                           (uint32_t)TB, totals, grad_params, overwrite);                                                      \
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra);              \
+                           (uint32_t)TB, totals, grad_params, overwrite, chunk0);                                              \
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra, chunk0);      \
     }                                                                                                                          \
     if (scan_only) break;                                                                                                      \
     hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \

@@ -252,7 +252,7 @@ __device__ __forceinline__ void j_clear_bin(const JLevels& lv, const JBin jb, fl
 __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n_levels, const uint32_t* __restrict__ counts,
                                                           uint32_t* __restrict__ prefix, uint32_t n_rows, uint32_t row_stride, uint32_t TB,
                                                           uint32_t* __restrict__ totals, float* __restrict__ gradA, float* __restrict__ gradB,
-                                                          int overwrite) {
+                                                          int overwrite, uint32_t chunk0) {
     __shared__ uint32_t part[JCS_THREADS / 64][JCS_BINS];
     __shared__ uint32_t carry[JCS_BINS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, rsub = lane >> 4, bcol = lane & 15u;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
     if (!overwrite) return;
     for (uint32_t k = 0; k < JCS_BINS; ++k) {                                    // workgroup-uniform
         const uint32_t hb = blockIdx.x * JCS_BINS + k;
-        if (hb < TB && carry[k] > ACC_CHUNK) j_clear_bin(lv, j_bin_of(lv, n_levels, hb), gradA, gradB, threadIdx.x, JCS_THREADS);
+        if (hb < TB && carry[k] > chunk0) j_clear_bin(lv, j_bin_of(lv, n_levels, hb), gradA, gradB, threadIdx.x, JCS_THREADS);
     }
 }
 
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
 struct JSingle { uint32_t lo[J_MAX_LEVELS], len[J_MAX_LEVELS]; };     // bin ranges of the split levels (bins that serve one grid only)
 __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __restrict__ totals, uint32_t TB,
                                                 uint32_t* __restrict__ rec_off, uint32_t* __restrict__ dw_off,
-                                                uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr) {
+                                                uint32_t* __restrict__ extra, uint32_t* __restrict__ hdr, uint32_t chunk0) {
+    // chunk0 = ACC_CHUNK, or 0xFFFFFFFF (US_GRID_BWD_DETERMINISTIC): no bin is split, every sum is formed by one workgroup in f64
     __shared__ uint32_t ws[3][16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     constexpr int E = J_MAX_BINS / 1024;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
 #pragma unroll
         for (int l = 0; l < J_MAX_LEVELS; ++l) single |= (b - sg.lo[l]) < sg.len[l];
         dwn[k] = b < TB ? (single ? 3u : 6u) : 0u;
-        s += c[k]; d += c[k] * dwn[k]; xs += c[k] > ACC_CHUNK ? (c[k] - 1u) / ACC_CHUNK : 0u;
+        s += c[k]; d += c[k] * dwn[k]; xs += c[k] > chunk0 ? (c[k] - 1u) / chunk0 : 0u;
     }
     auto block_scan = [&](uint32_t v, int slot, uint32_t& total) {    // inclusive scan over the 1024 threads
         uint32_t incl = v;
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
     uint32_t s_all, d_all, x_all;
     const uint32_t s_in = block_scan(s, 0, s_all), d_in = block_scan(d, 1, d_all);
     uint32_t x_in = block_scan(xs, 2, x_all);
-    uint32_t chunk = ACC_CHUNK;
+    uint32_t chunk = chunk0;
     if (x_all > ACC_EXTRA_MAX) {                                 // wave-uniform, rare: coarser chunks, scanned again
-        chunk = ACC_CHUNK * ((x_all + ACC_EXTRA_MAX - 1u) / ACC_EXTRA_MAX);
+        chunk = chunk0 * ((x_all + ACC_EXTRA_MAX - 1u) / ACC_EXTRA_MAX);
         xs = 0;
 #pragma unroll
         for (int k = 0; k < E; ++k) xs += c[k] > chunk ? (c[k] - 1u) / chunk : 0u;
@@ -753,6 +754,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         return US_OK;
     }
     const bool scanned = (flags & US_GRID_BWD_SCANNED) != 0;
+    const uint32_t chunk0 = (flags & US_GRID_BWD_DETERMINISTIC) ? 0xFFFFFFFFu : (uint32_t)ACC_CHUNK;
     US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
                "us_hashgrid_bwd_joint: the scan passes can only run ahead on counts left by us_hashgrid_fwd_joint (US_GRID_BWD_COUNTED)");
     US_REQUIRE((scan_only || (x && dL_dyA && dL_dyB)) && gradA && gradB && workspace, US_ERR_NULL, "us_hashgrid_bwd_joint: NULL pointer");
@@ -770,12 +772,12 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
                            (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
     if (!scanned) {
         hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,
-                           (uint32_t)TB, w.totals, gradA, gradB, overwrite);
+                           (uint32_t)TB, w.totals, gradA, gradB, overwrite, chunk0);
         JSingle sg;
         memset(&sg, 0, sizeof(sg));
         for (uint32_t l = 0; l < L; ++l)
             if (lv.l[l].flags & J_SPLIT) { sg.lo[l] = lv.l[l].first; sg.len[l] = j_level_bins(lv.l[l]); }
-        hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr);
+        hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, chunk0);
     }
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
     hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,

@@ -36,7 +36,7 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None):
+                 packed_records=False, joint=None, deterministic=False):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -59,6 +59,9 @@ class MapStep:
         self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
         self._dec_grad_clean = False
         self._joint_wanted = (group is None) if joint is None else bool(joint)
+        # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
+        # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
+        self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
         self.count_in_forward, self._counted = True, False
         # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
         # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
@@ -300,7 +303,7 @@ class MapStep:
         # probed step keeps them inside the timed gradient call)
         scan = counted and self.scan_in_forward and not self._probing
         self._scanned = scan
-        bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed
+        bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed | self._det
         self._jcounted = False
         if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
@@ -314,7 +317,7 @@ class MapStep:
             # the binning's scan passes depend on the counts only: they run beside the decoders (own stream; the backward pass waits for
             # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
             scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                             3 | L.US_GRID_BWD_OVERWRITE, P(self.ws), self.ws_bytes, q)
+                                                             3 | L.US_GRID_BWD_OVERWRITE | self._det, P(self.ws), self.ws_bytes, q)
             if not self._jcounted:
                 pass
             elif self._probing or not self.overlap:
@@ -398,7 +401,7 @@ class MapStep:
                                                               P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws_s), self.ws_bytes, q))
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws_s), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
                                                                                   off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
@@ -408,7 +411,7 @@ class MapStep:
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                    3 | L.US_GRID_BWD_OVERWRITE | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws), self.ws_bytes, q))
+                                                                                    3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
@@ -427,7 +430,7 @@ class MapStep:
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
             self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                 off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                                                3 | L.US_GRID_BWD_OVERWRITE | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0),
+                                                                                3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0),
                                                                                 P(self.ws), self.ws_bytes, st))
             if on_ready is not None:
                 on_ready(self.grad[self.o_tab_c:])
