@@ -153,6 +153,16 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The table gradient of a RANGE of the batch: x / dL_dy* point at the range's first point, n = points in the range, plane_stride =
+ * points of the whole batch (the distance between the level planes of a level-major dL_dy).  The gradient is additive over points,
+ * so a batch whose scratch (us_hashgrid_*_workspace_bytes grows with n) would exceed a budget is walked in ranges -- the first with
+ * US_GRID_BWD_OVERWRITE, the others adding -- on a workspace sized for one range.  No US_GRID_BWD_COUNTED here. */
+int us_hashgrid_bwd_joint_range(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
+                                int64_t n, int64_t plane_stride, float* gradA, float* gradB, int flags, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int us_hashgrid_bwd_binned_range(const us_grid_desc* desc_host, const float* x, const float* dL_dy, int64_t n, int64_t plane_stride,
+                                 float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two scan passes of us_hashgrid_bwd_joint, run ahead of the gradient call on a workspace whose counts us_hashgrid_fwd_joint left
  * (they depend on the counts only, so the mapping step issues them beside the decoders' forward pass).  flags / gradA / gradB as in the
  * gradient call that follows, which then carries US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED.  With US_GRID_BWD_OVERWRITE the entries of

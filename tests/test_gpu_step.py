@@ -763,3 +763,37 @@ def test_mapstep_joint_grids_equal_separate_grids(pair):
     assert torch.equal(res[True][8], res[False][8])
     close = torch.isclose(res[True][9], res[False][9], rtol=1e-5, atol=1e-6)
     assert float((~close).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("joint", [True, False])
+def test_mapstep_table_gradient_in_ranges(joint):
+    """max_workspace_bytes: a batch whose table-gradient scratch would exceed the budget is walked in ranges of rays
+    (us_hashgrid_bwd_joint_range / us_hashgrid_bwd_binned_range: first range OVERWRITE, the others add); same gradients and
+    parameters as the one-pass step, with a workspace several times smaller."""
+    import unislam_amd as us
+    R, S = 1000, 40
+    ro, rd, gd, gc = _rays(R, seed=33, outside=True)
+    t_rand = torch.rand(R, S, device=DEV)
+    res = {}
+    for budget in (4 << 30, 48 << 20):
+        torch.manual_seed(4)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, joint=joint, max_workspace_bytes=budget)
+        if budget < (1 << 30):
+            assert 0 < step.chunk_rays < R and step.ws_bytes <= budget, (step.chunk_rays, step.ws_bytes)
+        else:
+            assert step.chunk_rays == 0
+        loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+        g = step.grad.clone()
+        step.adam_step()
+        step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+        res[budget] = (g, loss.clone(), step.flat.clone(), step.ws_bytes)
+    a, b = res[4 << 30], res[48 << 20]
+    assert b[3] * 3 < a[3]
+    assert torch.equal(a[1], b[1])
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6 * float(a[0].abs().max()))
+    close = torch.isclose(a[2], b[2], rtol=1e-5, atol=1e-6)
+    assert float((~close).float().mean()) < 1e-4

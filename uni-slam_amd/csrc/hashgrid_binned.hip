@@ -147,7 +147,9 @@ template <int F, bool WRITE, bool PACKED = false>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_levels, uint32_t TB, const float* __restrict__ x,
                                                      const float* __restrict__ dL_dy, int64_t n, int clamp, int lm,
                                                      uint32_t* __restrict__ wg_counts, const uint32_t* __restrict__ wg_prefix,
-                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec, int all_live) {
+                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ rec, int all_live,
+                                                     int64_t plane_stride) {
+    // plane_stride: points per level plane of a level-major dL_dy (= n, or the whole batch when x / dL_dy are a range of it)
     // all_live: every point counts as live whatever its gradient (the counts came from the forward pass, which has no
     // gradients to look at: us_hashgrid_fwd_counted); a dead sample then emits zero records.
     // lcnt: COUNT pass: records per bin.  WRITE pass: cursor into the workgroup's LDS stage, where the records of one level
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
     // The gradient of level l+1 is requested while level l is worked on, and CONSUMED before level l's first record store: on gfx9 a
     // wait for a load also waits for every store issued before it (one vmcnt counter), so a load must never be waited for behind
     // this level's stores.  (Round 1 held all levels' gradients in 2 x 32 registers instead; the vertex runs need those registers.)
-    const int64_t dy_base = lm ? i * F : i * (int64_t)(n_levels * F), dy_step = lm ? n * F : (int64_t)F;
+    const int64_t dy_base = lm ? i * F : i * (int64_t)(n_levels * F), dy_step = lm ? plane_stride * F : (int64_t)F;
     auto load_dy = [&](uint32_t level, float (&d)[F]) {
 #pragma unroll
         for (int f = 0; f < F; ++f) d[f] = 0.0f;
@@ -588,7 +590,8 @@ extern "C" int us_hashgrid_bwd_binned_supported(const us_grid_desc* d, int64_t n
 }
 
 static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
-                      int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only) {
+                      int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only, int64_t plane_stride = 0) {
+    const int64_t ps = plane_stride > 0 ? plane_stride : n;
     US_REQUIRE(d, US_ERR_NULL, "us_hashgrid_bwd_binned: desc is NULL");
     US_REQUIRE(d->n_levels >= 1 && d->n_levels <= US_MAX_LEVELS && (d->n_features == 1 || d->n_features == 2 || d->n_features == 4) &&
                d->n_params == d->offset[d->n_levels] * d->n_features, US_ERR_CONFIG, "us_hashgrid_bwd_binned: bad descriptor");
@@ -636,14 +639,14 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #define LAUNCH_BIN_P(F, P)                                                                                                     \
-    if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0); \
+    if (!counted) hipLaunchKernelGGL((k_bin<F, false>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, 0, ps); \
     if (!scanned) {                                                                                                            \
         hipLaunchKernelGGL((k_bin_colscan<F>), dim3(us_cdiv(TB, COLSCAN_BINS)), dim3(COLSCAN_THREADS), 0, s, t, bm, L, wg_counts, wg_prefix, n_wg, \
                            (uint32_t)TB, totals, grad_params, overwrite, chunk0);                                              \
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, totals, (uint32_t)TB, offsets, extra, n_extra, chunk0);      \
     }                                                                                                                          \
     if (scan_only) break;                                                                                                      \
-    hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted); \
+    hipLaunchKernelGGL((k_bin<F, true, P>), gridA, block, 0, s, lv, L, (uint32_t)TB, x, dL_dy, n, clamp, lm, wg_counts, wg_prefix, offsets, rec, counted, ps); \
     hipLaunchKernelGGL((k_bin_accum<F, P>), dim3(e_max + TB), dim3(ACC_THREADS), 0, s, t, bm, L, e_max, offsets, extra, n_extra, rec, \
                        grad_params, overwrite);
 #define LAUNCH_BIN(F) LAUNCH_BIN_P(F, false)
@@ -661,6 +664,14 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
 extern "C" int us_hashgrid_bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* grad_params,
                                       int flags, void* workspace, size_t workspace_bytes, void* stream) {
     return bwd_binned(d, x, dL_dy, n, grad_params, flags, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int us_hashgrid_bwd_binned_range(const us_grid_desc* d, const float* x, const float* dL_dy, int64_t n, int64_t plane_stride,
+                                            float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(plane_stride >= n, US_ERR_SHAPE, "us_hashgrid_bwd_binned_range: plane_stride %lld < n %lld", (long long)plane_stride, (long long)n);
+    US_REQUIRE(!(flags & (US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED)), US_ERR_CONFIG,
+               "us_hashgrid_bwd_binned_range: the counts of a forward pass belong to the whole batch, not to a range of it");
+    return bwd_binned(d, x, dL_dy, n, grad_params, flags, workspace, workspace_bytes, stream, false, plane_stride);
 }
 
 extern "C" int us_hashgrid_bwd_scan(const us_grid_desc* d, int64_t n, float* grad_params, int flags, void* workspace,

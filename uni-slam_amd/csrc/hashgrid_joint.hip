@@ -370,7 +370,8 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const float* __restrict__ dyA, const float* __restrict__ dyB, int64_t n, int clamp,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
-                                                            uint32_t row_stride, uint32_t* __restrict__ rec, uint32_t rec_cap_dw) {
+                                                            uint32_t row_stride, uint32_t* __restrict__ rec, uint32_t rec_cap_dw,
+                                                            int64_t plane_stride) {
     __shared__ uint4 st4[J_STAGE];                               // {local entry, d0, d1, address of the record in dwords}: 64 KiB
     __shared__ uint32_t cur[2][J_LVL_BINS];                      // [level parity][bin of the level]: stage cursor
     __shared__ uint32_t gdl[2][J_LVL_BINS];                      // address of a record (dwords) = cursor * 3 + gdl
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
     auto load_dy = [&](uint32_t level, float (&d)[4]) {          // level-major gradient planes [L][N][2]
         d[0] = d[1] = d[2] = d[3] = 0.0f;
         if (in) {
-            const float2 a = *reinterpret_cast<const float2*>(dyA + ((int64_t)level * n + i) * 2);
-            const float2 b = *reinterpret_cast<const float2*>(dyB + ((int64_t)level * n + i) * 2);
+            const float2 a = *reinterpret_cast<const float2*>(dyA + ((int64_t)level * plane_stride + i) * 2);
+            const float2 b = *reinterpret_cast<const float2*>(dyB + ((int64_t)level * plane_stride + i) * 2);
             d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
         }
     };
@@ -739,7 +740,8 @@ extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* 
 }
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
-                     float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only) {
+                     float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
+                     int64_t plane_stride = 0) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -781,7 +783,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     }
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
     hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                       w.stride, w.rec, w.rec_cap_dw);
+                       w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
     hipLaunchKernelGGL(k_jaccum, dim3(2u * (ACC_EXTRA_MAX + (uint32_t)TB)), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
                        w.extra, w.hdr, w.rec, gradA, gradB, overwrite);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
@@ -799,4 +801,13 @@ extern "C" int us_hashgrid_joint_scan(const us_grid_desc* a, const us_grid_desc*
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     return bwd_joint(a, b, nullptr, nullptr, nullptr, n, gradA, gradB, (flags | US_GRID_BWD_COUNTED | US_GRID_LEVEL_MAJOR) & ~US_GRID_BWD_SCANNED,
                      workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int us_hashgrid_bwd_joint_range(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
+                                           const float* dL_dyB, int64_t n, int64_t plane_stride, float* gradA, float* gradB, int flags,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(plane_stride >= n, US_ERR_SHAPE, "us_hashgrid_bwd_joint_range: plane_stride %lld < n %lld", (long long)plane_stride, (long long)n);
+    US_REQUIRE(!(flags & (US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED)), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint_range: the counts of a forward pass belong to the whole batch, not to a range of it");
+    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, plane_stride);
 }

@@ -36,7 +36,7 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None, deterministic=False):
+                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -62,6 +62,10 @@ class MapStep:
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
         self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
+        # budget of the table gradient's scratch (it is sized for the worst case, 8 records per point and level: 3 KB per point for
+        # both grids).  A batch that would need more is walked in ranges of rays (us_hashgrid_bwd_*_range), the first range writing
+        # the gradient tables, the others adding: 4096 x 64 needs 0.8 GB, the 32 768-ray sweep point 6.6 GB -> two ranges.
+        self.max_ws = int(max_workspace_bytes)
         self.count_in_forward, self._counted = True, False
         # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
         # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
@@ -170,6 +174,17 @@ class MapStep:
         self.beta_part = f(R)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
         lib = L.lib()
+        self.chunk_rays = 0                                # > 0: the table gradient walks the batch in ranges of this many rays
+        N_all = N
+        need = lambda n: max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), n)),
+                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), n)),
+                             int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), n)))
+        if self.bwd_mode in (-1, 3) and need(N) > self.max_ws and R > 16:
+            parts = 2
+            while need(-(-R // parts) * S) > self.max_ws and -(-R // parts) > 16:
+                parts += 1
+            self.chunk_rays = -(-R // parts)
+            N = self.chunk_rays * S                        # the scratch below is sized for one range
         self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
         if self.bwd_mode == -1 and not (lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.es.desc), N) and
@@ -191,6 +206,7 @@ class MapStep:
         self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev) if self.overlap else self.mlp_ws
         if self.ws_s is None:
             self.ws_s = self.ws
+        N = N_all
 
     class _Branch:
         """`with step._branch() as st2:` -- the launches inside go to the side stream (st2 = its handle), which first waits
@@ -304,6 +320,8 @@ class MapStep:
         scan = counted and self.scan_in_forward and not self._probing
         self._scanned = scan
         bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed | self._det
+        if self.chunk_rays:
+            backward_follows = False                             # the counts of a forward pass belong to the whole batch, not to its ranges
         self._jcounted = False
         if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
@@ -416,7 +434,9 @@ class MapStep:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
 
-        if self.joint:
+        if self.chunk_rays and binned:
+            self._backward_in_ranges(R, on_ready)
+        elif self.joint:
             # the two decoder backward passes side by side, then ONE binned pass for both tables
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
@@ -459,6 +479,31 @@ class MapStep:
             L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
         self.n_rays = R
         return self.loss
+
+    def _backward_in_ranges(self, R, on_ready):
+        """the decoders' backward passes over the whole batch, then the table gradients range by range (scratch within max_workspace_bytes)"""
+        lib, st, P, S, N, fl = L.lib(), L.stream(), L.ptr, self.S, R * self.S, self.flat
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
+        L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c),
+                               off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st), "us_mlp_bwd")
+        L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s),
+                               off(self.grad, self.o_dec_s), 1, P(self.mlp_ws_s), self.mlp_ws_bytes, st), "us_mlp_bwd")
+        for k, r0 in enumerate(range(0, R, self.chunk_rays)):
+            n_k, i0 = (min(R, r0 + self.chunk_rays) - r0) * S, r0 * S
+            flags = 3 | self._det | (L.US_GRID_BWD_OVERWRITE if k == 0 else 0)
+            x, dya, dyb = off(self.pts, 3 * i0), off(self.d_feat_s, 2 * i0), off(self.d_feat_c, 2 * i0)
+            if self.joint:
+                L.check(lib.us_hashgrid_bwd_joint_range(ds, dc, x, dya, dyb, n_k, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                        flags, P(self.ws), self.ws_bytes, st), "us_hashgrid_bwd_joint_range")
+            else:
+                L.check(lib.us_hashgrid_bwd_binned_range(dc, x, dyb, n_k, N, off(self.grad, self.o_tab_c), flags | self._packed, P(self.ws),
+                                                         self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
+                L.check(lib.us_hashgrid_bwd_binned_range(ds, x, dya, n_k, N, off(self.grad, self.o_tab_s), flags | self._packed, P(self.ws_s),
+                                                         self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
+        if on_ready is not None:
+            on_ready(self.grad[self.o_tab_c:])
 
     def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False, zero_depth_draws=None):
         """single-process forward + backward (no optimiser step); returns loss[1]"""
