@@ -313,6 +313,8 @@ class MapStep:
         # the sdf and the colour branch are independent between the sample points and the compositing: two streams
         # with the binned backward the encoder also leaves the binning counts of these points in the branch's workspace
         # (us_hashgrid_fwd_counted: the gathers bound the kernel, the counting rides along), and the backward skips its count pass
+        if self.chunk_rays:
+            backward_follows = False                             # the counts of a forward pass belong to the whole batch, not to its ranges
         counted = self.ws is not None and self.count_in_forward and backward_follows
         self._counted = counted
         # ... and, if asked for, the two scan passes of the binning, which depend on those counts only, follow the encoder at once (a
@@ -320,8 +322,6 @@ class MapStep:
         scan = counted and self.scan_in_forward and not self._probing
         self._scanned = scan
         bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed | self._det
-        if self.chunk_rays:
-            backward_follows = False                             # the counts of a forward pass belong to the whole batch, not to its ranges
         self._jcounted = False
         if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
