@@ -580,7 +580,10 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
                                                           const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
                                                           const uint32_t* __restrict__ rec, float* __restrict__ gradA,
                                                           float* __restrict__ gradB, int overwrite) {
-    __shared__ double acc[J_ACC_DOUBLES];                        // by component: acc[f * nl + loc] (bank spread)
+    // accumulators by component: acc[f * nl + loc] (bank spread).  A slice of few entries (the 2^16-entry sdf table: 256 per bin, ~25
+    // records each) is kept in REP copies, lane l adding into copy l % REP: lanes that meet on one entry no longer serialise on one
+    // address; the copies are REP_PAD doubles apart in bank phase and summed in the sweep.
+    __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
     const uint32_t side = blockIdx.x & 1u, slot = blockIdx.x >> 1;  // side 0: grid A, 1: grid B
     uint32_t b, chunk = 0;
     const uint32_t CH = hdr[1];                                  // records per workgroup (k_jscan)
@@ -596,6 +599,8 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
     const JLevel q = j_level(lv, jb.level);
     const uint32_t hs = side ? q.hsB : q.hsA, lg = side ? q.lgB : q.lgA;
     const uint32_t nl = bin_n_local(hs, jb.bl, lg);
+    const uint32_t REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u, rstride = 2u * nl + 8u;       // copies and their distance in doubles
+    double* my = acc + (threadIdx.x & (REP - 1u)) * rstride;
     float* gl = (side ? gradB : gradA) + (size_t)(side ? q.offB : q.offA) * 2u;
     const uint32_t b0 = rec_off[b], b1 = rec_off[b + 1];
     const bool hot = (b1 - b0) > CH;                             // several workgroups add into this bin's entries
@@ -630,14 +635,14 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
             if (at + u * J_ACC_THREADS + threadIdx.x <= r_last) {
                 const uint32_t lc = w3[buf][u].x;
                 if (lc < nl) {
-                    atomicAdd(&acc[lc], (double)__uint_as_float(w3[buf][u].y));               // ds_add_f64
-                    atomicAdd(&acc[nl + lc], (double)__uint_as_float(w3[buf][u].z));
+                    atomicAdd(&my[lc], (double)__uint_as_float(w3[buf][u].y));                // ds_add_f64
+                    atomicAdd(&my[nl + lc], (double)__uint_as_float(w3[buf][u].z));
                 }
             }
         }
     };
     fetch(0, r0);                                                // in flight while the accumulators are cleared
-    for (uint32_t k = threadIdx.x; k < 2u * nl; k += J_ACC_THREADS) acc[k] = 0.0;
+    for (uint32_t k = threadIdx.x; k < REP * rstride; k += J_ACC_THREADS) acc[k] = 0.0;
     __syncthreads();
     for (uint32_t at = r0;;) {
         fetch(1, at + STEP); add(0, at); at += STEP;
@@ -650,7 +655,9 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
         const uint32_t e = entry_of(loc, jb.bl, lg);
         if (e >= hs) continue;
         float* p = gl + (size_t)e * 2u;
-        const float v0 = (float)acc[loc], v1 = (float)acc[nl + loc];
+        double s0 = acc[loc], s1 = acc[nl + loc];
+        for (uint32_t r = 1; r < REP; ++r) { s0 += acc[r * rstride + loc]; s1 += acc[r * rstride + nl + loc]; }   // fixed order
+        const float v0 = (float)s0, v1 = (float)s1;
         if (hot) {
             if (v0 != 0.0f) atomicAdd(p, v0);
             if (v1 != 0.0f) atomicAdd(p + 1, v1);
