@@ -90,9 +90,6 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * does not see: results repeat bit for bit from run to run (tests/test_gpu_joint.py).  Slower when the batch concentrates on few
  * cells (one workgroup then walks a hot bin alone); meant for diffing runs. */
 #define US_GRID_BWD_DETERMINISTIC 128
-/* US_GRID_FWD_LEVEL_ORDER (us_hashgrid_fwd_joint): dispatch the blocks level after level (round 1's order) instead of giving each
- * XCD its own pair of levels; for A/B measurements. */
-#define US_GRID_FWD_LEVEL_ORDER 256
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 

@@ -20,7 +20,6 @@ US_GRID_BWD_COUNTED = 16
 US_GRID_BWD_PACKED = 32
 US_GRID_BWD_SCANNED = 64
 US_GRID_BWD_DETERMINISTIC = 128
-US_GRID_FWD_LEVEL_ORDER = 256
 US_MLP_LEVEL_MAJOR = 1
 
 c_f = ctypes.c_void_p          # device pointers travel as void*

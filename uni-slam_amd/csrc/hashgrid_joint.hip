@@ -123,23 +123,11 @@ static int make_jlevels(const us_grid_desc* a, const us_grid_desc* b, int64_t n,
 template <bool GATHER, bool COUNT>
 __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
-                                                        int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
-                                                        uint32_t n_wg, int xcd_levels) {
+                                                        int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows) {
     constexpr int HALVES = J_FWD_THREADS / J_ROW_POINTS;
     __shared__ uint32_t lcnt[HALVES][J_LVL_BINS];
     __shared__ uint32_t done;
-    // Block -> (workgroup of points, level).  Blocks are dealt round-robin over the 8 XCDs (observed, not promised: speed only), and
-    // every XCD has its own L2.  With "level = blockIdx.y" each XCD walks ALL levels for an eighth of the points, so every table slab
-    // is pulled into all 8 L2s: 8 x 49 MB of fills per launch.  xcd_levels: the blocks of XCD class x = id % 8 take the levels
-    // x, 15 - x, 8 + x, ... (a cheap coarse level paired with an expensive fine one) for ALL points: a slab lives in one L2.
-    uint32_t level, wg;
-    if (xcd_levels) {
-        const uint32_t x = blockIdx.x & 7u, s = blockIdx.x >> 3, j = s / n_wg;
-        wg = s - j * n_wg;
-        level = (j & 1u) ? (n_levels - 1u - x - 8u * (j >> 1)) : (x + 8u * (j >> 1));
-    } else {
-        level = blockIdx.x / n_wg; wg = blockIdx.x - level * n_wg;
-    }
+    const uint32_t level = blockIdx.y;
     const JLevel q = lv.l[level];
     const uint32_t nlb = j_level_bins(q);
     if (COUNT) {
@@ -148,7 +136,7 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, lg16 = lane & (RUN_GROUP - 1);
-    const int64_t i = (int64_t)wg * J_FWD_THREADS + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * J_FWD_THREADS + threadIdx.x;
     const bool in = i < n;
     float pos[3]; uint32_t cell[3];
 #pragma unroll
@@ -202,7 +190,7 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
     if (ticket == J_FWD_THREADS / 64 - 1) {
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
-            const uint32_t r = HALVES * wg + h;
+            const uint32_t r = HALVES * blockIdx.x + h;
             if (r >= n_rows) break;
             uint32_t* row = counts + (size_t)r * row_stride + q.first;
             for (uint32_t t = (uint32_t)lane; t < nlb; t += 64) row[t] = lcnt[h][t];
@@ -743,18 +731,16 @@ extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* 
     US_REQUIRE(paramsA && paramsB && x && outA && outB, US_ERR_NULL, "us_hashgrid_fwd_joint: NULL pointer");
     US_REQUIRE(((uintptr_t)paramsA & 15u) == 0 && ((uintptr_t)paramsB & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_fwd_joint: params must be 16-byte aligned");
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
-    const uint32_t n_wg = (uint32_t)us_cdiv(n, J_FWD_THREADS);
-    const int xcd_levels = (a->n_levels % 8u == 0u && !(flags & US_GRID_FWD_LEVEL_ORDER)) ? 1 : 0;
-    dim3 grid(n_wg * a->n_levels), block(J_FWD_THREADS);
+    dim3 grid((unsigned)us_cdiv(n, J_FWD_THREADS), a->n_levels), block(J_FWD_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (workspace) {
         US_REQUIRE(((uintptr_t)workspace & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_fwd_joint: workspace must be 16-byte aligned");
         US_REQUIRE(workspace_bytes >= us_hashgrid_joint_workspace_bytes(a, b, n), US_ERR_WORKSPACE,
                    "us_hashgrid_fwd_joint: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
         const JWorkspace w = j_carve(workspace, a->n_levels, TB, n);
-        hipLaunchKernelGGL((k_jfwd<true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, n_wg, xcd_levels);
+        hipLaunchKernelGGL((k_jfwd<true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows);
     } else {
-        hipLaunchKernelGGL((k_jfwd<true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, n_wg, xcd_levels);
+        hipLaunchKernelGGL((k_jfwd<true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u);
     }
     US_CHECK_LAUNCH("us_hashgrid_fwd_joint");
     return US_OK;
@@ -791,9 +777,8 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     const int clamp = flags & US_GRID_CLAMP01;
     const uint32_t L = a->n_levels;
     if (!counted)
-        hipLaunchKernelGGL((k_jfwd<false, true>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS) * L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
-                           (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows,
-                           (uint32_t)us_cdiv(n, J_FWD_THREADS), 0);
+        hipLaunchKernelGGL((k_jfwd<false, true>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
+                           (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
     if (!scanned) {
         hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,
                            (uint32_t)TB, w.totals, gradA, gradB, overwrite, chunk0);
