@@ -628,6 +628,7 @@ class TrackStep:
         self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
         self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
         self.desc_s, self.desc_c = decoders.mlp_descs()
+        self._joint = None
         self._alloc(max_rays)
 
     def _alloc(self, R):
@@ -681,9 +682,15 @@ class TrackStep:
                                      ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
                                      P(self.pstep) if hasattr(self, "pstep") else None, 1 if self.perturb else 0, 1, P(self.valid),
                                      P(self.z), P(self.pts), st), "us_sample_points")
-        # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers
-        L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
-        L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
+        # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers.  Both tables in
+        # one launch where the pair of grids qualifies (positions and cells computed once, one launch less in a latency-bound chain)
+        if self._joint is None:
+            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
+        if self._joint:
+            L.check(lib.us_hashgrid_fwd_joint(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), 3, None, 0, st), "us_hashgrid_fwd_joint")
+        else:
+            L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
+            L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
         L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
         L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), P(self._beta), R, S, P(self.term), P(self.unc), P(self.depth),
