@@ -207,6 +207,10 @@ size_t us_mlp_n_params(const us_mlp_desc* d);
 /* flags: US_MLP_LEVEL_MAJOR -> `in` (and `dL_din`) are the hash grid's level-major [16][N][2] planes (feature k lives in
  * plane k/2, component k%2) instead of row-major [N][32] */
 #define US_MLP_LEVEL_MAJOR 1
+/* US_MLP_DEFER_REDUCE (us_mlp_bwd with a workspace): leave the per-workgroup partial weight gradients in the workspace; the caller adds
+ * them with us_mlp_reduce later -- e.g. on another stream, beside the table gradient, instead of ahead of it */
+#define US_MLP_DEFER_REDUCE 2
+int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t workspace_bytes, int64_t n, float* grad_params, void* stream);
 
 /* out[i*out_stride + o] = act(MLP(in[i][:]))[o], o < n_out   (out_stride lets two decoders write one raw[N][4]) */
 int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n,
@@ -304,6 +308,14 @@ int us_composite_bwd(const float* raw, const float* z_vals, const float* beta, i
  * Two phases so that data-dependent mask COUNTS can be all-reduced across ranks before gradients are scaled.
  * ---------------------------------------------------------------------------------------------- */
 enum { US_LOSS_MAP_ORIGINAL = 0, US_LOSS_MAP_NOMASK = 1, US_LOSS_TRK_ORIGINAL = 2, US_LOSS_TRK_NOMASK = 3 };
+/* or-ed into `mode` of us_render_loss_bwd: the per-ray d(beta) partials are left in beta_partials and summed by the caller's
+ * us_beta_reduce(beta_partials, n_rays, d_beta, stream) (d_beta += fixed-order sum), off the backward pass's critical path */
+#define US_LOSS_DEFER_BETA 256
+int us_beta_reduce(const float* beta_partials, int64_t n_rays, float* d_beta, void* stream);
+/* us_adam_step_segments(_dev): bit 31 of zero_grad_mask = the device-side step count was already advanced for this step by
+ * us_adam_step_inc(step_dev, beta1, beta2, stream) (one thread: count + 1 and the two bias corrections) */
+#define US_ADAM_STEP_ADVANCED 0x80000000u
+int us_adam_step_inc(float* step_dev, double beta1, double beta2, void* stream);
 enum { US_LS_FS = 0, US_LS_CENTER = 1, US_LS_TAIL = 2, US_LS_COLOR = 3, US_LS_DEPTH = 4, US_LS_N = 5 };
 /* stats[10]: sums[5] then counts[5] (fp32; overwritten).  sdf[(r*S+s)*sdf_stride] (stride 4 reads raw[R][S][4]'s
  * 4th channel in place); valid[R] (nullable) drops rays the bbox pre-filter rejected without compacting the

@@ -21,6 +21,9 @@ US_GRID_BWD_PACKED = 32
 US_GRID_BWD_SCANNED = 64
 US_GRID_BWD_DETERMINISTIC = 128
 US_MLP_LEVEL_MAJOR = 1
+US_MLP_DEFER_REDUCE = 2
+US_LOSS_DEFER_BETA = 256
+US_ADAM_STEP_ADVANCED = 0x80000000
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -74,6 +77,9 @@ SIGNATURES = {
     "us_mlp_n_params": (ctypes.c_size_t, [_MP]),
     "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [_MP]),
+    "us_mlp_reduce": (c_int, [_MP, c_f, ctypes.c_size_t, c_i64, c_f, c_f]),
+    "us_beta_reduce": (c_int, [c_f, c_i64, c_f, c_f]),
+    "us_adam_step_inc": (c_int, [c_f, c_dbl, c_dbl, c_f]),
     "us_mlp_bwd": (c_int, [_MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_sample_z": (c_int, [c_f, c_i64, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt, c_f, c_f, c_f]),
     "us_ray_points": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f]),

@@ -606,10 +606,26 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     else MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                       dout_stride, n, dL_din, grad_params, lm, partials);
     US_CHECK_LAUNCH("us_mlp_bwd");
-    if (partials) {
+    if (partials && !(flags & US_MLP_DEFER_REDUCE)) {
         const int np = (int)us_mlp_n_params(d);
         hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, s, partials, (int)nb, np, grad_params);
         US_CHECK_LAUNCH("us_mlp_bwd(reduce)");
     }
+    return US_OK;
+}
+
+// the reduction us_mlp_bwd(..., US_MLP_DEFER_REDUCE, workspace) left out: grad_params += sum of the workspace's partial rows (fixed order)
+extern "C" int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t workspace_bytes, int64_t n, float* grad_params, void* stream) {
+    int rc = check_mlp("us_mlp_reduce", d); if (rc) return rc;
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(workspace && grad_params, US_ERR_NULL, "us_mlp_reduce: NULL pointer");
+    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(d), US_ERR_WORKSPACE, "us_mlp_reduce: workspace %zu B < %zu B", workspace_bytes,
+               us_mlp_bwd_workspace_bytes(d));
+    const bool bf = d->precision != US_PREC_F32;
+    const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
+    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;
+    const int np = (int)us_mlp_n_params(d);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, (int)nb, np, grad_params);
+    US_CHECK_LAUNCH("us_mlp_reduce");
     return US_OK;
 }

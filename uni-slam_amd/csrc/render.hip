@@ -1190,6 +1190,8 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
                                   const uint8_t* valid, const float* gt_depth, const float* gt_color, const float* depth, const float* rgb,
                                   const float* pixel_unc, double truncation, const float* w5_host, const float* stats, float* d_raw,
                                   float* d_beta, float* beta_partials, float* loss_out, void* stream) {
+    const bool defer_beta = (mode & US_LOSS_DEFER_BETA) != 0;    // the caller sums the per-ray d(beta) partials itself (us_beta_reduce)
+    mode &= ~US_LOSS_DEFER_BETA;
     US_REQUIRE(mode == US_LOSS_MAP_ORIGINAL || mode == US_LOSS_MAP_NOMASK || mode == US_LOSS_TRK_NOMASK, US_ERR_CONFIG,
                "us_render_loss_bwd: mode %d needs the median of the rendered depth error (use us_loss_grad + us_composite_bwd)", mode);
     US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_render_loss_bwd: empty batch");
@@ -1210,10 +1212,18 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
         hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, d_beta,
                            d_beta ? beta_partials : nullptr, lb);
     US_CHECK_LAUNCH("us_render_loss_bwd");
-    if (d_beta && beta_partials) {
+    if (d_beta && beta_partials && !defer_beta) {
         hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, s, beta_partials, n_rays, d_beta);
         US_CHECK_LAUNCH("us_render_loss_bwd(beta)");
     }
+    return US_OK;
+}
+
+extern "C" int us_beta_reduce(const float* beta_partials, int64_t n_rays, float* d_beta, void* stream) {
+    US_REQUIRE(beta_partials && d_beta, US_ERR_NULL, "us_beta_reduce: NULL pointer");
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    hipLaunchKernelGGL(k_beta_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, beta_partials, n_rays, d_beta);
+    US_CHECK_LAUNCH("us_beta_reduce");
     return US_OK;
 }
 
@@ -1311,7 +1321,9 @@ static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, cons
         sg.off[k] = seg_off[k]; sg.n[k] = seg_n[k]; sg.step_size[k] = (float)(seg_lr[k] / bc1);
         if (seg_n[k] > n_max) n_max = seg_n[k];
     }
-    if (step_dev) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2);      // also when no element is owned
+    const bool advanced = (zero_grad_mask & US_ADAM_STEP_ADVANCED) != 0;      // us_adam_step_inc has run for this step already
+    zero_grad_mask &= ~US_ADAM_STEP_ADVANCED;
+    if (step_dev && !advanced) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2);   // also when no element is owned
     if (n_max == 0) return US_OK;
     hipLaunchKernelGGL(k_adam_segs, dim3(grid_1d(n_max, 256, 4096), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
@@ -1331,6 +1343,13 @@ extern "C" int us_adam_step_segments_dev(float* p, float* g, float* m, float* v,
                                          float* step_dev, unsigned zero_grad_mask, void* stream) {
     US_REQUIRE(step_dev && ((uintptr_t)step_dev & 7u) == 0, US_ERR_NULL, "us_adam_step_segments_dev: step_dev is NULL or not 8-byte aligned");
     return adam_segments(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, 0, step_dev, zero_grad_mask, stream);
+}
+
+extern "C" int us_adam_step_inc(float* step_dev, double beta1, double beta2, void* stream) {
+    US_REQUIRE(step_dev && ((uintptr_t)step_dev & 7u) == 0, US_ERR_NULL, "us_adam_step_inc: step_dev is NULL or not 8-byte aligned");
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2);
+    US_CHECK_LAUNCH("us_adam_step_inc");
+    return US_OK;
 }
 
 extern "C" int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* intr_host4, int W0, int H0, int crop_w,

@@ -58,6 +58,7 @@ class MapStep:
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
         self._dec_grad_clean = False
+        self._step_advanced = False
         self._joint_wanted = (group is None) if joint is None else bool(joint)
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
@@ -153,6 +154,7 @@ class MapStep:
         self.m.zero_(); self.v.zero_()
         self.opt_step = 0
         self.step_dev.zero_()
+        self._step_advanced = False
         self.lr_factor = float(lr_factor)
         self._graph = None              # a captured iteration holds the old learning rates
 
@@ -408,10 +410,14 @@ class MapStep:
         self._dec_grad_clean = False
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
-        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
+        binned = self.ws is not None
+        # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
+        # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
+        defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing and self.group is None)
+        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode | (L.US_LOSS_DEFER_BETA if (defer and gbeta is not None) else 0),
+                                       P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
                                        P(self.unc), self.truncation, self.w5, P(self.stats), P(self.d_raw), gbeta, P(self.beta_part),
                                        P(self.loss), st), "us_render_loss_bwd")
-        binned = self.ws is not None
 
         def sdf_branch(q):
             self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
@@ -438,20 +444,32 @@ class MapStep:
             self._backward_in_ranges(R, on_ready)
         elif self.joint:
             # the two decoder backward passes side by side, then ONE binned pass for both tables
+            mflags = 1 | (L.US_MLP_DEFER_REDUCE if defer else 0)
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                                                off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                                                off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             with self._branch() as st2:
                 mlp_s(st2)
             self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st))
-            self._join()
+                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
+            self._join()                                         # the main stream waits for the sdf decoder's backward pass, nothing later
+            if defer:
+                with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
+                    L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
+                    L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
+                    if gbeta is not None:
+                        L.check(lib.us_beta_reduce(P(self.beta_part), R, gbeta, st2), "us_beta_reduce")
+                    if not self._step_advanced:
+                        L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st2), "us_adam_step_inc")
+                        self._step_advanced = True
             if self.scan_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
             self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                 off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                                                                                 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0),
                                                                                 P(self.ws), self.ws_bytes, st))
+            if defer:
+                self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
             if on_ready is not None:
                 on_ready(self.grad[self.o_tab_c:])
         elif self.overlap and not self._probing:
@@ -539,6 +557,9 @@ class MapStep:
         if not segs:
             segs = [(0, 0, 0.0)]        # a rank that owns only padding still advances the device-side step count (k_step_inc), so the
         k = len(segs)                   # bias corrections and the sampler's jitter salt stay in lock-step over the ranks
+        if self._step_advanced:         # backward() already queued the step increment (us_adam_step_inc, beside the table gradient)
+            zero_mask |= L.US_ADAM_STEP_ADVANCED
+            self._step_advanced = False
         I64, DBL = ctypes.c_int64 * k, ctypes.c_double * k
         # the step count lives on the device (advanced by the launch itself): nothing in the arguments changes between iterations
         L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), k, I64(*[g[0] for g in segs]),
