@@ -153,6 +153,17 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* us_hashgrid_bwd_joint + torch.optim.Adam of the two tables in one pass (single process; flags must carry US_GRID_BWD_OVERWRITE): the
+ * workgroup that has summed a bin's gradient entries updates params / m / v of exactly those entries (every table entry belongs to one
+ * bin), so the 6 x n_params floats of optimiser traffic stream under the LDS atomics that bound the accumulate pass instead of in a
+ * pass of their own (src/Mapper.py:443-445: backward, then optimizer.step() over the table param groups of :118-126).  The gradient
+ * tables are still written.  step_dev: the device-side step count of us_adam_step_segments_dev, ALREADY advanced for this step
+ * (us_adam_step_inc); lrA / lrB: the two tables' learning rates.  Same arithmetic as us_adam_step_segments_dev. */
+int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
+                               int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes,
+                               float* paramsA, float* paramsB, float* mA, float* mB, float* vA, float* vB, double lrA, double lrB,
+                               double beta1, double beta2, double eps, const float* step_dev, void* stream);
+
 /* The table gradient of a RANGE of the batch: x / dL_dy* point at the range's first point, n = points in the range, plane_stride =
  * points of the whole batch (the distance between the level planes of a level-major dL_dy).  The gradient is additive over points,
  * so a batch whose scratch (us_hashgrid_*_workspace_bytes grows with n) would exceed a budget is walked in ranges -- the first with

@@ -797,3 +797,40 @@ def test_mapstep_table_gradient_in_ranges(joint):
     assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6 * float(a[0].abs().max()))
     close = torch.isclose(a[2], b[2], rtol=1e-5, atol=1e-6)
     assert float((~close).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("pair", [(16, 19), (16, 16)])
+def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
+    """MapStep.iterate() of a single process applies Adam to the two tables inside the accumulate pass of the joint table gradient
+    (us_hashgrid_bwd_joint_adam: the workgroup that summed a bin updates that bin's entries).  Same parameters, moments and losses as
+    the separate dense pass (k_adam_segs) -- over several iterations, a fresh optimiser in between (Mapper.py:358-364), a degenerate
+    batch whose hot bins take the k_jadam_hot route, and with the one-grid kernels as a third reference."""
+    import unislam_amd as us
+    R, S = 700, 40
+    batches = [_rays(R, seed=40 + k, outside=True) for k in range(3)]
+    hot = list(_rays(R, seed=50))
+    hot[0] = hot[0][:1].repeat(R, 1).contiguous(); hot[1] = hot[1][:1].repeat(R, 1).contiguous()    # every ray the same: hot bins
+    batches.append(tuple(hot))
+    res = {}
+    for name, kw in (("fused", dict(joint=True, fuse_adam=True)), ("joint", dict(joint=True, fuse_adam=False)), ("single", dict(joint=False))):
+        torch.manual_seed(4)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(pair[0])).to(DEV), us.HashGridEncoding(3, _ecfg(pair[1])).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, **kw)
+        losses = []
+        for k, (ro, rd, gd, gc) in enumerate(batches):
+            t_rand = torch.rand(R, S, generator=torch.Generator().manual_seed(60 + k)).to(DEV)
+            losses.append(float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)))
+            if k == 1:
+                step.reset_optimizer(5.0)
+        res[name] = (losses, step.flat.clone(), step.m.clone(), step.v.clone(), float(step.step_dev[0]))
+    for other in ("joint", "single"):
+        a, b = res["fused"], res[other]
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+        assert a[4] == b[4] == 2.0                                              # two steps since the optimiser was reset
+        for k in (1, 2, 3):
+            close = torch.isclose(a[k], b[k], rtol=1e-5, atol=1e-7)
+            assert float((~close).float().mean()) < 1e-4, (other, k, float((~close).float().mean()))
+    assert torch.equal(res["fused"][1], res["joint"][1])                        # same gradients, same arithmetic: bit-identical tables

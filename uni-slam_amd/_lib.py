@@ -71,6 +71,8 @@ SIGNATURES = {
     "us_hashgrid_bwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_range": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_binned_range": (c_int, [_GP, c_f, c_f, c_i64, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f, c_f, c_f, c_f, c_f, c_f,
+                                           c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_hashgrid_joint_scan": (c_int, [_GP, _GP, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_hashgrid_bwd_input_gather": (c_int, [_GP, c_f, c_f, c_f, c_i64, c_f, c_int, c_f]),

@@ -36,7 +36,7 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30):
+                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30, fuse_adam=True):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -59,6 +59,10 @@ class MapStep:
         self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
         self._dec_grad_clean = False
         self._step_advanced = False
+        # fuse_adam: iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table entries it
+        # has just summed (us_hashgrid_bwd_joint_adam); adam_step() then covers the decoders only.  forward() / backward() / adam_step()
+        # called one by one keep the separate optimiser pass.
+        self.fuse_adam = bool(fuse_adam)
         self._joint_wanted = (group is None) if joint is None else bool(joint)
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
@@ -348,6 +352,9 @@ class MapStep:
                 self.scan_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.scan_stream):
                     L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
+                    if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
+                        L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
+                        self._step_advanced = True
             with self._branch() as st2:
                 self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
             self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
@@ -384,7 +391,7 @@ class MapStep:
         self.n_rays = R
         return self.stats
 
-    def backward(self, on_ready=None, ray_grads=False):
+    def backward(self, on_ready=None, ray_grads=False, fuse_adam=False):
         """
         Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
         ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
@@ -464,10 +471,22 @@ class MapStep:
                         self._step_advanced = True
             if self.scan_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
-            self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
-                                                                                off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                                                3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0),
-                                                                                P(self.ws), self.ws_bytes, st))
+            jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
+            self._adam_fused = bool(fuse_adam and self.fuse_adam and self.group is None)
+            if self._adam_fused:
+                if not self._step_advanced:                      # (a forward pass that did not queue it: probing / one-stream mode)
+                    L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
+                    self._step_advanced = True
+                f_ = self.lr_factor
+                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint_adam(
+                    ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
+                    P(self.ws), self.ws_bytes, off(fl, self.o_tab_s), off(fl, self.o_tab_c), off(self.m, self.o_tab_s), off(self.m, self.o_tab_c),
+                    off(self.v, self.o_tab_s), off(self.v, self.o_tab_c), self.lr["sdf_grid"] * f_, self.lr["color_grid"] * f_, 0.9, 0.999, 1e-8,
+                    P(self.step_dev), st))
+            else:
+                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
+                                                                                    off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
+                                                                                    P(self.ws), self.ws_bytes, st))
             if defer:
                 self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
             if on_ready is not None:
@@ -546,6 +565,9 @@ class MapStep:
         if ranges is None:
             segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
             self._dec_grad_clean = True                          # cleared on the way
+            if getattr(self, "_adam_fused", False):              # the tables were updated inside the table gradient's accumulate pass
+                segs = segs[:1]
+                self._adam_fused = False
         else:
             segs, zero_mask = [], 0
             for (lo, hi) in ranges:
@@ -568,6 +590,11 @@ class MapStep:
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
+        if self.group is None and self.fuse_adam:
+            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
+            loss = self.backward(fuse_adam=True)                 # ... which updates the tables where the joint pass runs
+            self.adam_step()
+            return loss
         return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth), self.group)
 
     def capture(self, n_rays, t_rand=False):
