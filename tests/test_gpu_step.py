@@ -801,8 +801,8 @@ def test_mapstep_table_gradient_in_ranges(joint):
 
 @pytest.mark.parametrize("pair", [(16, 19), (16, 16)])
 def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
-    """MapStep.iterate() of a single process applies Adam to the two tables inside the accumulate pass of the joint table gradient
-    (us_hashgrid_bwd_joint_adam: the workgroup that summed a bin updates that bin's entries).  Same parameters, moments and losses as
+    """MapStep(fuse_adam=True).iterate() of a single process applies Adam to the two tables inside the accumulate pass of the joint table
+    gradient (us_hashgrid_bwd_joint_adam: the workgroup that summed a bin updates that bin's entries; opt-in, measured slower).  Same parameters, moments and losses as
     the separate dense pass (k_adam_segs) -- over several iterations, a fresh optimiser in between (Mapper.py:358-364), a degenerate
     batch whose hot bins take the k_jadam_hot route, and with the one-grid kernels as a third reference."""
     import unislam_amd as us
