@@ -90,13 +90,6 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * does not see: results repeat bit for bit from run to run (tests/test_gpu_joint.py).  Slower when the batch concentrates on few
  * cells (one workgroup then walks a hot bin alone); meant for diffing runs. */
 #define US_GRID_BWD_DETERMINISTIC 128
-/* US_GRID_JOINT_ACCUM_A / _B (us_hashgrid_bwd_joint): run the accumulate pass for that grid only; the other grid's follows with
- * us_hashgrid_joint_accum(a, b, n, gradA, gradB, flags with the other bit, workspace, ...) on the same workspace.  A finished table's
- * gradient can then go to its consumer -- Adam, an all-reduce -- while the other table is still being summed. */
-#define US_GRID_JOINT_ACCUM_A 512
-#define US_GRID_JOINT_ACCUM_B 1024
-int us_hashgrid_joint_accum(const us_grid_desc* a, const us_grid_desc* b, int64_t n, float* gradA, float* gradB, int flags,
-                            void* workspace, size_t workspace_bytes, void* stream);
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 

@@ -20,8 +20,6 @@ US_GRID_BWD_COUNTED = 16
 US_GRID_BWD_PACKED = 32
 US_GRID_BWD_SCANNED = 64
 US_GRID_BWD_DETERMINISTIC = 128
-US_GRID_JOINT_ACCUM_A = 512
-US_GRID_JOINT_ACCUM_B = 1024
 US_MLP_LEVEL_MAJOR = 1
 US_MLP_DEFER_REDUCE = 2
 US_LOSS_DEFER_BETA = 256
@@ -75,7 +73,6 @@ SIGNATURES = {
     "us_hashgrid_bwd_binned_range": (c_int, [_GP, c_f, c_f, c_i64, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f, c_f, c_f, c_f, c_f, c_f,
                                            c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
-    "us_hashgrid_joint_accum": (c_int, [_GP, _GP, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_joint_scan": (c_int, [_GP, _GP, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_hashgrid_bwd_input_gather": (c_int, [_GP, c_f, c_f, c_f, c_i64, c_f, c_int, c_f]),

@@ -599,13 +599,12 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
                                                           const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
                                                           const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
                                                           const uint32_t* __restrict__ rec, float* __restrict__ gradA,
-                                                          float* __restrict__ gradB, int overwrite, JAdam ad, int side_sel) {
+                                                          float* __restrict__ gradB, int overwrite, JAdam ad) {
     // accumulators by component: acc[f * nl + loc] (bank spread).  A slice of few entries (the 2^16-entry sdf table: 256 per bin, ~25
     // records each) is kept in REP copies, lane l adding into copy l % REP: lanes that meet on one entry no longer serialise on one
     // address; the copies are REP_PAD doubles apart in bank phase and summed in the sweep.
     __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
-    // side 0: grid A, 1: grid B.  side_sel < 0: both grids in this launch (block -> (slot, side)); else the launch serves one grid
-    const uint32_t side = side_sel < 0 ? (blockIdx.x & 1u) : (uint32_t)side_sel, slot = side_sel < 0 ? (blockIdx.x >> 1) : blockIdx.x;
+    const uint32_t side = blockIdx.x & 1u, slot = blockIdx.x >> 1;  // side 0: grid A, 1: grid B
     uint32_t b, chunk = 0;
     const uint32_t CH = hdr[1];                                  // records per workgroup (k_jscan)
     if (slot < e_max) {
@@ -837,11 +836,10 @@ extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* 
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
                      float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
-                     int64_t plane_stride = 0, const JAdam* adam = nullptr, bool accum_only = false) {
+                     int64_t plane_stride = 0, const JAdam* adam = nullptr) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
-    if (accum_only) flags |= US_GRID_BWD_SCANNED | US_GRID_BWD_COUNTED;      // the workspace holds the records already
     const int overwrite = (flags & US_GRID_BWD_OVERWRITE) ? 1 : 0, counted = (flags & US_GRID_BWD_COUNTED) ? 1 : 0;
     if (n == 0) {                                                // no samples: the gradients are zero
         if (overwrite) {
@@ -852,14 +850,14 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         }
         return US_OK;
     }
-    const bool scanned = (flags & US_GRID_BWD_SCANNED) != 0 || accum_only;
+    const bool scanned = (flags & US_GRID_BWD_SCANNED) != 0;
     const uint32_t chunk0 = (flags & US_GRID_BWD_DETERMINISTIC) ? 0xFFFFFFFFu : (uint32_t)ACC_CHUNK;
     US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
                "us_hashgrid_bwd_joint: the scan passes can only run ahead on counts left by us_hashgrid_fwd_joint (US_GRID_BWD_COUNTED)");
-    US_REQUIRE((scan_only || accum_only || (x && dL_dyA && dL_dyB)) && gradA && gradB && workspace, US_ERR_NULL, "us_hashgrid_bwd_joint: NULL pointer");
+    US_REQUIRE((scan_only || (x && dL_dyA && dL_dyB)) && gradA && gradB && workspace, US_ERR_NULL, "us_hashgrid_bwd_joint: NULL pointer");
     US_REQUIRE(flags & US_GRID_LEVEL_MAJOR, US_ERR_CONFIG, "us_hashgrid_bwd_joint: the gradients must be level-major planes (US_GRID_LEVEL_MAJOR)");
     US_REQUIRE(((uintptr_t)gradA & 15u) == 0 && ((uintptr_t)gradB & 15u) == 0 && ((uintptr_t)workspace & 15u) == 0 &&
-               (scan_only || accum_only || (((uintptr_t)dL_dyA & 7u) == 0 && ((uintptr_t)dL_dyB & 7u) == 0)), US_ERR_SHAPE,
+               (scan_only || (((uintptr_t)dL_dyA & 7u) == 0 && ((uintptr_t)dL_dyB & 7u) == 0)), US_ERR_SHAPE,
                "us_hashgrid_bwd_joint: gradient tables and workspace must be 16-byte aligned, dL_dy 8-byte aligned");
     US_REQUIRE(workspace_bytes >= us_hashgrid_joint_workspace_bytes(a, b, n), US_ERR_WORKSPACE,
                "us_hashgrid_bwd_joint: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
@@ -879,8 +877,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, chunk0);
     }
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
-    if (!accum_only)
-        hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
+    hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
                        w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
     JAdam ad;
     memset(&ad, 0, sizeof(ad));
@@ -888,12 +885,8 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         US_REQUIRE(overwrite, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: needs US_GRID_BWD_OVERWRITE (the update uses the complete gradient)");
         ad = *adam; ad.enabled = 1;
     }
-    // the accumulate pass for both grids, or for one (US_GRID_JOINT_ACCUM_A / _B: the other follows by us_hashgrid_joint_accum, so that
-    // e.g. Adam of the finished table runs beside it)
-    const int sides = flags & (US_GRID_JOINT_ACCUM_A | US_GRID_JOINT_ACCUM_B);
-    const int side_sel = (sides == US_GRID_JOINT_ACCUM_A) ? 0 : (sides == US_GRID_JOINT_ACCUM_B) ? 1 : -1;
-    hipLaunchKernelGGL(k_jaccum, dim3((side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB)), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                       w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad, side_sel);
+    hipLaunchKernelGGL(k_jaccum, dim3(2u * (ACC_EXTRA_MAX + (uint32_t)TB)), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
+                       w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad);
     if (adam) hipLaunchKernelGGL(k_jadam_hot, dim3(ACC_EXTRA_MAX, 2), dim3(J_ACC_THREADS), 0, s, lv, L, w.extra, w.hdr, gradA, gradB, ad);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
@@ -934,11 +927,4 @@ extern "C" int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_d
     ad.one_minus_b1 = (float)(1.0 - beta1); ad.b2 = (float)beta2; ad.one_minus_b2 = (float)(1.0 - beta2); ad.eps = (float)eps;
     ad.step_dev = step_dev;
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, &ad);
-}
-
-extern "C" int us_hashgrid_joint_accum(const us_grid_desc* a, const us_grid_desc* b, int64_t n, float* gradA, float* gradB, int flags,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
-    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
-    US_REQUIRE(flags & (US_GRID_JOINT_ACCUM_A | US_GRID_JOINT_ACCUM_B), US_ERR_CONFIG, "us_hashgrid_joint_accum: name the grid (US_GRID_JOINT_ACCUM_A / _B)");
-    return bwd_joint(a, b, nullptr, nullptr, nullptr, n, gradA, gradB, flags | US_GRID_LEVEL_MAJOR, workspace, workspace_bytes, stream, false, 0, nullptr, true);
 }

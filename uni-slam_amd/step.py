@@ -392,7 +392,7 @@ class MapStep:
         self.n_rays = R
         return self.stats
 
-    def backward(self, on_ready=None, ray_grads=False, fuse_adam=False, colour_first=False):
+    def backward(self, on_ready=None, ray_grads=False, fuse_adam=False):
         """
         Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
         ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
@@ -401,7 +401,6 @@ class MapStep:
         [decoders | beta | sdf table] segment, of self.grad are final (dist.dp_iterate overlaps their all-reduces).
         """
         lib, st = L.lib(), L.stream()
-        self._sdf_accum_pending = False
         o, d, gd, gc, R = self._batch
         S, N = self.S, R * self.S
         P = L.ptr
@@ -474,11 +473,6 @@ class MapStep:
             if self.scan_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
             jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
-            # colour_first (iterate() of a single process): this call sums the colour table only; iterate() then runs Adam on the colour
-            # segment (HBM-bound) BESIDE the accumulate pass of the sdf table (LDS-bound) -- finish_sdf_table() -- instead of behind it
-            self._sdf_accum_pending = bool(colour_first and not fuse_adam and self.overlap and not self._probing)
-            if self._sdf_accum_pending:
-                jflags |= L.US_GRID_JOINT_ACCUM_B
             self._adam_fused = bool(fuse_adam and self.fuse_adam and self.group is None)
             if self._adam_fused:
                 if not self._step_advanced:                      # (a forward pass that did not queue it: probing / one-stream mode)
@@ -549,35 +543,6 @@ class MapStep:
         if on_ready is not None:
             on_ready(self.grad[self.o_tab_c:])
 
-    def _adam_colour_beside_sdf_accumulate(self):
-        """after backward(colour_first=True): [side stream] Adam of the colour table   ||   [main] accumulate pass of the sdf table; then Adam of the rest"""
-        lib, st, P = L.lib(), L.stream(), L.ptr
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
-        N = self.n_rays * self.S
-        f = self.lr_factor
-        if not self._step_advanced:
-            L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
-            self._step_advanced = True
-        I64, DBL = ctypes.c_int64 * 1, ctypes.c_double * 1
-        with self._branch() as st2:                              # the side stream waits for the colour table's gradient
-            L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), 1, I64(self.o_tab_c), I64(self.ec.desc.n_params),
-                                                  DBL(self.lr["color_grid"] * f), 0.9, 0.999, 1e-8, P(self.step_dev), L.US_ADAM_STEP_ADVANCED, st2),
-                    "us_adam_step_segments_dev")
-        L.check(lib.us_hashgrid_joint_accum(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                            3 | L.US_GRID_BWD_OVERWRITE | self._det | L.US_GRID_JOINT_ACCUM_A, P(self.ws), self.ws_bytes, st),
-                "us_hashgrid_joint_accum")
-        self._join()
-        self._sdf_accum_pending = False
-        self.opt_step += 1
-        groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f))
-        I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
-        L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), 2, I64(*[g[0] for g in groups]),
-                                              I64(*[g[1] for g in groups]), DBL(*[g[2] for g in groups]), 0.9, 0.999, 1e-8, P(self.step_dev),
-                                              0b001 | L.US_ADAM_STEP_ADVANCED, st), "us_adam_step_segments_dev")
-        self._dec_grad_clean = True
-        self._step_advanced = False
-
     def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False, zero_depth_draws=None):
         """single-process forward + backward (no optimiser step); returns loss[1]"""
         self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, zero_depth_draws)
@@ -630,14 +595,6 @@ class MapStep:
             self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
             loss = self.backward(fuse_adam=True)                 # ... which updates the tables where the joint pass runs
             self.adam_step()
-            return loss
-        if self.group is None:
-            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
-            loss = self.backward(colour_first=True)
-            if getattr(self, "_sdf_accum_pending", False):
-                self._adam_colour_beside_sdf_accumulate()
-            else:
-                self.adam_step()
             return loss
         return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth), self.group)
 
