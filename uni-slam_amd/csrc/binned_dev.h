@@ -61,7 +61,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // 4 296 records per ray and grid instead of 5 580 with runs of equal CELLS in groups of 8 (8 192 without combining).
 // Exact for any point order: only equal vertices in adjacent lanes are merged.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef RUN_GROUP
 #define RUN_GROUP 16
+#endif
 
 struct SlotGeom {
     uint32_t idx[8];          // entry index of the slot's vertex inside the level

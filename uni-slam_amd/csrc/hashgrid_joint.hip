@@ -32,8 +32,12 @@
 #define J_LVL_BINS 512                   // bins of one level (split level: A bins + B bins)
 #define J_STAGE (J_ROW_POINTS * 8)       // stage entries: every slot of every point of one level
 #define J_ACC_DOUBLES 4096               // 32 KiB of f64 accumulators per (bin, grid)
+#ifndef J_ACC_THREADS
 #define J_ACC_THREADS 512
+#endif
+#ifndef J_ACC_UNROLL
 #define J_ACC_UNROLL 4
+#endif
 #define J_TARGET_RECORDS 8192
 #define J_WANT_MAX 8
 
