@@ -123,17 +123,14 @@ __device__ __forceinline__ void slot_weights(const float pos[3], const uint32_t 
     for (int p = 0; p < 8; ++p) w[p] = wxy[p & 3] * a[2][p >> 2];
 }
 
-// head / tail masks (bit p: slot p starts / ends a run in this lane), returned as {head, tail}.  Every DPP move executes with the
-// whole wave active.
+// head / tail masks (bit p: slot p starts / ends a run in this lane), returned as {head, tail}.  To be called with the WHOLE WAVE
+// active (never as one arm of `in ? ... : ...`): the tail mask of a lane is the head mask of the lane above it.
 __device__ __forceinline__ uint2 slot_run_masks(const uint32_t (&key)[8], int lg16) {
-    uint32_t head = 0u, tail = 0u;
+    uint32_t head = 0u;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const uint32_t kp = dpp_u32<DPP_ROW_SHR(1)>(key[p]), kn = dpp_u32<DPP_ROW_SHL1>(key[p]);
-        head |= (kp != key[p]) ? (1u << p) : 0u;
-        tail |= (kn != key[p]) ? (1u << p) : 0u;
-    }
+    for (int p = 0; p < 8; ++p) head |= (dpp_u32<DPP_ROW_SHR(1)>(key[p]) != key[p]) ? (1u << p) : 0u;
     if (lg16 == 0) head = 0xFFu;
+    uint32_t tail = dpp_u32<DPP_ROW_SHL1>(head);                 // a run ends where the next lane starts one
     if (lg16 == RUN_GROUP - 1) tail = 0xFFu;
     return make_uint2(head, tail);
 }
@@ -182,3 +179,29 @@ __device__ __forceinline__ uint2 slot_run_masks(const uint32_t (&key)[8], int lg
 #define SLOT_SCAN_APPLY(NV, take_all, steps)                                                                         \
     SLOT_SCAN_APPLY_STEP(0, 1, NV, take_all, steps) SLOT_SCAN_APPLY_STEP(1, 2, NV, take_all, steps)                  \
     SLOT_SCAN_APPLY_STEP(2, 4, NV, take_all, steps) SLOT_SCAN_APPLY_STEP(3, 8, NV, take_all, steps)
+
+// SLOT_SCAN_APPLY for TWO values per slot, written out: per step and slot v_bfe_u32 + v_cvt_f32_ubyte0 (take bit -> 0.0 / 1.0) and
+// one v_fmac_f32 per value with the row shift on its first operand (val += shifted(val) * take) -- 32 vector instructions per step.
+// The compiler pairs the two values of a slot into a v_pk_fma_f32, which cannot carry DPP, and pays a v_mov_b32_dpp per value and
+// three instructions per take bit for it: 48 per step.  A step no lane of the wave takes in is skipped (s_cbranch on its bit of
+// `steps`); the leading s_nop covers the two wait states between a VALU write of a register and its DPP read, which the compiler does
+// not see through an asm block.  Operands: %0..%15 = val[p][f], %16 %17 = temporaries, %18 = take_all, %19 = steps.
+#define RS_FMAC(i, t, O) "v_fmac_f32_dpp %" #i ", %" #i ", %" #t " row_shr:" #O " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RS_SLOT(i0, i1, t, bit, O) "v_bfe_u32 %" #t ", %18, " #bit ", 1\n\tv_cvt_f32_ubyte0_e32 %" #t ", %" #t "\n\t" RS_FMAC(i0, t, O) RS_FMAC(i1, t, O)
+#define RS_STEP(S, O, b0, b1, b2, b3, b4, b5, b6, b7)                                                                \
+    "s_bitcmp1_b32 %19, " #S "\n\ts_cbranch_scc0 .Lrs" #S "_%=\n\t"                                                  \
+    RS_SLOT(0, 1, 16, b0, O) RS_SLOT(2, 3, 17, b1, O) RS_SLOT(4, 5, 16, b2, O) RS_SLOT(6, 7, 17, b3, O)              \
+    RS_SLOT(8, 9, 16, b4, O) RS_SLOT(10, 11, 17, b5, O) RS_SLOT(12, 13, 16, b6, O) RS_SLOT(14, 15, 17, b7, O)        \
+    ".Lrs" #S "_%=:\n\t"
+__device__ __forceinline__ void slot_scan_apply_pairs(float (&val)[8][2], uint32_t take_all, uint32_t steps) {
+    float t0, t1;
+    steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)steps);                              // wave-uniform by construction: into an SGPR
+    asm("s_nop 1\n\t"
+        RS_STEP(0, 1, 0, 1, 2, 3, 4, 5, 6, 7) RS_STEP(1, 2, 8, 9, 10, 11, 12, 13, 14, 15)
+        RS_STEP(2, 4, 16, 17, 18, 19, 20, 21, 22, 23) RS_STEP(3, 8, 24, 25, 26, 27, 28, 29, 30, 31)
+        : "+v"(val[0][0]), "+v"(val[0][1]), "+v"(val[1][0]), "+v"(val[1][1]), "+v"(val[2][0]), "+v"(val[2][1]), "+v"(val[3][0]),
+          "+v"(val[3][1]), "+v"(val[4][0]), "+v"(val[4][1]), "+v"(val[5][0]), "+v"(val[5][1]), "+v"(val[6][0]), "+v"(val[6][1]),
+          "+v"(val[7][0]), "+v"(val[7][1]), "=&v"(t0), "=&v"(t1)
+        : "v"(take_all), "s"(steps)
+        : "scc");
+}

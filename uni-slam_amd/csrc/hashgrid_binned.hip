@@ -728,7 +728,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fwd_count(LevelTable tab, BinLe
     // ---- the counts of k_bin<COUNT> with every point live (same vertex runs, same bins)
     uint32_t key[8];
     slot_keys(cell, in && q.packable, lane, key);
-    const uint32_t tail = in ? slot_run_masks(key, lg16).y : 0u;     // whole wave active here
+    const uint2 ht = slot_run_masks(key, lg16);                      // outside any condition on `in`: its row shifts read the neighbour lanes
+    const uint32_t tail = in ? ht.y : 0u;
     if (tail != 0u) {
         const uint32_t nbm = nb - 1u;
         uint32_t idx[8];

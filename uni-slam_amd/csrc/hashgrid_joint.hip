@@ -169,7 +169,8 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
     // ---- the records k_jwrite will emit for these points, per bin (every point counts: no gradient exists yet)
     uint32_t key[8];
     slot_keys(cell, in && (q.flags & J_PACKABLE), lane, key);
-    const uint32_t tail = in ? slot_run_masks(key, lg16).y : 0u;     // whole wave active here
+    const uint2 ht = slot_run_masks(key, lg16);                      // outside any condition on `in`: its row shifts read the neighbour lanes
+    const uint32_t tail = in ? ht.y : 0u;
     const uint32_t half = threadIdx.x / J_ROW_POINTS;
     if (tail != 0u) {
         uint32_t e[8];
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             for (int p = 0; p < 8; ++p) { val[p][0] = w[p] * dy[2 * g]; val[p][1] = w[p] * dy[2 * g + 1]; }
         };
         products(0);
-        SLOT_SCAN_APPLY(2, take_all, steps)
+        slot_scan_apply_pairs(val, take_all, steps);
         // ---- requests for the next level: its cursor inputs and gradients.  They are consumed below, BEFORE this level's first
         //      record store: a wait for a load also waits for every store issued before it (one vmcnt counter).
         if (has_next) { setup_load(level + 1, c1, p1, o1, t1); load_dy(level + 1, dn); }
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             copy_out(cnt, gdl[par], 0u);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
-            SLOT_SCAN_APPLY(2, take_all, steps)
+            slot_scan_apply_pairs(val, take_all, steps);
             lds_barrier();
             {                                                    // table B: same bins, same stage positions, the B half of the bin's region
                 uint32_t e[8];
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             copy_out(na, gdl[par], 0u);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
-            SLOT_SCAN_APPLY(2, take_all, steps)
+            slot_scan_apply_pairs(val, take_all, steps);
             lds_barrier();
             const uint32_t sb = atot[par];
             {                                                    // table B: bins behind the A bins, stage index = cursor - records of the A bins
@@ -732,6 +733,169 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// accumulate, persistent form: J_ACCP_GROUPS workgroups (four per CU), each takes the items t = blockIdx.x + k * gridDim.x
+// (item = (bin or extra chunk of a hot bin, grid), the extra chunks -- the largest items -- first).  One workgroup per item spends most
+// of its life outside the record stream: arguments, offsets, first records, clear, two barriers, sweep -- ~12 us for ~50 KB of
+// records.  Here wave 0 decodes ALL items of the workgroup up front (one round trip, descriptors in LDS), and the record stream runs
+// as ONE software pipeline over the items: the first records of item k + 1 are requested before the last batch of item k is added and
+// are in flight across its barriers and its sweep (the barriers order LDS only).  The sweep returns the accumulators it read to zero,
+// so no clear pass and no third barrier per item.
+// ---------------------------------------------------------------------------------------------------------------
+#define J_ACCP_GROUPS 1024
+#define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
+static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
+
+template <int BUF> struct JBufTag { static constexpr int value = BUF; };
+
+__global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
+                                                            const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
+                                                            const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
+                                                            const uint32_t* __restrict__ rec, float* __restrict__ gradA,
+                                                            float* __restrict__ gradB, int overwrite) {
+    __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
+    __shared__ uint32_t items[JI_FIELDS][J_ACCP_MAXI];           // items with records, in the order they are taken
+    __shared__ uint32_t zitems[JI_FIELDS][J_ACCP_MAXI];          // OVERWRITE: bins nothing landed in (their entries get a zero gradient)
+    __shared__ uint32_t n_items, n_zitems;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t k = tid; k < J_ACC_DOUBLES + 4 * 8; k += J_ACC_THREADS) acc[k] = 0.0;
+    if (tid < 64) {                                              // wave 0, lane i: the workgroup's i-th item
+        const uint32_t T = 2u * (e_max + TB), t = blockIdx.x + tid * gridDim.x;
+        const uint32_t side = t & 1u, slot = t >> 1;
+        const uint32_t CH = hdr[1];                              // records per item (k_jscan)
+        bool ok = t < T && tid < J_ACCP_MAXI;
+        uint32_t b = 0, chunk = 0;
+        if (ok) {
+            if (slot < e_max) {
+                ok = slot < hdr[0];
+                if (ok) { const uint32_t pk = extra[slot]; b = pk & 0xFFFFu; chunk = pk >> 16; }
+            } else b = slot - e_max;
+        }
+        const JBin jb = j_bin_of(lv, n_levels, b);
+        if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) ok = false;        // a single-grid bin has no records of the other grid
+        uint32_t hs = 1u, lg = 0u, goff = 0u;
+#pragma unroll
+        for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
+            const JLevel& q = lv.l[l];
+            if (l < n_levels && jb.level == l) { hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA; }
+        }
+        uint32_t cnt = 0, dwo = 0;
+        if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
+        const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
+        const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
+        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? cnt * 3u : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
+                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff};
+        const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
+        if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
+#pragma unroll
+            for (int f = 0; f < JI_FIELDS; ++f) items[f][p] = fields[f]; }
+        if (zero) { const uint32_t p = (uint32_t)__popcll(mz & below);
+#pragma unroll
+            for (int f = 0; f < JI_FIELDS; ++f) zitems[f][p] = fields[f]; }
+        if (tid == 0) { n_items = (uint32_t)__popcll(mh); n_zitems = (uint32_t)__popcll(mz); }
+    }
+    __syncthreads();
+    const uint32_t n = n_items, nz = n_zitems;
+    auto field = [&](int f, uint32_t k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)items[f][k]); };
+    constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL;
+    constexpr int EPT = J_ACC_DOUBLES / 2 / J_ACC_THREADS;       // entries per thread in the sweep
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+    u32x3 w3[2][J_ACC_UNROLL];
+    // ---- the request side of the pipeline: item fk, records from fa on
+    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
+    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
+    auto fetch = [&](auto tag) {                                 // every load unconditional (a load behind a branch of its own costs the waits
+        constexpr int buf = decltype(tag)::value;                // their order: see k_jaccum): past the end of an item, and past the last
+                                                                 // item of the workgroup, it re-reads the last record
+        const uint32_t* base = rec + (size_t)f_base;
+#pragma unroll
+        for (int u = 0; u < J_ACC_UNROLL; ++u) {
+            const uint32_t r = min(fa + u * J_ACC_THREADS + tid, f_c1 - 1u);
+            w3[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(base + (size_t)r * 3u));
+        }
+        fa += STEP;
+        if (fa >= f_c1) { ++fk; f_load(); }
+    };
+    // ---- the adding side: item k, records from a on
+    uint32_t k = 0, a = 0, c1 = 0, nl = 0, misc = 0, hs = 0, goff = 0, REP = 1, rstride = 0;
+    double* my = acc;
+    auto a_load = [&]() {
+        a = field(JI_C0, k); c1 = field(JI_C1, k); nl = field(JI_NL, k); misc = field(JI_MISC, k); hs = field(JI_HS, k); goff = field(JI_GOFF, k);
+        REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;                   // as in k_jaccum
+        my = acc + (tid & (REP - 1u)) * rstride;
+    };
+    auto sweep = [&]() {                                         // sums of the item -> gradient table; the accumulators return to zero
+        const uint32_t bl = misc & 0xFFFFu, lg = (misc >> 16) & 0xFFu, side = (misc >> 24) & 1u;
+        const bool hot = ((misc >> 25) & 1u) != 0u;
+        float* gl = (side ? gradB : gradA) + (size_t)goff * 2u;
+#pragma unroll
+        for (int e4 = 0; e4 < EPT; ++e4) {
+            const uint32_t loc = tid + e4 * J_ACC_THREADS;
+            if (loc >= nl) continue;
+            double s0 = acc[loc], s1 = acc[nl + loc];
+            acc[loc] = 0.0; acc[nl + loc] = 0.0;
+            for (uint32_t r = 1; r < REP; ++r) {                 // fixed order
+                s0 += acc[r * rstride + loc]; s1 += acc[r * rstride + nl + loc];
+                acc[r * rstride + loc] = 0.0; acc[r * rstride + nl + loc] = 0.0;
+            }
+            const uint32_t e = entry_of(loc, bl, lg);
+            if (e >= hs) continue;
+            float* p = gl + (size_t)e * 2u;
+            const float v0 = (float)s0, v1 = (float)s1;
+            if (hot) {
+                if (v0 != 0.0f) atomicAdd(p, v0);
+                if (v1 != 0.0f) atomicAdd(p + 1, v1);
+            } else if (overwrite) {
+                *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
+            } else if (v0 != 0.0f || v1 != 0.0f) {               // this workgroup is the only writer of its entries
+                float2 o = *reinterpret_cast<const float2*>(p);
+                o.x += v0; o.y += v1;
+                *reinterpret_cast<float2*>(p) = o;
+            }
+        }
+    };
+    auto step = [&](auto tag, auto other) -> bool {              // request the next batch, add this one; true when the workgroup is done
+        constexpr int buf = decltype(tag)::value;
+        fetch(other);
+#pragma unroll
+        for (int u = 0; u < J_ACC_UNROLL; ++u) {
+            if (a + u * J_ACC_THREADS + tid < c1) {
+                const uint32_t lc = w3[buf][u].x;
+                if (lc < nl) {
+                    atomicAdd(&my[lc], (double)__uint_as_float(w3[buf][u].y));                    // ds_add_f64
+                    atomicAdd(&my[nl + lc], (double)__uint_as_float(w3[buf][u].z));
+                }
+            }
+        }
+        a += STEP;
+        if (a >= c1) {                                           // the item's last batch (workgroup-uniform)
+            lds_barrier();                                       // LDS only: the next item's records stay in flight
+            sweep();
+            if (++k == n) return true;
+            a_load();
+            lds_barrier();
+        }
+        return false;
+    };
+    if (n > 0) {
+        f_load(); a_load();
+        fetch(JBufTag<0>{});
+        for (;;) {
+            if (step(JBufTag<0>{}, JBufTag<1>{})) break;
+            if (step(JBufTag<1>{}, JBufTag<0>{})) break;
+        }
+    }
+    for (uint32_t z = 0; z < nz; ++z) {                          // empty bins: zero gradient
+        const uint32_t znl = zitems[JI_NL][z], zm = zitems[JI_MISC][z], zhs = zitems[JI_HS][z];
+        float* gl = (((zm >> 24) & 1u) ? gradB : gradA) + (size_t)zitems[JI_GOFF][z] * 2u;
+        for (uint32_t loc = tid; loc < znl; loc += J_ACC_THREADS) {
+            const uint32_t e = entry_of(loc, zm & 0xFFFFu, (zm >> 16) & 0xFFu);
+            if (e < zhs) *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
+        }
+    }
+}
+
 // fused Adam, the entries of hot bins: their gradient was added by several workgroups of k_jaccum; one workgroup per hot bin and grid
 __global__ __launch_bounds__(J_ACC_THREADS) void k_jadam_hot(JLevels lv, uint32_t n_levels, const uint32_t* __restrict__ extra,
                                                              const uint32_t* __restrict__ hdr, const float* __restrict__ gradA,
@@ -889,8 +1053,13 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         US_REQUIRE(overwrite, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: needs US_GRID_BWD_OVERWRITE (the update uses the complete gradient)");
         ad = *adam; ad.enabled = 1;
     }
-    hipLaunchKernelGGL(k_jaccum, dim3(2u * (ACC_EXTRA_MAX + (uint32_t)TB)), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
-                       w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad);
+    const uint32_t n_acc_items = 2u * (ACC_EXTRA_MAX + (uint32_t)TB);
+    if (!adam)
+        hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
+                           (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite);
+    else
+        hipLaunchKernelGGL(k_jaccum, dim3(n_acc_items), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
+                           w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad);
     if (adam) hipLaunchKernelGGL(k_jadam_hot, dim3(ACC_EXTRA_MAX, 2), dim3(J_ACC_THREADS), 0, s, lv, L, w.extra, w.hdr, gradA, gradB, ad);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
