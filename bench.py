@@ -418,9 +418,13 @@ def run_rank(args):
                     fn()
                 torch.cuda.synchronize()
                 return 1e3 * (time.perf_counter() - t1) / k
-            fwd_ms = timed(lambda: step.forward(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False, backward_follows=False))
+            render = lambda: step.forward(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False, backward_follows=False)
+            fwd_ms = timed(render)
+            step.fused_render = True                             # ... and as ONE launch (us_encode_decode_fwd; opt-in: measured slower)
+            fwd1_ms = timed(render)
+            step.fused_render = False
             fb_ms = timed(lambda: step.forward_backward(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False))
-            rec["extra"] = {"forward_only_ms": fwd_ms, "forward_only_rays_per_s": R / (fwd_ms / 1e3),
+            rec["extra"] = {"forward_only_ms": fwd_ms, "forward_only_rays_per_s": R / (fwd_ms / 1e3), "forward_only_one_launch_ms": fwd1_ms,
                             "iteration_without_adam_ms": fb_ms}
 
             def side_run(st):

@@ -237,6 +237,16 @@ int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const
                const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, int flags,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Render-only encode + decode in one launch: outA = decoder A(grid A(x)), outB = decoder B(grid B(x)) -- what Decoders.forward
+ * (src/networks/decoders.py:158-188) computes for Renderer.render_img / Mesher.eval_points, calls that need no gradient.  The features
+ * stay in LDS.  Needs two 16-level F = 2 grids of equal base resolution and per-level scale, and two bf16 decoders (US_PREC_BF16 or
+ * US_PREC_BF16_PLAIN, the same for both) of equal width and depth: us_encode_decode_supported() says whether a pair qualifies; results
+ * are bit-identical to us_hashgrid_fwd + us_mlp_fwd.  flags: US_GRID_CLAMP01. */
+int us_encode_decode_supported(const us_grid_desc* a, const us_grid_desc* b, const us_mlp_desc* ma, const us_mlp_desc* mb);
+int us_encode_decode_fwd(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
+                         const us_mlp_desc* ma, const us_mlp_desc* mb, const float* mlp_paramsA, const float* mlp_paramsB,
+                         const float* x, int64_t n, float* outA, int64_t strideA, float* outB, int64_t strideB, int flags, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray sampling / points  (replaces src/utils/Renderer.py:81-101,132-137 and src/common.py:152-166 gather+rotate)
  * ---------------------------------------------------------------------------------------------- */

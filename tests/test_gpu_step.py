@@ -834,3 +834,28 @@ def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
             close = torch.isclose(a[k], b[k], rtol=1e-5, atol=1e-7)
             assert float((~close).float().mean()) < 1e-4, (other, k, float((~close).float().mean()))
     assert torch.equal(res["fused"][1], res["joint"][1])                        # same gradients, same arithmetic: bit-identical tables
+
+
+def test_mapstep_render_only_in_one_launch_equals_four_launches():
+    """MapStep.fused_render (opt-in): a render-only call through us_encode_decode_fwd -- both grids and both decoders in one kernel, the
+    features kept in LDS -- renders bit for bit what the encoders and decoders launched one by one render."""
+    import unislam_amd as us
+    torch.manual_seed(5)
+    cfg = _cfg(False, 48, 16)
+    cfg["model"] = {"mlp_precision": "bf16"}
+    dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+    R = 777
+    step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=R)
+    ro, rd, gd, gc = _rays(R, seed=8, outside=True)
+    t_rand = torch.rand(R, 64, device=DEV)
+    res = {}
+    for fused in (False, True):
+        step.fused_render = fused
+        stats = step.forward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False, backward_follows=False)
+        torch.cuda.synchronize()
+        res[fused] = [t.clone() for t in step.rendered()] + [stats.clone(), step.raw[:R].clone()]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

@@ -629,3 +629,6 @@ extern "C" int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t
     US_CHECK_LAUNCH("us_mlp_reduce");
     return US_OK;
 }
+
+#include <string.h>
+#include "encode_decode.inc"

@@ -57,6 +57,10 @@ class MapStep:
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
         self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
+        # opt-in: render-only calls (forward(backward_follows=False)) as ONE launch (us_encode_decode_fwd: both grids, both decoders, the features
+        # kept in LDS) where the model qualifies.  Bit-identical, but measured slower than the four launches (0.20 against 0.18 ms at 4096 x 64:
+        # csrc/encode_decode.inc), so off.
+        self.fused_render = False
         self._dec_grad_clean = False
         self._step_advanced = False
         # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
@@ -360,6 +364,11 @@ class MapStep:
                 self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
             self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
             self._join()
+            return self._finish_forward(o, d, gd, gc, R)
+        if not backward_follows and self.fused_render and lib.us_encode_decode_supported(ds, dc, ms, mc):
+            # a render-only call: both grids and both decoders in one launch, the features never leave the CU (csrc/encode_decode.inc)
+            self._timed("encode_decode", lambda: lib.us_encode_decode_fwd(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), ms, mc, off(fl, self.o_dec_s),
+                                                                          off(fl, self.o_dec_c), P(self.pts), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
             return self._finish_forward(o, d, gd, gc, R)
         with self._branch() as st2:
             if counted:
