@@ -242,7 +242,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BinLevels lv, uint32_t n_le
             for (int p = 0; p < 8; ++p)
 #pragma unroll
                 for (int f = 0; f < F; ++f) val[p][f] = w[p] * dy[f];                  // dy == 0 on dead lanes
-            SLOT_SCAN(F)
+            if constexpr (F == 2) {                              // the scan written out (binned_dev.h): 32 instead of 48 instructions per step
+                uint32_t take_all, steps;
+                SLOT_SCAN_PRE(head, take_all, steps)
+                slot_scan_apply_pairs(val, take_all, steps);
+            } else {
+                SLOT_SCAN(F)
+            }
         }
         }   // wave has live samples
         if (level + 1 < n_levels) load_dy(level + 1, dn);
