@@ -61,6 +61,10 @@ class MapStep:
         # kept in LDS) where the model qualifies.  Bit-identical, but measured slower than the four launches (0.20 against 0.18 ms at 4096 x 64:
         # csrc/encode_decode.inc), so off.
         self.fused_render = False
+        # The two decoders on two streams (joint path)?  Under graph replay a dependency ACROSS queues costs 10-14 us where kernels that
+        # follow each other on one queue start back to back, and the decoder kernels fill the chip on their own: 0.614 -> 0.59 ms at
+        # 4096 x 64 with the decoders one after the other on the main stream (the scans and the small reductions keep their side streams).
+        self.decoders_side_by_side = False
         self._dec_grad_clean = False
         self._step_advanced = False
         # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
@@ -360,10 +364,14 @@ class MapStep:
                     if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
                         L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
                         self._step_advanced = True
-            with self._branch() as st2:
-                self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
+            if self.decoders_side_by_side:
+                with self._branch() as st2:
+                    self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
+            else:
+                self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
             self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
-            self._join()
+            if self.decoders_side_by_side:
+                self._join()
             return self._finish_forward(o, d, gd, gc, R)
         if not backward_follows and self.fused_render and lib.us_encode_decode_supported(ds, dc, ms, mc):
             # a render-only call: both grids and both decoders in one launch, the features never leave the CU (csrc/encode_decode.inc)
@@ -420,17 +428,21 @@ class MapStep:
         beta = off(fl, self.o_beta)
         # The binned table backward writes every table entry (US_GRID_BWD_OVERWRITE); the decoder segment, which the MLP
         # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
-        if self.bwd_mode not in (-1, 3):
-            self.grad.zero_()
-        elif not self._dec_grad_clean:
-            self.grad[:self.o_tab_s].zero_()
-        self._dec_grad_clean = False
-        gbeta = off(self.grad, self.o_beta) if self.has_beta else None
-        # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
         binned = self.ws is not None
         # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
         # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
         defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing and self.group is None)
+        clear_later = False
+        if self.bwd_mode not in (-1, 3):
+            self.grad.zero_()
+        elif not self._dec_grad_clean:
+            if defer:
+                clear_later = True                               # ... and so is the clearing of the segment they add to (a 6 us fill)
+            else:
+                self.grad[:self.o_tab_s].zero_()
+        self._dec_grad_clean = False
+        gbeta = off(self.grad, self.o_beta) if self.has_beta else None
+        # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
         L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode | (L.US_LOSS_DEFER_BETA if (defer and gbeta is not None) else 0),
                                        P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
                                        P(self.unc), self.truncation, self.w5, P(self.stats), P(self.d_raw), gbeta, P(self.beta_part),
@@ -465,13 +477,19 @@ class MapStep:
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
-            with self._branch() as st2:
-                mlp_s(st2)
+            if self.decoders_side_by_side:
+                with self._branch() as st2:
+                    mlp_s(st2)
+            else:
+                mlp_s(st)
             self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
-            self._join()                                         # the main stream waits for the sdf decoder's backward pass, nothing later
+            if self.decoders_side_by_side:
+                self._join()                                     # the main stream waits for the sdf decoder's backward pass, nothing later
             if defer:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
+                    if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
+                        self.grad[:self.o_tab_s].zero_()
                     L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
                     L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
                     if gbeta is not None:
