@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
+    ap.add_argument("--no-decoder-pair", action="store_true", help="the two decoders as two launches each way instead of one (MapStep.decoder_pair)")
     ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
                     help="both grids in one encoder launch and one binned table-gradient pass (csrc/hashgrid_joint.hip); auto = MapStep's default")
     ap.add_argument("--packed-records", action="store_true", help="8-byte intermediate records in the table gradient (US_GRID_BWD_PACKED)")
@@ -288,6 +289,7 @@ def run_rank(args):
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
                         grad_comm=comm, sharded_adam=sharded, packed_records=args.packed_records,
                         joint=None if args.joint == "auto" else args.joint == "1")
+        st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)

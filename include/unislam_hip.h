@@ -247,6 +247,18 @@ int us_encode_decode_fwd(const us_grid_desc* a, const us_grid_desc* b, const flo
                          const us_mlp_desc* ma, const us_mlp_desc* mb, const float* mlp_paramsA, const float* mlp_paramsB,
                          const float* x, int64_t n, float* outA, int64_t strideA, float* outB, int64_t strideB, int flags, void* stream);
 
+/* Two decoders of equal shape (32 inputs, the same width, depth and bf16 precision: us_mlp_pair_supported) in ONE launch each way --
+ * the sdf and the colour decoder of Decoders.forward.  Arguments and results as two us_mlp_fwd / us_mlp_bwd calls (bit-identical);
+ * the backward pass needs both parameter gradients and one workspace (us_mlp_bwd_workspace_bytes) per decoder. */
+int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b);
+int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                    const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags, void* stream);
+int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                    const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                    const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                    float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                    void* workspace_b, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray sampling / points  (replaces src/utils/Renderer.py:81-101,132-137 and src/common.py:152-166 gather+rotate)
  * ---------------------------------------------------------------------------------------------- */

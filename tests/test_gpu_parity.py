@@ -1084,3 +1084,46 @@ def test_binned_backward_packed_records(us, log2T):
     ws4 = torch.empty(nb4, dtype=torch.uint8, device=DEV); g4 = torch.zeros(enc4.params.numel(), device=DEV)
     rc = lib.us_hashgrid_bwd_binned(ctypes.byref(enc4.desc), P(x4), P(dy4), 64, P(g4), L.US_GRID_BWD_PACKED, P(ws4), nb4, st)
     assert rc == L.US_ERR_CONFIG
+
+
+@pytest.mark.parametrize("width,n_hidden,bias,prec,n", [(32, 2, True, "bf16", 70001), (32, 2, False, "bf16_plain", 4096), (16, 1, True, "bf16", 100),
+                                                        (64, 2, True, "bf16", 5000), (64, 1, False, "bf16_plain", 1)])
+def test_mlp_pair_equals_two_launches(us, width, n_hidden, bias, prec, n):
+    """us_mlp_fwd_pair / us_mlp_bwd_pair (two decoders of one shape in one launch, blockIdx.y = decoder) against us_mlp_fwd / us_mlp_bwd
+    per decoder: outputs, input gradients and parameter gradients bit-identical, with the level-major feature planes and the raw[N][4]
+    output layout of the render path."""
+    import ctypes
+    from unislam_amd import _lib as L
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    g = torch.Generator(device=DEV).manual_seed(width + n)
+    ma = us.make_mlp_desc(32, width, n_hidden, 1, "none", bias, prec)
+    mb = us.make_mlp_desc(32, width, n_hidden, 3, "sigmoid", bias, prec)
+    A, B = ctypes.byref(ma), ctypes.byref(mb)
+    assert lib.us_mlp_pair_supported(A, B) == 1
+    pa = (torch.rand(us.network.mlp_n_params(ma), device=DEV, generator=g) * 2 - 1) * 0.4
+    pb = (torch.rand(us.network.mlp_n_params(mb), device=DEV, generator=g) * 2 - 1) * 0.4
+    fa, fb = torch.randn((16, n, 2), device=DEV, generator=g), torch.randn((16, n, 2), device=DEV, generator=g)
+    d_raw = torch.randn((n, 4), device=DEV, generator=g)
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+    wsb = max(int(lib.us_mlp_bwd_workspace_bytes(A)), int(lib.us_mlp_bwd_workspace_bytes(B)))
+    res = {}
+    for pair in (False, True):
+        raw = torch.full((n, 4), -3.0, device=DEV)
+        dfa, dfb = torch.zeros_like(fa), torch.zeros_like(fb)
+        ga, gb = torch.zeros_like(pa), torch.zeros_like(pb)
+        wa, wb = torch.empty(wsb, dtype=torch.uint8, device=DEV), torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        if pair:
+            L.check(lib.us_mlp_fwd_pair(A, B, P(pa), P(pb), P(fa), P(fb), n, off(raw, 3), 4, P(raw), 4, 1, st), "fwd pair")
+            L.check(lib.us_mlp_bwd_pair(A, B, P(pa), P(pb), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, n, P(dfa), P(dfb),
+                                        P(ga), P(gb), 1, P(wa), P(wb), wsb, st), "bwd pair")
+        else:
+            L.check(lib.us_mlp_fwd(A, P(pa), P(fa), n, off(raw, 3), 4, 1, st), "fwd a")
+            L.check(lib.us_mlp_fwd(B, P(pb), P(fb), n, P(raw), 4, 1, st), "fwd b")
+            L.check(lib.us_mlp_bwd(A, P(pa), P(fa), off(raw, 3), 4, off(d_raw, 3), 4, n, P(dfa), P(ga), 1, P(wa), wsb, st), "bwd a")
+            L.check(lib.us_mlp_bwd(B, P(pb), P(fb), P(raw), 4, P(d_raw), 4, n, P(dfb), P(gb), 1, P(wb), wsb, st), "bwd b")
+        res[pair] = (raw, dfa, dfb, ga, gb)
+    for x, y in zip(res[True], res[False]):
+        assert torch.equal(x, y)
+    assert lib.us_mlp_pair_supported(A, ctypes.byref(us.make_mlp_desc(32, width, 3 - n_hidden, 3, "sigmoid", bias, prec))) == 0
+    assert lib.us_mlp_pair_supported(ctypes.byref(us.make_mlp_desc(32, width, n_hidden, 1, "none", bias, "fp32")),
+                                     ctypes.byref(us.make_mlp_desc(32, width, n_hidden, 3, "sigmoid", bias, "fp32"))) == 0

@@ -630,5 +630,90 @@ extern "C" int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t
     return US_OK;
 }
 
+// ---- two decoders of equal shape in one launch each way (k_mlp_fwd_pair / k_mlp_bwd_pair in mlp_bf16.inc)
+static bool mlp_pair_ok(const us_mlp_desc* a, const us_mlp_desc* b) {
+    return a && b && a->n_in == 32 && b->n_in == 32 && a->width == b->width && a->n_hidden == b->n_hidden && a->precision == b->precision &&
+           (a->precision == US_PREC_BF16 || a->precision == US_PREC_BF16_PLAIN) && (a->width == 16 || a->width == 32 || a->width == 64) &&
+           (a->n_hidden == 1 || a->n_hidden == 2) && a->n_out >= 1 && a->n_out <= 16 && b->n_out >= 1 && b->n_out <= 16 &&
+           a->out_act <= US_ACT_SIGMOID && b->out_act <= US_ACT_SIGMOID;
+}
+extern "C" int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b) { return mlp_pair_ok(a, b) ? 1 : 0; }
+
+#define MLP_PAIR_DISPATCH(KERNEL, ...)                                                                             \
+    do {                                                                                                           \
+        const int key = (int)da->width * 10 + (int)da->n_hidden;                                                   \
+        if (da->precision == US_PREC_BF16) {                                                                       \
+            switch (key) {                                                                                         \
+                case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+                case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+                case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+                case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+                case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+                default:  hipLaunchKernelGGL((KERNEL<32, 64, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
+            }                                                                                                      \
+        } else {                                                                                                   \
+            switch (key) {                                                                                         \
+                case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+                case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+                case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+                case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+                case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+                default:  hipLaunchKernelGGL((KERNEL<32, 64, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+
+extern "C" int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                               const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags,
+                               void* stream) {
+    US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_fwd_pair: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
+    US_REQUIRE(out_stride_a >= (int64_t)da->n_out && out_stride_b >= (int64_t)db->n_out, US_ERR_SHAPE, "us_mlp_fwd_pair: out_stride < n_out");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params_a && params_b && in_a && in_b && out_a && out_b, US_ERR_NULL, "us_mlp_fwd_pair: NULL pointer");
+    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = us_cdiv(n, 64 * MLP_WAVES); if (nb > 2048) nb = 2048;           // as us_mlp_fwd (bf16)
+    dim3 grid((unsigned)nb, 2), block(MLP_THREADS);
+    MlpFwdJob a = {params_a, (int)da->has_bias, (int)da->n_out, (int)da->out_act, in_a, out_a, (long long)out_stride_a};
+    MlpFwdJob b = {params_b, (int)db->has_bias, (int)db->n_out, (int)db->out_act, in_b, out_b, (long long)out_stride_b};
+    MLP_PAIR_DISPATCH(k_mlp_fwd_pair, a, b, n, lm);
+    US_CHECK_LAUNCH("us_mlp_fwd_pair");
+    return US_OK;
+}
+
+extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                               const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                               const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                               float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                               void* workspace_b, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_bwd_pair: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
+    US_REQUIRE(out_stride_a >= (int64_t)da->n_out && dout_stride_a >= (int64_t)da->n_out && out_stride_b >= (int64_t)db->n_out &&
+               dout_stride_b >= (int64_t)db->n_out, US_ERR_SHAPE, "us_mlp_bwd_pair: stride < n_out");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(params_a && params_b && in_a && in_b && out_a && out_b && dL_dout_a && dL_dout_b, US_ERR_NULL, "us_mlp_bwd_pair: NULL pointer");
+    US_REQUIRE(grad_params_a && grad_params_b && workspace_a && workspace_b && workspace_a != workspace_b, US_ERR_NULL,
+               "us_mlp_bwd_pair: needs both parameter gradients and one workspace per decoder");
+    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
+               "us_mlp_bwd_pair: workspace %zu B too small", workspace_bytes);
+    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int waves = MLP_BF_BWD_WAVES(da->width);
+    int64_t nb = us_cdiv(n, 16 * MLP_BF_BWD_NQ(da->width, da->n_hidden) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;     // as us_mlp_bwd
+    dim3 grid((unsigned)nb, 2), block(waves * 64);
+    MlpBwdJob a = {params_a, (int)da->has_bias, (int)da->n_out, (int)da->out_act, in_a, out_a, (long long)out_stride_a, dL_dout_a,
+                   (long long)dout_stride_a, dL_din_a, grad_params_a, (float*)workspace_a};
+    MlpBwdJob b = {params_b, (int)db->has_bias, (int)db->n_out, (int)db->out_act, in_b, out_b, (long long)out_stride_b, dL_dout_b,
+                   (long long)dout_stride_b, dL_din_b, grad_params_b, (float*)workspace_b};
+    MLP_PAIR_DISPATCH(k_mlp_bwd_pair, a, b, n, lm);
+    US_CHECK_LAUNCH("us_mlp_bwd_pair");
+    if (!(flags & US_MLP_DEFER_REDUCE)) {
+        const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
+        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npa, 64)), dim3(1024), 0, s, (const float*)workspace_a, (int)nb, npa, grad_params_a);
+        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npb, 64)), dim3(1024), 0, s, (const float*)workspace_b, (int)nb, npb, grad_params_b);
+        US_CHECK_LAUNCH("us_mlp_bwd_pair(reduce)");
+    }
+    return US_OK;
+}
+
 #include <string.h>
 #include "encode_decode.inc"

@@ -65,6 +65,7 @@ class MapStep:
         # follow each other on one queue start back to back, and the decoder kernels fill the chip on their own: 0.614 -> 0.59 ms at
         # 4096 x 64 with the decoders one after the other on the main stream (the scans and the small reductions keep their side streams).
         self.decoders_side_by_side = False
+        self.decoder_pair = True        # ... and, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
         self._dec_grad_clean = False
         self._step_advanced = False
         # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
@@ -218,10 +219,16 @@ class MapStep:
         self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
                                 int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
-        self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev) if self.overlap else self.mlp_ws
+        self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)      # (one per decoder: they may run in one launch)
         if self.ws_s is None:
             self.ws_s = self.ws
         N = N_all
+
+    def _decoder_pair(self):
+        """joint path: run the two decoders as ONE launch each way (us_mlp_fwd_pair / us_mlp_bwd_pair)?  Yes when they have one shape and a
+        bf16 precision and are not asked to run side by side on two streams."""
+        return bool(self.decoder_pair and not self.decoders_side_by_side and
+                    L.lib().us_mlp_pair_supported(ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)))
 
     class _Branch:
         """`with step._branch() as st2:` -- the launches inside go to the side stream (st2 = its handle), which first waits
@@ -364,6 +371,10 @@ class MapStep:
                     if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
                         L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
                         self._step_advanced = True
+            if self._decoder_pair():                             # both decoders in one launch
+                self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
+                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+                return self._finish_forward(o, d, gd, gc, R)
             if self.decoders_side_by_side:
                 with self._branch() as st2:
                     self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
@@ -477,15 +488,22 @@ class MapStep:
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
-            if self.decoders_side_by_side:
-                with self._branch() as st2:
-                    mlp_s(st2)
+            if self._decoder_pair():                             # both decoders' backward passes in one launch
+                self._timed("mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c),
+                                                                        off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4, P(self.d_raw), 4, N,
+                                                                        P(self.d_feat_s), P(self.d_feat_c), off(self.grad, self.o_dec_s),
+                                                                        off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws_s), P(self.mlp_ws),
+                                                                        self.mlp_ws_bytes, st))
             else:
-                mlp_s(st)
-            self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
-            if self.decoders_side_by_side:
-                self._join()                                     # the main stream waits for the sdf decoder's backward pass, nothing later
+                if self.decoders_side_by_side:
+                    with self._branch() as st2:
+                        mlp_s(st2)
+                else:
+                    mlp_s(st)
+                self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
+                                                                    N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
+                if self.decoders_side_by_side:
+                    self._join()                                 # the main stream waits for the sdf decoder's backward pass, nothing later
             if defer:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
                     if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
