@@ -249,7 +249,8 @@ int us_encode_decode_fwd(const us_grid_desc* a, const us_grid_desc* b, const flo
 
 /* Two decoders of equal shape (32 inputs, the same width, depth and bf16 precision: us_mlp_pair_supported) in ONE launch each way --
  * the sdf and the colour decoder of Decoders.forward.  Arguments and results as two us_mlp_fwd / us_mlp_bwd calls (bit-identical);
- * the backward pass needs both parameter gradients and one workspace (us_mlp_bwd_workspace_bytes) per decoder. */
+ * the backward pass forms the parameter gradients of both decoders (then with one workspace, us_mlp_bwd_workspace_bytes, per decoder) or of
+ * neither (grad_params and workspaces NULL: the input gradients only, as tracking needs them). */
 int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b);
 int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
                     const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags, void* stream);

@@ -1124,6 +1124,11 @@ def test_mlp_pair_equals_two_launches(us, width, n_hidden, bias, prec, n):
         res[pair] = (raw, dfa, dfb, ga, gb)
     for x, y in zip(res[True], res[False]):
         assert torch.equal(x, y)
+    # input gradients only (tracking): no parameter gradients, no workspaces
+    dfa, dfb = torch.zeros_like(fa), torch.zeros_like(fb)
+    L.check(lib.us_mlp_bwd_pair(A, B, P(pa), P(pb), P(fa), P(fb), off(res[True][0], 3), 4, P(res[True][0]), 4, off(d_raw, 3), 4, P(d_raw), 4, n,
+                                P(dfa), P(dfb), None, None, 1, None, None, 0, st), "bwd pair, inputs only")
+    assert torch.equal(dfa, res[False][1]) and torch.equal(dfb, res[False][2])
     assert lib.us_mlp_pair_supported(A, ctypes.byref(us.make_mlp_desc(32, width, 3 - n_hidden, 3, "sigmoid", bias, prec))) == 0
     assert lib.us_mlp_pair_supported(ctypes.byref(us.make_mlp_desc(32, width, n_hidden, 1, "none", bias, "fp32")),
                                      ctypes.byref(us.make_mlp_desc(32, width, n_hidden, 3, "sigmoid", bias, "fp32"))) == 0

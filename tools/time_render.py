@@ -38,7 +38,7 @@ def timed(fn, k=50):
     return 1e3 * (time.perf_counter() - t) / k
 
 out = {}
-for fused in (True, False):
-    step.fused_render = fused
-    out["fused" if fused else "four launches"] = (round(timed(render), 4), round(timed(CapturedIteration(render, warmup=2).replay), 4))
-print("render-only ms (eager, graph replay):", out, " rays/s fused graph: %.1f M" % (R / out["fused"][1] / 1e3))
+for name, fused, joint in (("one launch", True, False), ("two launches on one stream", False, True), ("four launches on two streams", False, False)):
+    step.fused_render, step.render_joint = fused, joint
+    out[name] = (round(timed(render), 4), round(timed(CapturedIteration(render, warmup=2).replay), 4))
+print("render-only ms (eager, graph replay):", out)

@@ -691,10 +691,16 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
                dout_stride_b >= (int64_t)db->n_out, US_ERR_SHAPE, "us_mlp_bwd_pair: stride < n_out");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(params_a && params_b && in_a && in_b && out_a && out_b && dL_dout_a && dL_dout_b, US_ERR_NULL, "us_mlp_bwd_pair: NULL pointer");
-    US_REQUIRE(grad_params_a && grad_params_b && workspace_a && workspace_b && workspace_a != workspace_b, US_ERR_NULL,
-               "us_mlp_bwd_pair: needs both parameter gradients and one workspace per decoder");
-    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
-               "us_mlp_bwd_pair: workspace %zu B too small", workspace_bytes);
+    const bool wgrad = grad_params_a || grad_params_b;           // tracking asks for the input gradients only
+    if (wgrad) {
+        US_REQUIRE(grad_params_a && grad_params_b && workspace_a && workspace_b && workspace_a != workspace_b, US_ERR_NULL,
+                   "us_mlp_bwd_pair: parameter gradients are formed for both decoders or for neither, with one workspace per decoder");
+        US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
+                   "us_mlp_bwd_pair: workspace %zu B too small", workspace_bytes);
+    } else {
+        US_REQUIRE(dL_din_a && dL_din_b, US_ERR_NULL, "us_mlp_bwd_pair: nothing to compute (no parameter gradients, no input gradients)");
+        workspace_a = workspace_b = nullptr;
+    }
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int waves = MLP_BF_BWD_WAVES(da->width);
@@ -706,7 +712,7 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
                    (long long)dout_stride_b, dL_din_b, grad_params_b, (float*)workspace_b};
     MLP_PAIR_DISPATCH(k_mlp_bwd_pair, a, b, n, lm);
     US_CHECK_LAUNCH("us_mlp_bwd_pair");
-    if (!(flags & US_MLP_DEFER_REDUCE)) {
+    if (wgrad && !(flags & US_MLP_DEFER_REDUCE)) {
         const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
         hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npa, 64)), dim3(1024), 0, s, (const float*)workspace_a, (int)nb, npa, grad_params_a);
         hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npb, 64)), dim3(1024), 0, s, (const float*)workspace_b, (int)nb, npb, grad_params_b);

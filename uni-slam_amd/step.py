@@ -65,6 +65,7 @@ class MapStep:
         # follow each other on one queue start back to back, and the decoder kernels fill the chip on their own: 0.614 -> 0.59 ms at
         # 4096 x 64 with the decoders one after the other on the main stream (the scans and the small reductions keep their side streams).
         self.decoders_side_by_side = False
+        self.render_joint = True
         self.decoder_pair = True        # ... and, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
         self._dec_grad_clean = False
         self._step_advanced = False
@@ -388,6 +389,13 @@ class MapStep:
             # a render-only call: both grids and both decoders in one launch, the features never leave the CU (csrc/encode_decode.inc)
             self._timed("encode_decode", lambda: lib.us_encode_decode_fwd(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), ms, mc, off(fl, self.o_dec_s),
                                                                           off(fl, self.o_dec_c), P(self.pts), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+            return self._finish_forward(o, d, gd, gc, R)
+        if not backward_follows and self.render_joint and self.joint and self._decoder_pair():
+            # a render-only call on ONE stream: both encoders in one launch (no binning counts), both decoders in one launch
+            self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
+                                                                                P(self.feat_s), P(self.feat_c), 3, None, 0, st))
+            self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
+                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1, st))
             return self._finish_forward(o, d, gd, gc, R)
         with self._branch() as st2:
             if counted:
@@ -785,8 +793,13 @@ class TrackStep:
         else:
             L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
             L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
-        L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
-        L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
+        pair = bool(lib.us_mlp_pair_supported(ms, mc))             # both decoders in one launch each way
+        if pair:
+            L.check(lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st),
+                    "us_mlp_fwd_pair")
+        else:
+            L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
+            L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), P(self._beta), R, S, P(self.term), P(self.unc), P(self.depth),
                                      P(self.rgb), P(self.dunc), None, st), "us_composite_fwd")
         med = None
@@ -808,10 +821,15 @@ class TrackStep:
                                  P(self.g_rgb), P(self.loss), st), "us_loss_grad")
         L.check(lib.us_composite_bwd(P(self.raw), P(self.z), P(self._beta), R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
                                      P(self.g_sdf), P(self.d_raw), None, None, st), "us_composite_bwd")
-        L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1,
-                               None, 0, st), "us_mlp_bwd")
-        L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
-                               None, 0, st), "us_mlp_bwd")
+        if pair:
+            L.check(lib.us_mlp_bwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
+                                        off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st),
+                    "us_mlp_bwd_pair")
+        else:
+            L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1,
+                                   None, 0, st), "us_mlp_bwd")
+            L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
+                                   None, 0, st), "us_mlp_bwd")
         L.check(lib.us_hashgrid_bwd_input_gather(ds, P(ts), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
                 "us_hashgrid_bwd_input_gather")
         L.check(lib.us_hashgrid_bwd_input_gather(dc, P(tc), P(self.pts), P(self.d_feat_c), N, P(self.d_pts), 3 | L.US_GRID_ACCUMULATE, st),
