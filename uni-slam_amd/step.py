@@ -47,11 +47,12 @@ class MapStep:
                  grids qualifies; no with a process group, where the colour table's gradient is finished FIRST so that its all-reduce
                  hides behind the sdf branch (a joint pass would finish both tables at the same moment, with nothing left to hide behind).
                  Measured at 4096 x 64 (room0 tables): the iteration takes the same 0.66 ms either way -- the two one-grid chains overlap on
-                 two streams -- but the table gradient itself is 276 us for both grids against 157 + 147; render-only calls
-                 (backward_follows=False) always use the one-grid encoders on two streams (0.19 against 0.21 ms).
-        overlap: run the sdf branch (encode, decode and their backward) on a second HIP stream beside the colour branch;
-                 default: yes for a single process; no with a process group, where the branches run one after the other so that
-                 the all-reduce of the colour-table gradient hides behind the sdf branch.
+                 two streams -- but the table gradient itself is 262 us for both grids against 157 + 147; render-only calls
+                 (backward_follows=False) run the joint encoder without counts and both decoders in one launch (render_joint).
+        overlap: use side streams -- one-grid kernels: the sdf branch (encode, decode and their backward) beside the colour branch; joint
+                 kernels: the binning's scans and the small reductions beside the main chain (the decoders stay on the main stream:
+                 decoders_side_by_side); default: yes for a single process; no with a process group, where the branches run one after
+                 the other so that the all-reduce of the colour-table gradient hides behind the sdf branch.
         """
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
