@@ -825,7 +825,9 @@ def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
             losses.append(float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)))
             if k == 1:
                 step.reset_optimizer(5.0)
-        res[name] = (losses, step.flat.clone(), step.m.clone(), step.v.clone(), float(step.step_dev[0]))
+            if k == 2:
+                before_hot = step.flat.clone()                   # (the hot batch's bins are summed with float atomics: order-dependent rounding)
+        res[name] = (losses, step.flat.clone(), step.m.clone(), step.v.clone(), float(step.step_dev[0]), before_hot)
     for other in ("joint", "single"):
         a, b = res["fused"], res[other]
         np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
@@ -833,7 +835,7 @@ def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
         for k in (1, 2, 3):
             close = torch.isclose(a[k], b[k], rtol=1e-5, atol=1e-7)
             assert float((~close).float().mean()) < 1e-4, (other, k, float((~close).float().mean()))
-    assert torch.equal(res["fused"][1], res["joint"][1])                        # same gradients, same arithmetic: bit-identical tables
+    assert torch.equal(res["fused"][5], res["joint"][5])                        # same gradients, same arithmetic: bit-identical tables
 
 
 def test_mapstep_render_only_in_one_launch_equals_four_launches():
