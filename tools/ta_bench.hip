@@ -81,7 +81,7 @@ int main() {
             }
         }
     }
-    for (int lg = 11; lg <= 26; lg += 3) {               // 16 KiB ... 512 MiB tables
+    for (int lg = 11; lg <= 26; lg += (lg >= 14 && lg < 21) ? 1 : 3) {   // 16 KiB ... 512 MiB tables (every power of two between 128 KiB and 16 MiB)
         float2* big; const size_t entries = (size_t)1 << lg;
         CHECK(hipMalloc(&big, entries * sizeof(float2))); CHECK(hipMemset(big, 0, entries * sizeof(float2)));
         for (int wide = 0; wide < 2; ++wide) {
