@@ -835,7 +835,9 @@ def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
         for k in (1, 2, 3):
             close = torch.isclose(a[k], b[k], rtol=1e-5, atol=1e-7)
             assert float((~close).float().mean()) < 1e-4, (other, k, float((~close).float().mean()))
-    assert torch.equal(res["fused"][5], res["joint"][5])                        # same gradients, same arithmetic: bit-identical tables
+    # same gradients up to the order of the f64 LDS additions (two accumulate kernels), same optimiser arithmetic
+    close = torch.isclose(res["fused"][5], res["joint"][5], rtol=1e-6, atol=1e-9)
+    assert float((~close).float().mean()) < 1e-5
 
 
 def test_mapstep_render_only_in_one_launch_equals_four_launches():
