@@ -92,16 +92,29 @@ def spawn_ranks(args, argv):
         out = subprocess.PIPE if r == 0 else sys.stderr          # only rank 0 prints the record
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out, stderr=sys.stderr))
     rc, line0 = 0, b""
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # rank 0's stdout is drained while all ranks are watched
+    reader.start()
     try:
-        line0, _ = procs[0].communicate()
-        for p in procs:
-            p.wait()
-            if p.returncode != 0 and rc == 0:
-                rc = p.returncode
+        live = list(procs)
+        while live and rc == 0:                                    # the first non-zero exit ends the job: a rank that outlives a failed
+            for p in list(live):                                   # peer would wait in a collective (or in the rendezvous) until its timeout
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    if code != 0:
+                        rc = code
+            if live and rc == 0:
+                time.sleep(0.05)
     finally:
-        for p in procs:                                            # a rank that outlives a failed peer would wait in a collective forever
+        for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    line0 = out0[0] if out0 else b""
     for line in line0.decode(errors="replace").splitlines():       # stdout carries the JSON record only; library chatter
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")   # (e.g. gloo's connection notes) goes to stderr
     sys.stdout.flush()
@@ -251,6 +264,10 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     global torch
+    wd = float(os.environ.get("US_BENCH_WATCHDOG", "0"))            # seconds; > 0: a rank that is still running then dumps the Python
+    if wd > 0:                                                     # stacks of all its threads to stderr (where does a stuck rank wait?)
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, repeat=False, file=sys.stderr)
     import torch as _torch
     torch = _torch
     import unislam_amd as us
@@ -331,8 +348,16 @@ def run_rank(args):
     nxt, ins = make_runner(step)
     # set-up, before the W warm-up steps: keep the GPU busy for a fixed wall time so that the timed region does not start on a card
     # that is still ramping its clocks after the CPU-side scene construction (a 20-step region lasts 14 ms)
+    # (every iteration of a data-parallel run contains collectives: the ranks must agree on how many they run, so the decision to go on
+    #  is itself reduced over the ranks -- a wall-clock test per rank let them part ways and wait for each other forever)
+    def all_agree(flag):
+        if world == 1:
+            return flag
+        f = torch.tensor([1.0 if flag else 0.0], device=dev)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_s:
+    while all_agree(time.perf_counter() - t_pre < args.prewarm_s):
         for _ in range(20):
             nxt()
         torch.cuda.synchronize()
