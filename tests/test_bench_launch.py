@@ -36,9 +36,9 @@ def test_plain_multi_gpu_command_spawns_ranks_and_propagates_failure():
 def test_plain_command_rehearsal_on_one_gpu(n, extra):
     """n ranks on cuda:0 over gloo through bench.py's own launcher.  (At most 6 processes may use the card of a test box at once:
     4 ranks + this process is the largest rehearsal that fits; the 8-rank protocol itself runs on the CPU in test_dist_gloo.py.)"""
-    env = dict(os.environ, US_BENCH_REHEARSE="1")
+    env = dict(os.environ, US_BENCH_REHEARSE="1", US_BENCH_WATCHDOG="300")         # (a rank still running after 5 minutes says where it waits)
     out = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "3", "--warmup", "1", "--rays", "512", "--probe-steps", "1",
-                          "--no-tracking", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                          "--no-tracking", "--no-cpu-baseline", "--prewarm-s", "0"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
