@@ -350,12 +350,8 @@ def run_rank(args):
     # that is still ramping its clocks after the CPU-side scene construction (a 20-step region lasts 14 ms)
     # (every iteration of a data-parallel run contains collectives: the ranks must agree on how many they run, so the decision to go on
     #  is itself reduced over the ranks -- a wall-clock test per rank let them part ways and wait for each other forever)
-    def all_agree(flag):
-        if world == 1:
-            return flag
-        f = torch.tensor([1.0 if flag else 0.0], device=dev)
-        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
-        return bool(f.item() > 0.5)
+    from unislam_amd.dist import all_agree as _all_agree
+    all_agree = lambda flag: _all_agree(flag, True if world > 1 else None, dev)
     t_pre = time.perf_counter()
     while all_agree(time.perf_counter() - t_pre < args.prewarm_s):
         for _ in range(20):

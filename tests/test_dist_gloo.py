@@ -236,3 +236,35 @@ def test_averaging_local_means_is_not_equivalent():
         e.forward(*tuple(t[:12] if r == 0 else t[12:] for t in full)); e.backward(); gs.append(e.grad.clone())
     naive = 0.5 * (gs[0] + gs[1])
     assert (naive - g_full).abs().max() > 1e-3 * g_full.abs().max()     # uneven slices: 12 vs 36 rays
+
+
+def _worker_budget_loop(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import time
+    from unislam_amd.dist import init_from_env, all_agree
+    init_from_env("gloo")
+    # a loop with a collective in its body and a per-rank wall-clock budget (rank r may spend 0.05 * (r + 1) s): as bench.py's set-up phase
+    t0, turns, acc = time.perf_counter(), 0, torch.zeros(1)
+    while all_agree(time.perf_counter() - t0 < 0.05 * (rank + 1)):
+        dist.all_reduce(acc)                                         # would hang if the ranks ran different numbers of turns
+        acc += 1.0
+        time.sleep(0.004)
+        turns += 1
+    flags = [all_agree(rank == 0), all_agree(True), all_agree(False)]
+    torch.save({"turns": turns, "flags": flags}, f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_all_agree_keeps_rank_local_budgets_in_step():
+    """unislam_amd.dist.all_agree: a loop that every rank would leave by its own wall clock, with a collective in its body, runs the same
+    number of turns on every rank (the shortest budget decides) -- the condition under which bench.py's set-up phase deadlocked a
+    data-parallel run before it used this -- and a flag that is true on one rank only is false everywhere."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o")
+        mp.spawn(_worker_budget_loop, args=(2, port, out), nprocs=2, join=True)
+        r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["turns"] == r1["turns"] and 1 <= r0["turns"] <= 40
+    assert r0["flags"] == r1["flags"] == [False, True, False]
+    from unislam_amd.dist import all_agree
+    assert all_agree(True, None) is True and all_agree(False, None) is False       # no process group: the flag itself

@@ -130,6 +130,18 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def all_agree(flag, group=True, device="cpu"):
+    """True on every rank iff `flag` is true on EVERY rank (one MIN all-reduce); without a process group: flag itself.
+    For loops whose length a rank would otherwise decide by itself -- a wall-clock budget, a host-side convergence test -- when the
+    loop body contains collectives: ranks that leave such a loop after different numbers of turns wait for each other forever
+    (bench.py's set-up phase did)."""
+    if group is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(_pg(group)) == 1:
+        return bool(flag)
+    f = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=_pg(group))
+    return bool(f.item() > 0.5)
+
+
 def shard_frames(n_frames, rank, world):
     """frames {f : f mod world == rank}"""
     return list(range(rank, n_frames, world))
