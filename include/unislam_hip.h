@@ -252,6 +252,11 @@ int us_encode_decode_fwd(const us_grid_desc* a, const us_grid_desc* b, const flo
  * the backward pass forms the parameter gradients of both decoders (then with one workspace, us_mlp_bwd_workspace_bytes, per decoder) or of
  * neither (grad_params and workspaces NULL: the input gradients only, as tracking needs them). */
 int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b);
+/* us_mlp_bwd_pair(..., US_MLP_DEFER_REDUCE, ...) leaves the partial weight gradients of both decoders in their workspaces;
+ * us_mlp_reduce_pair adds them to the gradients later (one launch, fixed order).  (The pair launch lays out its partial rows its own
+ * way: its workspaces are reduced by this function, not by us_mlp_reduce.) */
+int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b, size_t workspace_bytes,
+                       int64_t n, float* grad_params_a, float* grad_params_b, void* stream);
 int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
                     const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags, void* stream);
 int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,

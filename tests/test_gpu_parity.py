@@ -1122,8 +1122,18 @@ def test_mlp_pair_equals_two_launches(us, width, n_hidden, bias, prec, n):
             L.check(lib.us_mlp_bwd(A, P(pa), P(fa), off(raw, 3), 4, off(d_raw, 3), 4, n, P(dfa), P(ga), 1, P(wa), wsb, st), "bwd a")
             L.check(lib.us_mlp_bwd(B, P(pb), P(fb), P(raw), 4, P(d_raw), 4, n, P(dfb), P(gb), 1, P(wb), wsb, st), "bwd b")
         res[pair] = (raw, dfa, dfb, ga, gb)
-    for x, y in zip(res[True], res[False]):
+    for x, y in zip(res[True][:3], res[False][:3]):               # outputs, input gradients: bit-identical
         assert torch.equal(x, y)
+    for x, y in zip(res[True][3:], res[False][3:]):               # parameter gradients: the same per-workgroup partials, fewer rows to sum
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6 * float(y.abs().max()))
+    # the deferred reduction of the pair
+    ga2, gb2 = torch.zeros_like(pa), torch.zeros_like(pb)
+    wa, wb = torch.empty(wsb, dtype=torch.uint8, device=DEV), torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    L.check(lib.us_mlp_bwd_pair(A, B, P(pa), P(pb), P(fa), P(fb), off(res[True][0], 3), 4, P(res[True][0]), 4, off(d_raw, 3), 4, P(d_raw), 4, n,
+                                None, None, P(ga2), P(gb2), 1 | 2, P(wa), P(wb), wsb, st), "bwd pair, deferred")
+    assert float(ga2.abs().max()) == 0.0 and float(gb2.abs().max()) == 0.0
+    L.check(lib.us_mlp_reduce_pair(A, B, P(wa), P(wb), wsb, n, P(ga2), P(gb2), st), "reduce pair")
+    assert torch.equal(ga2, res[True][3]) and torch.equal(gb2, res[True][4])
     # input gradients only (tracking): no parameter gradients, no workspaces
     dfa, dfb = torch.zeros_like(fa), torch.zeros_like(fb)
     L.check(lib.us_mlp_bwd_pair(A, B, P(pa), P(pb), P(fa), P(fb), off(res[True][0], 3), 4, P(res[True][0]), 4, off(d_raw, 3), 4, P(d_raw), 4, n,

@@ -347,6 +347,28 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ p
     }
 }
 
+// ... for the two decoders of a pair launch at once (blockIdx.y = decoder)
+__global__ __launch_bounds__(1024) void k_mlp_reduce_pair(const float* __restrict__ pa, const float* __restrict__ pb, int n_rows, int npa, int npb,
+                                                          float* __restrict__ ga, float* __restrict__ gb) {
+    __shared__ float sh[16][64];
+    const float* partials = blockIdx.y ? pb : pa;
+    float* grad = blockIdx.y ? gb : ga;
+    const int np = blockIdx.y ? npb : npa;
+    const int kl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    float s = 0.0f;
+    if (k < np)
+        for (int r = sl; r < n_rows; r += 16) s += partials[(size_t)r * np + k];
+    sh[sl][kl] = s;
+    __syncthreads();
+    if (sl == 0 && k < np) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][kl];
+        grad[k] += t;
+    }
+}
+
 #ifndef MLP_BWD_W32
 #define MLP_BWD_W32 8
 #endif
@@ -560,10 +582,9 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->precision != US_PREC_F32;
-    const int pts = (d->width == 64 && !bf) ? 32 : 64;
-    // fp32: 2 workgroups per CU, each wave loops with its next chunk prefetched (21.9 vs 23.8 us at 262144 points, MI355X); the bf16
-    // kernel is shorter than its launch ramp and prefers one chunk per wave (12.2 vs 13.0 us)
-    const int64_t cap = bf ? 2048 : MLP_FWD_MAX_WG;
+    const int pts = bf ? 16 * MLP_BF_FWD_NQ : (d->width == 64 ? 32 : 64);
+    // fp32: 2 workgroups per CU, each wave loops with its next chunk prefetched (21.9 vs 23.8 us at 262144 points, MI355X); bf16: mlp_bf16.inc
+    const int64_t cap = bf ? MLP_BF_FWD_CAP1 : MLP_FWD_MAX_WG;
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
     if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
@@ -573,7 +594,9 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     return US_OK;
 }
 
+#ifndef MLP_BWD_MAX_WG
 #define MLP_BWD_MAX_WG 256
+#endif
 
 extern "C" size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d) {
     return d ? (size_t)MLP_BWD_MAX_WG * us_mlp_n_params(d) * sizeof(float) : 0;
@@ -639,6 +662,17 @@ static bool mlp_pair_ok(const us_mlp_desc* a, const us_mlp_desc* b) {
 }
 extern "C" int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b) { return mlp_pair_ok(a, b) ? 1 : 0; }
 
+// workgroups (= partial rows of the weight gradient) PER DECODER of the pair's backward launch: both decoders together put one
+// workgroup on every CU (MI355X, 2 x 32 decoders, 262 144 points: 48.0 us; 2 x 192: 61.0; 2 x 256: 55.8; 2 x 384: 64.6)
+#ifndef MLP_BWD_PAIR_WG
+#define MLP_BWD_PAIR_WG 128
+#endif
+static int64_t mlp_pair_rows(const us_mlp_desc* d, int64_t n) {
+    const int waves = MLP_BF_BWD_WAVES(d->width);
+    int64_t nb = us_cdiv(n, 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) * waves);
+    return nb > MLP_BWD_PAIR_WG ? MLP_BWD_PAIR_WG : nb;
+}
+
 #define MLP_PAIR_DISPATCH(KERNEL, ...)                                                                             \
     do {                                                                                                           \
         const int key = (int)da->width * 10 + (int)da->n_hidden;                                                   \
@@ -672,7 +706,7 @@ extern "C" int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
     US_REQUIRE(params_a && params_b && in_a && in_b && out_a && out_b, US_ERR_NULL, "us_mlp_fwd_pair: NULL pointer");
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    int64_t nb = us_cdiv(n, 64 * MLP_WAVES); if (nb > 2048) nb = 2048;           // as us_mlp_fwd (bf16)
+    int64_t nb = us_cdiv(n, 16 * MLP_BF_FWD_NQ * MLP_WAVES); if (nb > MLP_BF_FWD_CAP) nb = MLP_BF_FWD_CAP;           // as us_mlp_fwd (bf16)
     dim3 grid((unsigned)nb, 2), block(MLP_THREADS);
     MlpFwdJob a = {params_a, (int)da->has_bias, (int)da->n_out, (int)da->out_act, in_a, out_a, (long long)out_stride_a};
     MlpFwdJob b = {params_b, (int)db->has_bias, (int)db->n_out, (int)db->out_act, in_b, out_b, (long long)out_stride_b};
@@ -704,7 +738,7 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int waves = MLP_BF_BWD_WAVES(da->width);
-    int64_t nb = us_cdiv(n, 16 * MLP_BF_BWD_NQ(da->width, da->n_hidden) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;     // as us_mlp_bwd
+    const int64_t nb = mlp_pair_rows(da, n);
     dim3 grid((unsigned)nb, 2), block(waves * 64);
     MlpBwdJob a = {params_a, (int)da->has_bias, (int)da->n_out, (int)da->out_act, in_a, out_a, (long long)out_stride_a, dL_dout_a,
                    (long long)dout_stride_a, dL_din_a, grad_params_a, (float*)workspace_a};
@@ -714,10 +748,25 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
     US_CHECK_LAUNCH("us_mlp_bwd_pair");
     if (wgrad && !(flags & US_MLP_DEFER_REDUCE)) {
         const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
-        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npa, 64)), dim3(1024), 0, s, (const float*)workspace_a, (int)nb, npa, grad_params_a);
-        hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(npb, 64)), dim3(1024), 0, s, (const float*)workspace_b, (int)nb, npb, grad_params_b);
+        hipLaunchKernelGGL(k_mlp_reduce_pair, dim3((unsigned)us_cdiv(npa > npb ? npa : npb, 64), 2), dim3(1024), 0, s, (const float*)workspace_a,
+                           (const float*)workspace_b, (int)nb, npa, npb, grad_params_a, grad_params_b);
         US_CHECK_LAUNCH("us_mlp_bwd_pair(reduce)");
     }
+    return US_OK;
+}
+
+// the reductions us_mlp_bwd_pair(..., US_MLP_DEFER_REDUCE) left out, both decoders in one launch (fixed order)
+extern "C" int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b, size_t workspace_bytes,
+                                  int64_t n, float* grad_params_a, float* grad_params_b, void* stream) {
+    US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_reduce_pair: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(workspace_a && workspace_b && grad_params_a && grad_params_b, US_ERR_NULL, "us_mlp_reduce_pair: NULL pointer");
+    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
+               "us_mlp_reduce_pair: workspace %zu B too small", workspace_bytes);
+    const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
+    hipLaunchKernelGGL(k_mlp_reduce_pair, dim3((unsigned)us_cdiv(npa > npb ? npa : npb, 64), 2), dim3(1024), 0, (hipStream_t)stream,
+                       (const float*)workspace_a, (const float*)workspace_b, (int)mlp_pair_rows(da, n), npa, npb, grad_params_a, grad_params_b);
+    US_CHECK_LAUNCH("us_mlp_reduce_pair");
     return US_OK;
 }
 

@@ -517,8 +517,12 @@ class MapStep:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
                     if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
                         self.grad[:self.o_tab_s].zero_()
-                    L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
-                    L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
+                    if self._decoder_pair():                     # (the pair launch's partial rows: reduced by its own function)
+                        L.check(lib.us_mlp_reduce_pair(ms, mc, P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s),
+                                                       off(self.grad, self.o_dec_c), st2), "us_mlp_reduce_pair")
+                    else:
+                        L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
+                        L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
                     if gbeta is not None:
                         L.check(lib.us_beta_reduce(P(self.beta_part), R, gbeta, st2), "us_beta_reduce")
                     if not self._step_advanced:
