@@ -25,7 +25,9 @@
 #include "binned_dev.h"
 #include <string.h>
 
+#ifndef J_FWD_THREADS
 #define J_FWD_THREADS 1024               // encoder workgroup: 1024 points x one level (two count rows)
+#endif
 #define J_ROW_POINTS 512                 // points per count row = per k_jwrite workgroup
 #define J_MAX_LEVELS 16
 #define J_MAX_BINS 8192                  // bins over all levels
@@ -742,7 +744,9 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n
 // are in flight across its barriers and its sweep (the barriers order LDS only).  The sweep returns the accumulators it read to zero,
 // so no clear pass and no third barrier per item.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef J_ACCP_GROUPS
 #define J_ACCP_GROUPS 1024
+#endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
 enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
