@@ -191,6 +191,17 @@ int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uin
 int us_hashgrid_bwd_input_gather(const us_grid_desc* desc_host, const float* params, const float* x, const float* dL_dy,
                                  int64_t n, float* dL_dx, int flags, void* stream);
 
+/* Both grids' input gradient reduced to the rays in ONE launch: dL_do[R][3], dL_dd[R][3] = adjoint of us_ray_points applied to
+ * dL/dx = us_hashgrid_bwd_input_gather(a) + us_hashgrid_bwd_input_gather(b) -- what the camera pose receives in
+ * Tracker.optimize_tracking (src/Tracker.py:170-174,241) and in the joint pose optimisation of Mapper.optimize_mapping
+ * (src/Mapper.py:372-376,444).  x[R*S][3] unit-cube points of R rays x S samples, z_vals[R][S]; dL_dx (nullable): the per-point
+ * gradient as well (bit-identical to the two one-grid launches).  Two F = 2 grids of equal depth, S <= 128
+ * (us_hashgrid_bwd_input_rays_supported).  flags: US_GRID_CLAMP01, US_GRID_LEVEL_MAJOR. */
+int us_hashgrid_bwd_input_rays_supported(const us_grid_desc* a, const us_grid_desc* b, int n_samples);
+int us_hashgrid_bwd_input_rays(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB, const float* x,
+                               const float* dL_dyA, const float* dL_dyB, int64_t n_rays, int n_samples, const float* z_vals,
+                               const float* bound_host, float* dL_do, float* dL_dd, float* dL_dx, int flags, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused tiny MLP on MFMA  (replaces tcnn.Network "FullyFusedMLP" src/networks/decoders.py:50-70,123,148
  * and the nn.Linear stacks src/networks/decoders.py:74-84,125-128,150-153)
@@ -433,6 +444,35 @@ int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* 
 /* g_pose[7] = dL/dpose from dL/d rays_o, dL/d rays_d (closed-form chain rule through R(q) = I + 2 M(q)/|q|^2) */
 int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n, float* g_pose,
                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mapping window with joint pose optimisation  (replaces, per iteration of Mapper.optimize_mapping with joint_opt -- the default,
+ * configs/UNISLAM.yaml:50, on from the fifth keyframe src/Mapper.py:519 -- cam_pose_to_matrix + get_samples_all src/Mapper.py:372-393,
+ * src/common.py:152-166,196-208, and the pose param group of the optimiser src/Mapper.py:359-364,443-445)
+ * ---------------------------------------------------------------------------------------------- */
+/* Rays of window frames f_begin .. f_begin + f_count - 1, n_per_frame pixels each: idx[f_count][n_per_frame] int64 into the frames'
+ * pools (pool_*[b][P]..., indexed by the WINDOW frame number).  Frame 0 keeps the matrix c2w_first[4][4] (the oldest pose is fixed,
+ * src/Mapper.py:374); frame f >= 1 uses poses7[f-1] = (qr,qi,qj,qk, tx,ty,tz) through pytorch3d's quaternion_to_matrix.  Outputs as
+ * us_gather_rays plus dirs[n][3] (nullable), the camera-frame directions us_pose_window_step needs.  The output pointers address
+ * the first row of this call's block (a second call appends the extra rays of the newest frames, src/Mapper.py:385-393). */
+int us_window_rays(const float* c2w_first, const float* poses7, const float* pool_depth, const float* pool_color, const float* pool_dirs,
+                   const int64_t* idx, int64_t pool_size, int f_begin, int f_count, int64_t n_per_frame, float* rays_o, float* rays_d,
+                   float* depth, float* color, float* dirs, void* stream);
+/* Pose gradient and Adam step of n_poses poses in one launch (one workgroup per pose).  Pose j owns rows
+ * [row_a + j*n_a, row_a + (j+1)*n_a) of g_rays_o / g_rays_d / dirs and, if n_b > 0 and j >= first_pose_b, rows
+ * [row_b + (j-first_pose_b)*n_b, ... + n_b).  g7 = dL/dpose by the closed-form chain rule through R(q) = I + 2 M(q)/|q|^2 (fixed-order
+ * f64 sums); then torch.optim.Adam on the 7 numbers (lr_q for the quaternion, lr_t for the translation).  g7_out (nullable) receives
+ * the gradients.  flags:
+ *   0                  step_dev = the float[8] of us_adam_step_inc, ALREADY advanced for this optimiser step (the poses are one more
+ *                      param group of the mapping optimiser: same count, same bias corrections as us_adam_step_segments_dev)
+ *   US_POSE_OWN_STEP   step_dev = float[1], advanced by this launch, fp32 bias corrections (us_pose_adam_step arithmetic; the
+ *                      tracker's per-frame optimiser src/Tracker.py:322-329,242); n_poses must be 1
+ *   US_POSE_GRAD_ONLY  no optimiser step (m7, v7, step_dev may be NULL) */
+#define US_POSE_GRAD_ONLY 1
+#define US_POSE_OWN_STEP 2
+int us_pose_window_step(float* poses7, int n_poses, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t row_a,
+                        int64_t n_a, int first_pose_b, int64_t row_b, int64_t n_b, float* m7, float* v7, float* g7_out, double lr_q,
+                        double lr_t, double beta1, double beta2, double eps, float* step_dev, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,9 @@ Fixtures:
                 association, frame-rate thinning, first-frame-relative poses) on small text files written here; the image decode of
                 __getitem__ needs OpenCV, which the image lacks, and is not captured
   g12_ate       src/tools/eval_ate.py: align (Horn), associate, evaluate_ate, pose_evaluation on generated trajectories
+  g14_mapping_joint  Mapper.optimize_mapping with joint_opt = True (dummy self): a 6-frame window, and a 12-frame window of a 22-keyframe
+                list with the 10 x 200 extra rays of Mapper.py:385-393; one iteration (pose / table gradients, state after Adam) and two
+                iterations (final tables, decoders, poses); pytorch3d's two quaternion helpers are the oracle's restatement
   g13_scene     src/UNISLAM.py update_cam / load_bound / get_resolution (dummy self) and the per_level_scale line of get_encoder, and
                 src/config.py load_config, for the room0 / scene0000 / fr1_desk settings (their numbers are inputs of the fixture)
 """
@@ -47,6 +50,7 @@ for m in ["pytorch3d", "pytorch3d.transforms", "tinycudann", "colorama", "cv2", 
     sys.modules[m] = MagicMock()
 # pytorch3d is absent: the pose helper is build-owned (parity unpinned for it); give the reference our restatement
 sys.modules["pytorch3d.transforms"].quaternion_to_matrix = O.quaternion_to_matrix
+sys.modules["pytorch3d.transforms"].matrix_to_quaternion = O.matrix_to_quaternion
 sys.path.insert(0, REF)
 import warnings  # noqa: E402
 warnings.simplefilter("ignore")
@@ -59,6 +63,7 @@ import src.Tracker as RT  # noqa: E402
 import src.Mapper as RM  # noqa: E402
 
 RC.quaternion_to_matrix = O.quaternion_to_matrix
+RC.matrix_to_quaternion = O.matrix_to_quaternion
 DEV = "cpu"
 
 
@@ -352,6 +357,74 @@ def g9():
     npz("g9_mapping", **out)
 
 
+def g14():
+    """Mapper.optimize_mapping (Mapper.py:276-459) with joint_opt = True and a dummy self: the window's poses are a fourth Adam group."""
+    H, W, fx, fy, cx, cy = 24, 32, 18.0, 18.0, 15.5, 11.5
+    cfg = make_cfg(32, 8, True)
+    cfg["mapping"] = {"lr": {"decoders_lr": 0.001, "hash_grids_lr": 0.05, "c_hash_grids_lr": 0.05}}
+    renderer = make_renderer(cfg, H, W, fx, fy, cx, cy)
+    dec0 = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+    sd0 = {k: v.clone() for k, v in dec0.state_dict().items()}
+    gs0, gc0 = small_grid(1401, amp=0.3).params.detach().clone(), small_grid(1402, amp=0.3).params.detach().clone()
+    rays_d = RC.get_camera_rays(H, W, fx, fy, cx, cy)
+    out = dict(intr=np.array([H, W, fx, fy, cx, cy]), grid_s0=gs0, grid_c0=gc0, cam_lr=0.001, lr_factor=1.0,
+               **{"dec0__" + k.replace(".", "__"): v for k, v in sd0.items()})
+    base = torch.tensor([0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0])
+    for tag, n_kf, picks, pixels, seed in (("w6", 5, [0, 1, 2], 120, 141), ("w12x", 22, [0, 2, 4, 6, 8, 10, 12, 14, 16], 120, 142)):
+        g = torch.Generator().manual_seed(seed)
+        n_pool = int(H * W * 0.1)
+        kd, kl = [], []
+        for k in range(n_kf):
+            pose = base + torch.cat([torch.randn(4, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1])
+            c2w = O.cam_pose_to_matrix(pose[None])[0]
+            depth = torch.rand(H * W, generator=g) * 1.5 + 0.5
+            depth[3::37] = 50.0                                              # beyond the scene box: dropped by the pre-filter
+            color = torch.rand(H * W, 3, generator=g)
+            ind = torch.randperm(H * W, generator=g)[:n_pool]
+            kd.append({"gt_c2w": c2w.clone(), "idx": 4 * k, "color": color[ind], "depth": depth[ind], "est_c2w": c2w.clone(),
+                       "rays_d": rays_d.reshape(-1, 3)[ind]})
+            kl.append(4 * k)
+        cur_depth = torch.rand(H, W, generator=g) * 1.5 + 0.5
+        cur_depth[7, 3:9] = 50.0
+        cur_color = torch.rand(H, W, 3, generator=g)
+        cur_c2w = O.cam_pose_to_matrix((base + torch.cat([torch.randn(4, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1]))[None])[0]
+        frames = sorted(picks + [n_kf - 1, n_kf - 2])
+        out.update({f"{tag}_n_kf": n_kf, f"{tag}_frames": np.array(frames), f"{tag}_pixels": pixels, f"{tag}_seed": seed,
+                    f"{tag}_kf_c2w": torch.stack([d["est_c2w"] for d in kd]), f"{tag}_kf_depth": torch.stack([d["depth"] for d in kd]),
+                    f"{tag}_kf_color": torch.stack([d["color"] for d in kd]), f"{tag}_kf_dirs": torch.stack([d["rays_d"] for d in kd]),
+                    f"{tag}_cur_depth": cur_depth, f"{tag}_cur_color": cur_color, f"{tag}_cur_c2w": cur_c2w})
+        for iters in (1, 2):
+            dec = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
+            dec.load_state_dict(sd0)
+            enc_s, enc_c = small_grid(1401, amp=0.3), small_grid(1402, amp=0.3)
+            kd_run = [dict(d, est_c2w=d["est_c2w"].clone()) for d in kd]
+            me = types.SimpleNamespace(cfg=cfg, hash_grids_xyz=[enc_s], c_hash_grids_xyz=[enc_c], device=DEV,
+                                       H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, bound=BOUND, renderer=renderer, decoders=dec,
+                                       truncation=0.06, m_mask_mode="original", w_color=5, w_depth=0.1, w_sdf_fs=5,
+                                       w_sdf_center=200, w_sdf_tail=10, keyframe_selection_method="global",
+                                       keyframe_dict=kd_run, keyframe_list=kl, mapping_pixels=pixels, joint_opt=True, joint_opt_cam_lr=0.001,
+                                       no_vis_on_first_frame=True, tracking_back=torch.zeros(1).int(), mapping_window_size=20,
+                                       visualizer=MagicMock())
+            me.sdf_losses = lambda *a, _me=me: RefMapper.sdf_losses(_me, *a)
+            me.create_optimizer = lambda c, f, _me=me: RefMapper.create_optimizer(_me, c, f)
+            me.keyframe_selection_LC = lambda *a, _p=picks: list(_p)       # SLAM policy (pinned by g10), kept out of the random stream
+            torch.manual_seed(seed)
+            new_c2w = RefMapper.optimize_mapping(me, iters, 1.0, 4 * n_kf, cur_color, cur_depth, cur_c2w, kd_run, kl, cur_c2w.clone(), rays_d)
+            cam = me.optimizer.param_groups[3]["params"][0]
+            pre = f"{tag}_i{iters}_"
+            out.update({pre + "poses": cam.detach().clone(), pre + "cur_c2w": new_c2w.detach().clone(),
+                        pre + "kf_c2w": torch.stack([d["est_c2w"].detach() for d in kd_run])})
+            if iters == 1:                                                   # the gradients of the (only) iteration
+                out.update({pre + "g_poses": cam.grad.clone(), pre + "g_beta": dec.beta.grad.clone()})
+                if tag == "w6":
+                    out.update({pre + "g_grid_s": enc_s.params.grad.clone(), pre + "g_grid_c": enc_c.params.grad.clone()})
+            else:                                                            # the state after two optimiser steps
+                out.update({pre + "grid_s": enc_s.params.detach().clone(), pre + "grid_c": enc_c.params.detach().clone(),
+                            **{pre + "dec__" + k.replace(".", "__"): v.clone() for k, v in dec.state_dict().items()}})
+    npz("g14_mapping_joint", **out)
+
+
+
 def g10():
     """Mapper.keyframe_selection_LC (Mapper.py:177-274) with a dummy self; three situations."""
     g = torch.Generator().manual_seed(10)
@@ -568,6 +641,6 @@ def g13():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()

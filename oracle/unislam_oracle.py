@@ -448,6 +448,28 @@ def cam_pose_to_matrix(poses):
     return c2w
 
 
+def matrix_to_quaternion(matrix):
+    """pytorch3d.transforms.matrix_to_quaternion (pinned commit 47d5dc88, requirements.txt:91; absent here: restated, parity unpinned):
+    real part first; the candidate built from the largest of the four |q_i| is taken, denominators floored at 0.1."""
+    m = matrix.reshape(matrix.shape[:-2] + (9,))
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m, dim=-1)
+    x = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
+    q_abs = torch.where(x > 0, torch.sqrt(torch.clamp(x, min=0.0)), torch.zeros_like(x))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(dim=-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+
+
+def matrix_to_cam_pose(mats):
+    """common.py:182-194 (RT=True): 4x4 -> [quat(4, real first), t(3)]."""
+    return torch.cat([matrix_to_quaternion(mats[:, :3, :3]), mats[:, :3, 3]], dim=-1)
+
+
 # --------------------------------------------------------------------------------------
 # renderer (src/utils/Renderer.py:42-158) and sample_pdf (src/common.py:49-85)
 # --------------------------------------------------------------------------------------
@@ -615,6 +637,18 @@ def tracking_loss(ret, gt_depth, gt_color, truncation, w, mask_mode="original"):
 # --------------------------------------------------------------------------------------
 # one full mapping iteration on CPU (Mapper.py:366-445) -- used as bench.py's cpu_baseline ("port")
 # --------------------------------------------------------------------------------------
+def window_rays(c2w_first, cam_poses, depths, colors, dirs_pool, indices, extra=None, indices_extra=None):
+    """Mapper.py:372-393 for a window whose poses 1.. are the 7-vectors `cam_poses` (a leaf the caller differentiates): the rays of
+    get_samples_all over all frames, then -- extra = (n_frames, n) -- of a second call over the newest n_frames frames."""
+    c2ws = torch.cat([c2w_first[None], cam_pose_to_matrix(cam_poses)], dim=0) if cam_poses is not None else c2w_first[None]
+    out = list(get_samples_all(indices.shape[1], c2ws, depths, colors, dirs_pool, indices))
+    if extra is not None:
+        nf = extra[0]
+        o2 = get_samples_all(extra[1], c2ws[-nf:], depths[-nf:], colors[-nf:], dirs_pool[-nf:], indices_extra)
+        out = [torch.cat([a, b], dim=0) for a, b in zip(out, o2)]
+    return out
+
+
 def mapping_iteration(scene_rep, decoders, optimizer, rays_o, rays_d, gt_depth, gt_color, bound, truncation,
                       n_stratified, n_importance, w, mask_mode="original", perturb=True):
     with torch.no_grad():

@@ -1,0 +1,243 @@
+"""
+GPU: the mapping window with joint pose optimisation (unislam_amd.window.MapWindow; the reference's default joint_opt,
+src/Mapper.py:359-376,443-459) -- its three kernels against torch / the oracle, the whole iteration against the fixture generated from
+the reference's Mapper.optimize_mapping (g14), hipGraph replay against eager.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import unislam_oracle as O
+from test_oracle_golden import g14_window
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+W = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+LR = dict(decoders=0.001, sdf_grid=0.05, color_grid=0.05)
+T = torch.from_numpy
+
+
+def _cfg(tcnn=False, ns=32, ni=8):
+    return {"rendering": {"perturb": True, "n_stratified": ns, "n_importance": ni}, "scale": 1, "grid_mode": "hash_grid",
+            "grid": {"tcnn_network": tcnn}}
+
+
+def _ecfg(log2T, res=816):
+    return {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2T,
+            "base_resolution": 16, "per_level_scale": O.per_level_scale(res)}
+
+
+def _window(b, P, seed, spread=0.1):
+    """a synthetic window: poses around a base pose inside the room, pools with depths inside the box (a few beyond it)"""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.tensor([0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0])
+    poses = base[None] + torch.cat([torch.randn(b, 4, generator=g) * 0.05, torch.randn(b, 3, generator=g) * spread], -1)
+    c2ws = O.cam_pose_to_matrix(poses)
+    u, v = torch.rand(b, P, generator=g) * 31, torch.rand(b, P, generator=g) * 23
+    dirs = torch.stack([(u - 15.5) / 18.0, -(v - 11.5) / 18.0, -torch.ones_like(u)], -1)
+    depths = torch.rand(b, P, generator=g) * 1.5 + 0.5
+    depths[:, 5::41] = 50.0
+    colors = torch.rand(b, P, 3, generator=g)
+    return c2ws, depths, colors, dirs
+
+
+def test_window_rays_and_pose_step_against_autograd():
+    """us_window_rays == the reference's cam_pose_to_matrix + get_samples_all (both calls); us_pose_window_step's gradient == autograd
+    through them, per frame, with and without the extra block; its Adam step == torch.optim.Adam on the poses"""
+    import ctypes
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    lib, P_ = L.lib(), L.ptr
+    for b, n_per, extra in ((6, 20, None), (12, 10, (10, 37)), (4, 9, (10, 5)), (2, 33, None)):
+        c2ws, depths, colors, dirs = _window(b, 300, 50 + b)
+        g = torch.Generator().manual_seed(b)
+        idx = torch.randint(300, (b, n_per), generator=g)
+        nf = min(extra[0], b) if extra else 0
+        idx2 = torch.randint(300, (nf, extra[1]), generator=g) if extra else None
+        poses = O.matrix_to_cam_pose(c2ws[1:]).requires_grad_(True)
+        ro, rd, gd, gc = O.window_rays(c2ws[0], poses, depths, colors, dirs, idx, (nf, extra[1]) if extra else None, idx2)
+        R = ro.shape[0]
+        f = lambda *s: torch.empty(s, device=DEV)
+        o_ro, o_rd, o_gd, o_gc, o_dirs = f(R, 3), f(R, 3), f(R), f(R, 3), f(R, 3)
+        d_c0, d_p = c2ws[0].contiguous().to(DEV), poses.detach().contiguous().to(DEV)
+        pd, pc, pr = depths.to(DEV), colors.to(DEV), dirs.contiguous().to(DEV)
+        L.check(lib.us_window_rays(P_(d_c0), P_(d_p), P_(pd), P_(pc), P_(pr), P_(idx.to(DEV)), 300, 0, b, n_per, P_(o_ro), P_(o_rd), P_(o_gd),
+                                   P_(o_gc), P_(o_dirs), L.stream()), "us_window_rays")
+        if extra:
+            r0 = b * n_per
+            off = lambda t, w: ctypes.c_void_p(t.data_ptr() + 4 * r0 * w)
+            L.check(lib.us_window_rays(P_(d_c0), P_(d_p), P_(pd), P_(pc), P_(pr), P_(idx2.to(DEV)), 300, b - nf, nf, extra[1], off(o_ro, 3),
+                                       off(o_rd, 3), off(o_gd, 1), off(o_gc, 3), off(o_dirs, 3), L.stream()), "us_window_rays")
+        assert torch.allclose(o_rd.cpu(), rd.detach(), rtol=1e-5, atol=1e-6) and torch.allclose(o_ro.cpu(), ro.detach(), rtol=1e-6, atol=1e-7)
+        assert torch.equal(o_gd.cpu(), gd) and torch.equal(o_gc.cpu(), gc)
+        g_o, g_d = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+        torch.autograd.backward([ro, rd], [g_o, g_d])
+        g7 = f(b - 1, 7)
+        args = (b - 1, P_(g_o.to(DEV)), P_(g_d.to(DEV)), P_(o_dirs), n_per, n_per, max(b - nf - 1, 0),
+                b * n_per + (extra[1] if (extra and nf == b) else 0), extra[1] if extra else 0)
+        L.check(lib.us_pose_window_step(P_(d_p), *args, None, None, P_(g7), 0.0, 0.0, 0.9, 0.999, 1e-8, None, L.US_POSE_GRAD_ONLY, L.stream()),
+                "us_pose_window_step")
+        assert torch.allclose(g7.cpu(), poses.grad, rtol=1e-4, atol=1e-5 * float(poses.grad.abs().max())), (b, extra)
+        # the optimiser step: three steps of torch.optim.Adam on the same gradients (the step count advanced by us_adam_step_inc)
+        pt = torch.nn.Parameter(poses.detach().clone()); opt = torch.optim.Adam([pt], lr=1e-3)
+        m7, v7, step_dev = torch.zeros(b - 1, 7, device=DEV), torch.zeros(b - 1, 7, device=DEV), torch.zeros(8, device=DEV)
+        for _ in range(3):
+            pt.grad = poses.grad.clone(); opt.step()
+            L.check(lib.us_adam_step_inc(P_(step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
+            L.check(lib.us_pose_window_step(P_(d_p), *args, P_(m7), P_(v7), None, 1e-3, 1e-3, 0.9, 0.999, 1e-8, P_(step_dev), 0, L.stream()),
+                    "us_pose_window_step")
+        # (the gradient is re-derived from the MOVED pose by the kernel; Adam's first steps are sign steps, so the paths agree to 1e-5)
+        assert torch.allclose(d_p.cpu(), pt.detach(), rtol=0, atol=2e-5), float((d_p.cpu() - pt.detach()).abs().max())
+
+
+@pytest.mark.parametrize("S,pair", [(64, (16, 19)), (40, (14, 15)), (96, (16, 16)), (7, (12, 12))])
+def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
+    """us_hashgrid_bwd_input_rays: per-point dL/dx bit-identical to two us_hashgrid_bwd_input_gather launches, dL/do and dL/dd equal to
+    us_ray_points_bwd of it (summation order differs: 1e-5)"""
+    import ctypes
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    lib, P_ = L.lib(), L.ptr
+    R = 133
+    N = R * S
+    g = torch.Generator().manual_seed(S)
+    es, ec = us.HashGridEncoding(3, _ecfg(pair[0])).to(DEV), us.HashGridEncoding(3, _ecfg(pair[1])).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape, generator=g) * 0.3); ec.params.copy_(torch.randn(ec.params.shape, generator=g) * 0.3)
+    x = (torch.rand(N, 3, generator=g) * 1.1 - 0.05).to(DEV)                   # some coordinates outside [0,1]: the clamp's zero gradient
+    dya, dyb = torch.randn(16, N, 2, generator=g).to(DEV), torch.randn(16, N, 2, generator=g).to(DEV)
+    z = torch.rand(R, S, generator=g).to(DEV) * 3
+    bh = us.common.bound_host(BOUND)
+    f = lambda *s: torch.empty(s, device=DEV)
+    d_ref, go_ref, gd_ref = f(N, 3), f(R, 3), f(R, 3)
+    ds, dc = ctypes.byref(es.desc), ctypes.byref(ec.desc)
+    L.check(lib.us_hashgrid_bwd_input_gather(ds, P_(es.params.detach()), P_(x), P_(dya), N, P_(d_ref), 3, L.stream()), "a")
+    L.check(lib.us_hashgrid_bwd_input_gather(dc, P_(ec.params.detach()), P_(x), P_(dyb), N, P_(d_ref), 3 | L.US_GRID_ACCUMULATE, L.stream()), "b")
+    L.check(lib.us_ray_points_bwd(P_(d_ref), P_(z), bh, R, S, P_(go_ref), P_(gd_ref), L.stream()), "c")
+    d_new, go, gd = f(N, 3), f(R, 3), f(R, 3)
+    assert lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S) == 1
+    L.check(lib.us_hashgrid_bwd_input_rays(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), P_(dya), P_(dyb), R, S, P_(z), bh,
+                                           P_(go), P_(gd), P_(d_new), 3, L.stream()), "us_hashgrid_bwd_input_rays")
+    assert torch.equal(d_new, d_ref)
+    for a, b in ((go, go_ref), (gd, gd_ref)):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+    go2, gd2 = f(R, 3), f(R, 3)                                                # without the per-point output
+    L.check(lib.us_hashgrid_bwd_input_rays(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), P_(dya), P_(dyb), R, S, P_(z), bh,
+                                           P_(go2), P_(gd2), None, 3, L.stream()), "us_hashgrid_bwd_input_rays")
+    assert torch.equal(go2, go) and torch.equal(gd2, gd)
+    assert lib.us_hashgrid_bwd_input_rays_supported(ds, dc, 129) == 0
+
+
+def _g14_scene(us, g):
+    dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06)
+    dec.load_state_dict({k[len("dec0__"):].replace("__", "."): T(v) for k, v in g.items() if k.startswith("dec0__")})
+    dec = dec.to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(10, 64)).to(DEV), us.HashGridEncoding(3, _ecfg(10, 64)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(T(g["grid_s0"])); ec.params.copy_(T(g["grid_c0"]))
+    return dec, es, ec
+
+
+@pytest.mark.parametrize("tag", ["w6", "w12x"])
+def test_mapwindow_reproduces_reference_joint_opt(golden, tag):
+    """MapWindow driven like Mapper.optimize_mapping with joint_opt (6-frame window; 12-frame window + the 10 x 200 extra rays) against
+    fixture g14: pose / table / beta gradients of the first iteration, and tables, decoders and poses after two optimiser steps"""
+    import unislam_amd as us
+    g = golden("g14_mapping_joint")
+    for iters in (1, 2):
+        dec, es, ec = _g14_scene(us, g)
+        c2ws, depths, colors, dirs, n_per, extra, frames = g14_window(g, tag)     # re-seeds torch's CPU generator like the reference run
+        b, P = depths.shape
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per + (2000 if extra else 0))
+        step.reset_optimizer(float(g["lr_factor"]))
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=float(g["cam_lr"]), extra=extra)
+        assert not win.has_zero
+        for it in range(iters):
+            idx = torch.randint(P, (n_per * b,)).reshape(b, -1)
+            idx2 = torch.randint(P, (extra[1] * extra[0],)).reshape(extra[0], -1) if extra else None
+            # the reference jitters only the rays its pre-filter kept (src/Mapper.py:396-406 -> Renderer.py:55): same stream positions
+            ro, rd, gd, _ = O.window_rays(c2ws[0], win.poses.cpu(), depths, colors, dirs, idx, extra, idx2)
+            inside = O.bbox_far(ro, rd, BOUND) >= gd
+            t_rand = torch.zeros(ro.shape[0], 40)
+            t_rand[inside] = torch.rand(int(inside.sum()), 40)
+            win.iterate(idx.to(DEV), idx2.to(DEV) if extra else None, t_rand=t_rand.to(DEV))
+            assert torch.equal(step.valid[:win.R].bool().cpu(), inside)
+        pre = f"{tag}_i{iters}_"
+        if iters == 1:
+            gp = T(g[pre + "g_poses"])
+            assert torch.allclose(win.g_pose.cpu(), gp, rtol=2e-3, atol=2e-4 * float(gp.abs().max())), float((win.g_pose.cpu() - gp).abs().max() / gp.abs().max())
+            # (the table gradients were consumed by Adam; beta's sits in the decoder segment Adam clears -> compare through the state)
+        np.testing.assert_allclose(win.poses.cpu().numpy(), g[pre + "poses"], rtol=0, atol=2e-5)
+        out = win.c2ws().cpu()
+        np.testing.assert_allclose(out[-1].numpy(), g[pre + "cur_c2w"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(out[:-1].numpy(), g[pre + "kf_c2w"][frames], rtol=0, atol=3e-5)
+        if iters == 2:
+            np.testing.assert_allclose(es.params.detach().cpu().numpy(), g[pre + "grid_s"], rtol=1e-3, atol=2e-5)
+            np.testing.assert_allclose(ec.params.detach().cpu().numpy(), g[pre + "grid_c"], rtol=1e-3, atol=2e-5)
+            for k, v in dec.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), g[pre + "dec__" + k.replace(".", "__")], rtol=1e-3, atol=2e-5)
+
+
+def test_mapwindow_first_iteration_gradients_against_reference(golden):
+    """the table and beta gradients of g14's first iteration (forward + backward of the window, no optimiser step)"""
+    import unislam_amd as us
+    g = golden("g14_mapping_joint")
+    dec, es, ec = _g14_scene(us, g)
+    c2ws, depths, colors, dirs, n_per, extra, frames = g14_window(g, "w6")
+    b, P = depths.shape
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per)
+    win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=float(g["cam_lr"]))
+    idx = torch.randint(P, (n_per * b,)).reshape(b, -1)
+    ro, rd, gd, _ = O.window_rays(c2ws[0], win.poses.cpu(), depths, colors, dirs, idx)
+    inside = O.bbox_far(ro, rd, BOUND) >= gd
+    t_rand = torch.zeros(ro.shape[0], 40); t_rand[inside] = torch.rand(int(inside.sum()), 40)
+    win.draw(idx.to(DEV))
+    step.lr = {k: 0.0 for k in step.lr}; win.cam_lr = 0.0
+    step.forward(*win.rays(), t_rand.to(DEV), False)
+    step.backward(ray_grads=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(es.params.grad.cpu().numpy(), g["w6_i1_g_grid_s"], rtol=1e-3, atol=1e-5 * float(np.abs(g["w6_i1_g_grid_s"]).max()))
+    np.testing.assert_allclose(ec.params.grad.cpu().numpy(), g["w6_i1_g_grid_c"], rtol=1e-3, atol=1e-5 * float(np.abs(g["w6_i1_g_grid_c"]).max()))
+    np.testing.assert_allclose(float(dec.beta.grad), float(g["w6_i1_g_beta"]), rtol=1e-3)
+
+
+def test_mapwindow_graph_replay_equals_eager():
+    """capture() / replay(): five replayed joint_opt iterations == five eager ones on the same draws and jitter (loss 1e-6, parameters
+    and poses allclose); capturing leaves model, optimiser and poses alone; the extra-ray block rides along"""
+    import unislam_amd as us
+    b, P, n_per, extra = 8, 500, 64, (10, 25)
+    c2ws, depths, colors, dirs = _window(b, P, 7)
+    g = torch.Generator().manual_seed(5)
+    R = b * n_per + min(extra[0], b) * extra[1]
+    draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.randint(P, (min(extra[0], b), extra[1]), generator=g).to(DEV),
+              torch.rand(R, 40, generator=g).to(DEV)) for _ in range(6)]
+    outs = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=False)
+        losses = [float(win.iterate(draws[0][0], draws[0][1], t_rand=draws[0][2]))]          # one eager step first: moments are non-zero
+        if mode == "graph":
+            before = (step.flat.clone(), step.m.clone(), win.poses.clone(), win.pm.clone(), float(step.step_dev[0]))
+            win.capture(t_rand=True)
+            assert torch.equal(step.flat, before[0]) and torch.equal(step.m, before[1]) and torch.equal(win.poses, before[2])
+            assert torch.equal(win.pm, before[3]) and float(step.step_dev[0]) == before[4] == 1.0
+        for ia, ib, tr in draws[1:]:
+            if mode == "graph":
+                win.t_rand.copy_(tr)
+                losses.append(float(win.replay(ia, ib)))
+            else:
+                losses.append(float(win.iterate(ia, ib, t_rand=tr)))
+        assert float(step.step_dev[0]) == 6.0
+        outs.append((losses, step.flat.clone(), win.poses.clone()))
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6)
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-6, atol=1e-8)
+    assert torch.allclose(outs[1][2], outs[0][2], rtol=0, atol=1e-7)
+    assert float((outs[0][2] - O.matrix_to_cam_pose(c2ws[1:]).to(DEV)).abs().max()) > 1e-3       # the poses did move

@@ -206,3 +206,55 @@ def test_g10_keyframe_selection(golden):
                                                cam, "cpu", tracking_back=bool(g[f"{tag}_tb"]), activated_mapping_mode=True, LC=True)
         assert [int(v) for v in sel] == [int(v) for v in g[f"{tag}_sel"]], tag
         assert int(loop) == int(g[f"{tag}_lc"])
+
+
+def g14_window(g, tag):
+    """the window of fixture g14 (pools, poses, the reference's random stream positioned after the current frame's randperm):
+    (c2ws [b,4,4], depths [b,P], colors [b,P,3], dirs [b,P,3], n_per, extra, frames) -- shared with the GPU test"""
+    H, W, fx, fy, cx, cy = g["intr"]; H, W = int(H), int(W)
+    frames = [int(f) for f in g[f"{tag}_frames"]]
+    kc, kd_, kcol, kdir = T(g[f"{tag}_kf_c2w"]), T(g[f"{tag}_kf_depth"]), T(g[f"{tag}_kf_color"]), T(g[f"{tag}_kf_dirs"])
+    cam = O.get_camera_rays(H, W, fx, fy, cx, cy)
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    ind = torch.randperm(H * W)[:int(H * W * 0.1)]                 # Mapper.py:333-335: the current frame's pool
+    cur_d, cur_c = T(g[f"{tag}_cur_depth"]).reshape(-1)[ind], T(g[f"{tag}_cur_color"]).reshape(-1, 3)[ind]
+    depths = torch.cat([kd_[frames], cur_d[None]]); colors = torch.cat([kcol[frames], cur_c[None]])
+    dirs = torch.cat([kdir[frames], cam.reshape(-1, 3)[ind][None]]); c2ws = torch.cat([kc[frames], T(g[f"{tag}_cur_c2w"])[None]])
+    b = len(frames) + 1
+    n_per = int(g[f"{tag}_pixels"]) // b                           # Mapper.py:315
+    extra = (10, 200) if int(g[f"{tag}_n_kf"]) > 20 else None     # Mapper.py:385-393
+    return c2ws, depths, colors, dirs, n_per, extra, frames
+
+
+@pytest.mark.parametrize("tag", ["w6", "w12x"])
+def test_g14_mapping_with_joint_pose_optimisation(golden, tag):
+    """oracle restatement of Mapper.optimize_mapping with joint_opt (poses as a fourth Adam group) against the reference's run"""
+    g = golden("g14_mapping_joint")
+    w = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+    for iters in (1, 2):
+        dec = _load_dec(g, "dec0__")
+        es, ec = _grid(g["grid_s0"]), _grid(g["grid_c0"])
+        c2ws, depths, colors, dirs, n_per, extra, frames = g14_window(g, tag)      # (re-seeds the random stream)
+        b, P = depths.shape
+        poses = torch.nn.Parameter(O.matrix_to_cam_pose(c2ws[1:]))
+        opt = torch.optim.Adam([{"params": list(dec.parameters()), "lr": 0.001}, {"params": [es.params], "lr": 0.05},
+                                {"params": [ec.params], "lr": 0.05}, {"params": [poses], "lr": float(g["cam_lr"])}])
+        for _ in range(iters):
+            idx = torch.randint(P, (n_per * b,)).reshape(b, -1)
+            idx2 = torch.randint(P, (extra[1] * extra[0],)).reshape(extra[0], -1) if extra else None
+            ro, rd, gd, gc = O.window_rays(c2ws[0], poses, depths, colors, dirs, idx, extra, idx2)
+            O.mapping_iteration(([es], [ec]), dec, opt, ro, rd, gd, gc, BOUND, 0.06, 32, 8, w, "original", True)
+        pre = f"{tag}_i{iters}_"
+        close(poses, g[pre + "poses"], 1e-5, 1e-6)
+        if iters == 1:
+            gp = g[pre + "g_poses"]
+            close(poses.grad, gp, 1e-3, 1e-4 * float(np.abs(gp).max())); close(dec.beta.grad, g[pre + "g_beta"], 1e-3, 1e-5)
+            if tag == "w6":
+                close(es.params.grad, g[pre + "g_grid_s"], 1e-4, 1e-6); close(ec.params.grad, g[pre + "g_grid_c"], 1e-4, 1e-6)
+        else:
+            close(es.params, g[pre + "grid_s"], 1e-4, 1e-6); close(ec.params, g[pre + "grid_c"], 1e-4, 1e-6)
+            for n, v in dec.state_dict().items():
+                close(v, g[pre + "dec__" + n.replace(".", "__")], 1e-4, 1e-6)
+            c2 = torch.cat([c2ws[0:1], O.cam_pose_to_matrix(poses.detach())])
+            close(c2[-1], g[pre + "cur_c2w"], 1e-5, 1e-6)
+            close(c2[:-1], g[pre + "kf_c2w"][frames], 1e-5, 1e-6)

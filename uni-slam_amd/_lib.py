@@ -24,6 +24,8 @@ US_MLP_LEVEL_MAJOR = 1
 US_MLP_DEFER_REDUCE = 2
 US_LOSS_DEFER_BETA = 256
 US_ADAM_STEP_ADVANCED = 0x80000000
+US_POSE_GRAD_ONLY = 1
+US_POSE_OWN_STEP = 2
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -120,6 +122,11 @@ SIGNATURES = {
     "us_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_pose_rays": (c_int, [c_f, c_f, c_i64, _HF, c_int, c_int, c_int, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_pose_grad": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f]),
+    "us_hashgrid_bwd_input_rays_supported": (c_int, [_GP, _GP, c_int]),
+    "us_hashgrid_bwd_input_rays": (c_int, [_GP, _GP, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, _HF, c_f, c_f, c_f, c_int, c_f]),
+    "us_window_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_pose_window_step": (c_int, [c_f, c_int, c_f, c_f, c_f, c_i64, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl,
+                                    c_dbl, c_f, c_int, c_f]),
 }
 
 _lib = None

@@ -103,7 +103,11 @@ def get_samples_all(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws, depths, color
     if not depths.is_cuda:
         raise L.UniSlamHipError("get_samples_all: the pixel pools must be on the GPU (unislam_amd has no CPU path)")
     if c2ws.requires_grad:
-        # joint pose optimisation (Mapper.py:372-376): keep the rotation in the autograd graph (torch ops on the GPU)
+        # joint pose optimisation (Mapper.py:372-376) through autograd: keep the rotation in the graph (torch ops on the GPU).
+        # (window.MapWindow is the kernel path for this case: poses on the device, no autograd)
+        if out is not None:
+            raise L.UniSlamHipError("get_samples_all: `out` cannot be combined with c2ws.requires_grad (the autograd branch returns "
+                                    "fresh tensors; a captured iteration would replay on stale rays)")
         sd = torch.gather(depths, 1, indices)
         sc = torch.gather(colors, 1, indices.unsqueeze(-1).expand(-1, -1, 3))
         gi = indices.unsqueeze(-1).expand(-1, -1, 3)

@@ -393,6 +393,64 @@ __global__ __launch_bounds__(256) void k_bwd_input_gather(LevelTable tab, uint32
     }
 }
 
+// Both grids' input gradient AND its reduction to the ray in one launch: dL/d(rays_o), dL/d(rays_d) are what the camera poses receive
+// (src/Tracker.py:170-174,241; joint pose optimisation src/Mapper.py:372-376,444), the per-point dL/dx is only a stop on the way.
+// A workgroup = one ray; wave w = its samples 16w .. 16w+15 x 4 level rows as in k_bwd_input_gather, first through table A's levels,
+// then through table B's (dL/dx = share_A + share_B, each share summed over its rows as the one-grid kernel does: the optional
+// per-point output is bit-identical to two us_hashgrid_bwd_input_gather launches).  Then the adjoint of us_ray_points on the values
+// the lanes hold: g = dL/dx / span, dL/do = sum_s g, dL/dd = sum_s g z_s -- wave sums, then the waves in order through LDS.
+#define IR_MAX_WAVES 8
+struct RaySpan { float span[3]; };
+__global__ __launch_bounds__(64 * IR_MAX_WAVES) void k_bwd_input_rays(LevelTable tabA, LevelTable tabB, uint32_t n_levels,
+                                                                      const float* __restrict__ pA, const float* __restrict__ pB,
+                                                                      const float* __restrict__ x, const float* __restrict__ dyA,
+                                                                      const float* __restrict__ dyB, int64_t n, int S,
+                                                                      const float* __restrict__ z_vals, RaySpan bd, float* __restrict__ g_o,
+                                                                      float* __restrict__ g_d, float* __restrict__ dL_dx, int clamp, int lm) {
+    __shared__ float sh[IR_MAX_WAVES][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, pt = lane & 15;
+    const int64_t ray = blockIdx.x;
+    const int s = wave * IG_POINTS + pt;
+    const bool in = s < S;
+    const int64_t i = ray * S + s;
+    float xv[3] = {0.f, 0.f, 0.f}, rA[3] = {0.f, 0.f, 0.f}, rB[3] = {0.f, 0.f, 0.f};
+    bool pass[3] = {true, true, true};
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float xin = x[i * 3 + k];
+            xv[k] = clamp ? fminf(fmaxf(xin, 0.0f), 1.0f) : xin;
+            pass[k] = !clamp || (xin >= 0.0f && xin <= 1.0f);
+        }
+        for (uint32_t level = (uint32_t)row; level < n_levels; level += 4)
+            input_grad_level<2>(tabA, level, n_levels, pA, xv, pass, dyA, i, n, lm, rA);
+        for (uint32_t level = (uint32_t)row; level < n_levels; level += 4)
+            input_grad_level<2>(tabB, level, n_levels, pB, xv, pass, dyB, i, n, lm, rB);
+    }
+    float so[3], sd[3];
+    const float z = (in && row == 0) ? z_vals[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rA[k] += __shfl_xor(rA[k], 16, 64); rA[k] += __shfl_xor(rA[k], 32, 64);
+        rB[k] += __shfl_xor(rB[k], 16, 64); rB[k] += __shfl_xor(rB[k], 32, 64);
+        const float r = rA[k] + rB[k];
+        if (dL_dx && row == 0 && in) dL_dx[i * 3 + k] = r;
+        const float gk = (row == 0 && in) ? r / bd.span[k] : 0.0f;
+        so[k] = wave_sum(gk); sd[k] = wave_sum(gk * z);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = so[k]; sh[wave][3 + k] = sd[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float a = 0.0f;
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) a += sh[w][threadIdx.x];
+        (threadIdx.x < 3 ? g_o : g_d)[ray * 3 + (threadIdx.x % 3)] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
@@ -525,5 +583,34 @@ extern "C" int us_hashgrid_bwd_input_gather(const us_grid_desc* d, const float* 
     switch (d->n_features) { case 1: LAUNCH_BIG(1) break; case 2: LAUNCH_BIG(2) break; default: LAUNCH_BIG(4) break; }
 #undef LAUNCH_BIG
     US_CHECK_LAUNCH("us_hashgrid_bwd_input_gather");
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_bwd_input_rays_supported(const us_grid_desc* a, const us_grid_desc* b, int n_samples) {
+    if (!a || !b) return 0;
+    if (a->n_features != 2 || b->n_features != 2 || a->n_levels != b->n_levels) return 0;
+    if (a->n_levels < 1 || a->n_levels > US_MAX_LEVELS) return 0;
+    return (n_samples >= 1 && n_samples <= IR_MAX_WAVES * IG_POINTS) ? 1 : 0;
+}
+
+extern "C" int us_hashgrid_bwd_input_rays(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
+                                          const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n_rays, int n_samples,
+                                          const float* z_vals, const float* bound_host, float* dL_do, float* dL_dd, float* dL_dx, int flags,
+                                          void* stream) {
+    int rc = check_desc("us_hashgrid_bwd_input_rays", a); if (rc) return rc;
+    rc = check_desc("us_hashgrid_bwd_input_rays", b); if (rc) return rc;
+    US_REQUIRE(us_hashgrid_bwd_input_rays_supported(a, b, n_samples), US_ERR_CONFIG,
+               "us_hashgrid_bwd_input_rays: needs two F = 2 grids of equal depth and 1..%d samples per ray (got F %u / %u, L %u / %u, S %d)",
+               IR_MAX_WAVES * IG_POINTS, a->n_features, b->n_features, a->n_levels, b->n_levels, n_samples);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(paramsA && paramsB && x && dL_dyA && dL_dyB && z_vals && bound_host && dL_do && dL_dd, US_ERR_NULL, "us_hashgrid_bwd_input_rays: NULL pointer");
+    US_REQUIRE((((uintptr_t)paramsA | (uintptr_t)paramsB) & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_bwd_input_rays: params must be 16-byte aligned");
+    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
+    RaySpan bd;
+    for (int k = 0; k < 3; ++k) bd.span[k] = bound_host[3 + k] - bound_host[k];
+    const int waves = (n_samples + IG_POINTS - 1) / IG_POINTS;
+    hipLaunchKernelGGL(k_bwd_input_rays, dim3((unsigned)n_rays), dim3(64 * waves), 0, (hipStream_t)stream, make_table(a), make_table(b),
+                       a->n_levels, paramsA, paramsB, x, dL_dyA, dL_dyB, n_rays * n_samples, n_samples, z_vals, bd, dL_do, dL_dd, dL_dx, clamp, lm);
+    US_CHECK_LAUNCH("us_hashgrid_bwd_input_rays");
     return US_OK;
 }

@@ -1,0 +1,186 @@
+// window.hip -- the camera poses of a mapping window (and of the tracked frame) on the device, for gfx950.
+//
+// With joint_opt (the reference's default, configs/UNISLAM.yaml:50, on from the fifth keyframe: src/Mapper.py:519) every mapping
+// iteration runs poses -> rotation -> rays (src/Mapper.py:372-376 -> src/common.py:152-166,196-208), and after the backward pass the
+// gradient flows rays -> rotation -> quaternion / translation into one more Adam param group (src/Mapper.py:359-364,443-445).  The
+// reference leaves both directions to autograd over ~20 small torch ops per iteration; here they are two launches:
+//   k_window_rays        pixel gather + quaternion -> rotation + rotate, per ray (the oldest frame keeps its given matrix:
+//                        "we fix the oldest c2w to avoid drifting", src/Mapper.py:374)
+//   k_pose_window_step   one workgroup per optimised frame: G = sum_rays g_d (x) dir, g_t = sum_rays g_o over the frame's rays
+//                        (fixed order, f64), the closed-form chain rule through R(q) = I + 2 M(q) / |q|^2, and Adam on the 7 numbers
+// The tracker's single frame (src/Tracker.py:170-174,240-242) is the same step with one workgroup and its own step count.
+// Compiled with -ffp-contract=off like render.hip: the ray arithmetic repeats the reference's separate fp32 ops.
+#include "us_common.h"
+#include <math.h>
+
+__device__ __forceinline__ void w_quat_rot(const float* __restrict__ q, float R[9]) {          // pytorch3d quaternion_to_matrix (real part first)
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1.f - s * (j * j + k * k); R[1] = s * (i * j - k * r); R[2] = s * (i * k + j * r);
+    R[3] = s * (i * j + k * r); R[4] = 1.f - s * (i * i + k * k); R[5] = s * (j * k - i * r);
+    R[6] = s * (i * k - j * r); R[7] = s * (j * k + i * r); R[8] = 1.f - s * (i * i + j * j);
+}
+
+// rays of `f_count` frames starting at window frame `f_begin`, n_per pixels each: idx[f_count][n_per] into the frames' pools
+__global__ __launch_bounds__(256) void k_window_rays(const float* __restrict__ c2w_first, const float* __restrict__ poses7,
+                                                     const float* __restrict__ pool_depth, const float* __restrict__ pool_color,
+                                                     const float* __restrict__ pool_dirs, const int64_t* __restrict__ idx, int64_t P,
+                                                     int f_begin, int64_t n_per, int64_t total, float* __restrict__ rays_o,
+                                                     float* __restrict__ rays_d, float* __restrict__ depth, float* __restrict__ color,
+                                                     float* __restrict__ dirs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = f_begin + i / n_per;
+        const int64_t src = f * P + idx[i];
+        float R[9], t[3];
+        if (f == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { R[k * 3] = c2w_first[k * 4]; R[k * 3 + 1] = c2w_first[k * 4 + 1]; R[k * 3 + 2] = c2w_first[k * 4 + 2]; t[k] = c2w_first[k * 4 + 3]; }
+        } else {
+            const float* q = poses7 + (f - 1) * 7;
+            w_quat_rot(q, R);
+            t[0] = q[4]; t[1] = q[5]; t[2] = q[6];
+        }
+        const float d0 = pool_dirs[src * 3 + 0], d1 = pool_dirs[src * 3 + 1], d2 = pool_dirs[src * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rays_d[i * 3 + k] = (d0 * R[k * 3 + 0] + d1 * R[k * 3 + 1]) + d2 * R[k * 3 + 2];
+            rays_o[i * 3 + k] = t[k];
+            color[i * 3 + k] = pool_color[src * 3 + k];
+        }
+        if (dirs) { dirs[i * 3] = d0; dirs[i * 3 + 1] = d1; dirs[i * 3 + 2] = d2; }
+        depth[i] = pool_depth[src];
+    }
+}
+
+struct PoseStep {
+    int64_t nA;                 // rows [j * nA, (j + 1) * nA) belong to optimised pose j ... shifted by first_row_A
+    int64_t rowA;               // first row of pose 0's block in segment A
+    int64_t nB, rowB;           // second segment (the extra rays of the newest frames, src/Mapper.py:385-393); nB == 0: none
+    int     jB;                 // first pose that owns rows in segment B
+    float   lr_q, lr_t, b1, b2, eps;
+    int     own_step;           // 1: step_dev is float[1], advanced here, fp32 bias corrections (the tracker's Adam, one workgroup)
+                                // 0: step_dev is the float[8] of us_adam_step_inc, already advanced for this step
+    int     apply;              // 0: gradient only
+};
+
+__global__ __launch_bounds__(256) void k_pose_window_step(float* __restrict__ poses7, const float* __restrict__ g_o, const float* __restrict__ g_d,
+                                                          const float* __restrict__ dirs, float* __restrict__ m7, float* __restrict__ v7,
+                                                          float* __restrict__ g7_out, float* __restrict__ step_dev, PoseStep ps) {
+    __shared__ double sh[12][4];
+    __shared__ float g7[7];
+    const int j = blockIdx.x;
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    for (int seg = 0; seg < 2; ++seg) {
+        int64_t n, r0;
+        if (seg == 0) { n = ps.nA; r0 = ps.rowA + (int64_t)j * ps.nA; }
+        else { if (ps.nB == 0 || j < ps.jB) break; n = ps.nB; r0 = ps.rowB + (int64_t)(j - ps.jB) * ps.nB; }
+        for (int64_t t = threadIdx.x; t < n; t += 256) {
+            const int64_t r = r0 + t;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float ga = g_d[r * 3 + a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a * 3 + b] += (double)(ga * dirs[r * 3 + b]);
+                acc[9 + a] += (double)g_o[r * 3 + a];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[k][wave] = v;
+    }
+    __syncthreads();
+    float* pose = poses7 + (int64_t)j * 7;
+    if (threadIdx.x == 0) {
+        float G[9], gt[3];
+        for (int k = 0; k < 12; ++k) { const double v = ((sh[k][0] + sh[k][1]) + sh[k][2]) + sh[k][3]; if (k < 9) G[k] = (float)v; else gt[k - 9] = (float)v; }
+        const float r = pose[0], i = pose[1], jj = pose[2], k = pose[3];
+        const float s = 2.0f / (r * r + i * i + jj * jj + k * k);
+        const float M[9] = {-(jj * jj + k * k), i * jj - k * r, i * k + jj * r, i * jj + k * r, -(i * i + k * k), jj * k - i * r,
+                            i * k - jj * r, jj * k + i * r, -(i * i + jj * jj)};
+        const float dMr[9] = {0, -k, jj, k, 0, -i, -jj, i, 0};
+        const float dMi[9] = {0, jj, k, jj, -2 * i, -r, k, r, -2 * i};
+        const float dMj[9] = {-2 * jj, i, r, i, 0, k, -r, k, -2 * jj};
+        const float dMk[9] = {-2 * k, -r, i, r, -2 * k, jj, i, jj, 0};
+        float gm = 0, gr = 0, gi = 0, gj = 0, gk = 0;
+        for (int e = 0; e < 9; ++e) { gm += G[e] * M[e]; gr += G[e] * dMr[e]; gi += G[e] * dMi[e]; gj += G[e] * dMj[e]; gk += G[e] * dMk[e]; }
+        const float ds = -s * s;                                   // d s / d q_m = -s^2 q_m
+        g7[0] = ds * r * gm + s * gr; g7[1] = ds * i * gm + s * gi;
+        g7[2] = ds * jj * gm + s * gj; g7[3] = ds * k * gm + s * gk;
+        g7[4] = gt[0]; g7[5] = gt[1]; g7[6] = gt[2];
+    }
+    float step = 0.0f;
+    if (ps.apply && ps.own_step) step = step_dev[0] + 1.0f;       // read by every thread before thread 0 stores the new count
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (e < 7) {
+        const float gi = g7[e];
+        if (g7_out) g7_out[(int64_t)j * 7 + e] = gi;
+        if (ps.apply) {
+            float step_size, bc2s;
+            const float lr = e < 4 ? ps.lr_q : ps.lr_t;
+            if (ps.own_step) {                                     // torch.optim.Adam(capturable) arithmetic, as us_pose_adam_step
+                const float bc1 = 1.0f - powf(ps.b1, step);
+                bc2s = sqrtf(1.0f - powf(ps.b2, step));
+                step_size = lr / bc1;
+            } else {                                               // the corrections us_adam_step_inc left, as k_adam_segs reads them
+                const double* aux = reinterpret_cast<const double*>(step_dev + 2);
+                step_size = (float)((double)lr / aux[0]);
+                bc2s = (float)aux[1];
+            }
+            float* m = m7 + (int64_t)j * 7; float* v = v7 + (int64_t)j * 7;
+            const float m0 = m[e], v0 = v[e];
+            const float mi = m0 + (1.0f - ps.b1) * (gi - m0);
+            const float vi = v0 * ps.b2 + ((1.0f - ps.b2) * gi) * gi;
+            const float denom = sqrtf(vi) / bc2s + ps.eps;
+            pose[e] = pose[e] + (-step_size) * (mi / denom);
+            m[e] = mi; v[e] = vi;
+        }
+    }
+    if (ps.apply && ps.own_step && threadIdx.x == 0) step_dev[0] = step;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int us_window_rays(const float* c2w_first, const float* poses7, const float* pool_depth, const float* pool_color,
+                              const float* pool_dirs, const int64_t* idx, int64_t pool_size, int f_begin, int f_count, int64_t n_per_frame,
+                              float* rays_o, float* rays_d, float* depth, float* color, float* dirs, void* stream) {
+    US_REQUIRE(pool_depth && pool_color && pool_dirs && idx && rays_o && rays_d && depth && color, US_ERR_NULL, "us_window_rays: NULL pointer");
+    US_REQUIRE(f_begin >= 0 && f_count >= 1 && pool_size >= 1 && n_per_frame >= 0, US_ERR_SHAPE, "us_window_rays: bad shape");
+    US_REQUIRE(f_begin > 0 || c2w_first, US_ERR_NULL, "us_window_rays: frame 0 needs its matrix");
+    US_REQUIRE(f_begin + f_count <= 1 || poses7, US_ERR_NULL, "us_window_rays: frames 1.. need poses7");
+    const int64_t total = (int64_t)f_count * n_per_frame;
+    if (total == 0) return US_OK;
+    int64_t blocks = us_cdiv(total, 256); if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_window_rays, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c2w_first, poses7, pool_depth, pool_color,
+                       pool_dirs, idx, pool_size, f_begin, n_per_frame, total, rays_o, rays_d, depth, color, dirs);
+    US_CHECK_LAUNCH("us_window_rays");
+    return US_OK;
+}
+
+extern "C" int us_pose_window_step(float* poses7, int n_poses, const float* g_rays_o, const float* g_rays_d, const float* dirs,
+                                   int64_t row_a, int64_t n_a, int first_pose_b, int64_t row_b, int64_t n_b, float* m7, float* v7,
+                                   float* g7_out, double lr_q, double lr_t, double beta1, double beta2, double eps, float* step_dev,
+                                   int flags, void* stream) {
+    US_REQUIRE(poses7 && g_rays_o && g_rays_d && dirs, US_ERR_NULL, "us_pose_window_step: NULL pointer");
+    US_REQUIRE(n_poses >= 1 && n_a >= 0 && n_b >= 0 && row_a >= 0 && row_b >= 0 && first_pose_b >= 0, US_ERR_SHAPE, "us_pose_window_step: bad shape");
+    const int apply = (flags & US_POSE_GRAD_ONLY) ? 0 : 1, own = (flags & US_POSE_OWN_STEP) ? 1 : 0;
+    US_REQUIRE(!apply || (m7 && v7 && step_dev), US_ERR_NULL, "us_pose_window_step: the optimiser step needs m7, v7 and step_dev");
+    US_REQUIRE(!apply || own || ((uintptr_t)step_dev & 7u) == 0, US_ERR_SHAPE, "us_pose_window_step: step_dev (float[8]) must be 8-byte aligned");
+    US_REQUIRE(!(apply && own) || n_poses == 1, US_ERR_CONFIG, "us_pose_window_step: US_POSE_OWN_STEP advances the count in the launch: one pose only");
+    US_REQUIRE(apply || g7_out, US_ERR_NULL, "us_pose_window_step: US_POSE_GRAD_ONLY needs g7_out");
+    PoseStep ps;
+    ps.nA = n_a; ps.rowA = row_a; ps.nB = n_b; ps.rowB = row_b; ps.jB = first_pose_b;
+    ps.lr_q = (float)lr_q; ps.lr_t = (float)lr_t; ps.b1 = (float)beta1; ps.b2 = (float)beta2; ps.eps = (float)eps;
+    ps.own_step = own; ps.apply = apply;
+    hipLaunchKernelGGL(k_pose_window_step, dim3((unsigned)n_poses), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
+                       g7_out, step_dev, ps);
+    US_CHECK_LAUNCH("us_pose_window_step");
+    return US_OK;
+}

@@ -11,10 +11,10 @@ lr factor / iterations, joint optimisation of the window's camera poses (oldest 
 Left out: visualiser, logger/checkpoints, mesher (SURVEY.md 8 "out of scope").
 """
 import torch
-import torch.nn as nn
 
-from .common import (cam_pose_to_matrix, get_samples, get_samples_all, matrix_to_cam_pose)
+from .common import cam_pose_to_matrix, get_samples, matrix_to_cam_pose
 from .step import MapStep, TrackStep
+from .window import MapWindow
 
 DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
     "tracking": dict(ignore_edge_W=75, ignore_edge_H=75, const_speed_assumption=True, lr_T=0.002, lr_R=0.001, pixels=2000, iters=8,
@@ -130,29 +130,17 @@ class Mapper:
         depths, colors, c2ws, dirs = torch.stack(depths), torch.stack(colors), torch.stack(c2ws), torch.stack(dirs)
         joint = self.joint_opt and c2ws.shape[0] > 1
         self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
-        if joint:
-            cam_poses = nn.Parameter(matrix_to_cam_pose(c2ws[1:]))                      # the oldest pose stays fixed
-            pose_opt = torch.optim.Adam([cam_poses], lr=c["joint_opt_cam_lr"])
-        has_zero = bool((depths <= 0).any())                                            # once per mapped frame, on the pools
+        # the loop of :366-445 with the window's poses on the device: pose -> rays, render, loss, backward, pose step and Adam are HIP
+        # launches on static buffers (window.MapWindow); the pools are looked at once for pixels without a depth
+        extra = (10, 200) if (not s.tracking_back and len(kl) > 20) else None           # extra rays from the newest frames (:381-390)
+        win = MapWindow(self.step, c2ws, depths, colors, dirs, pixs_per_image, joint_opt=joint, cam_lr=c["joint_opt_cam_lr"], extra=extra)
+        replay = bool(c.get("graph_replay", False)) and not win.has_zero and int(iters) >= 4
+        if replay:
+            win.capture()
         for _ in range(int(iters)):
-            c2ws_ = torch.cat([c2ws[0:1], cam_pose_to_matrix(cam_poses)], dim=0) if joint else c2ws
-            ro, rd, gd, gc = get_samples_all(0, H, 0, W, pixs_per_image, H, W, fx, fy, cx, cy, c2ws_, depths, colors, dev, dirs)
-            if not s.tracking_back and len(kl) > 20:                                    # extra rays from the newest frames (:381-390)
-                ro2, rd2, gd2, gc2 = get_samples_all(0, H, 0, W, 200, H, W, fx, fy, cx, cy, c2ws_[-10:], depths[-10:], colors[-10:], dev,
-                                                     dirs[-10:])
-                ro, rd, gd, gc = torch.cat([ro, ro2]), torch.cat([rd, rd2]), torch.cat([gd, gd2]), torch.cat([gc, gc2])
-            if joint:
-                self.step.forward(ro, rd, gd, gc, has_zero_depth=has_zero)
-                self.step.backward(ray_grads=True)
-                g_o, g_d = self.step.ray_gradients()
-                pose_opt.zero_grad()
-                torch.autograd.backward([ro, rd], [g_o, g_d])                           # rays -> c2ws -> quaternion / translation
-                self.step.adam_step()
-                pose_opt.step()
-            else:
-                self.step.iterate(ro, rd, gd, gc, has_zero_depth=has_zero)
+            win.replay() if replay else win.iterate()
         if joint:
-            opt_c2ws = cam_pose_to_matrix(cam_poses.detach())
+            opt_c2ws = win.c2ws()[1:]                                                   # put the updated camera poses back (:447-457)
             k = 0
             for f in optimize_frame[1:]:
                 if f != -1:

@@ -1,916 +1,7 @@
 """
-MapStep -- the body of the reference's mapping hot loop (src/Mapper.py:366-445: sample -> render -> masked loss ->
-backward -> Adam) as ONE straight-line sequence of HIP kernel launches on preallocated buffers: no autograd graph,
-no boolean-mask compaction, no host synchronisation.  Results are the same as driving Renderer / Decoders / losses
-through autograd (tests/test_gpu_step.py holds the two paths against each other and against the oracle).
-
-Parameter storage.  All trainable parameters live in ONE flat fp32 buffer
-
-    [ sdf decoder | colour decoder | beta | pad ][ sdf hash table ][ colour hash table ]
-
-laid out so that each decoder segment is directly the flat vector the fused MLP kernel consumes (nn.Linear weights are
-re-pointed to views of it; the last matrix is zero-padded to 16 rows) and each table segment is the encoder's
-`params`.  The modules keep working (state_dict, deepcopy, Tracker reading the shared tables); gradients live in a
-second flat buffer of the same layout, which is what the single RCCL all-reduce per optimiser step moves
-(BASELINE.json north_star), and Adam runs over the three learning-rate groups of Mapper.create_optimizer
-(src/Mapper.py:111-139).
+Compatibility module: the autograd-free drivers of the hot loops live in mapstep.py (MapStep: src/Mapper.py:366-445),
+window.py (MapWindow: the same with the window's camera poses on the device, joint_opt) and trackstep.py (TrackStep:
+src/Tracker.py:149-244).
 """
-import ctypes
-
-import torch
-import torch.nn as nn
-
-from . import _lib as L
-from .common import bound_host
-from .decoders import Decoders
-from .hashgrid import HashGridEncoding
-from .network import make_mlp_desc, mlp_n_params
-from .dist import dp_iterate
-
-
-def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for 1, 2, 4, 8 ... ranks (dist: sharded Adam)
-    return (n + a - 1) // a * a
-
-
-
-class MapStep:
-    def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
-                 weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30, fuse_adam=False):
-        """
-        hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
-        weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
-        lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
-        group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
-        joint: encode both grids in one launch and form both table gradients in one binned pass (us_hashgrid_fwd_joint /
-                 us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes for a single process when the pair of
-                 grids qualifies; no with a process group, where the colour table's gradient is finished FIRST so that its all-reduce
-                 hides behind the sdf branch (a joint pass would finish both tables at the same moment, with nothing left to hide behind).
-                 Measured at 4096 x 64 (room0 tables): the iteration takes the same 0.66 ms either way -- the two one-grid chains overlap on
-                 two streams -- but the table gradient itself is 262 us for both grids against 157 + 147; render-only calls
-                 (backward_follows=False) run the joint encoder without counts and both decoders in one launch (render_joint).
-        overlap: use side streams -- one-grid kernels: the sdf branch (encode, decode and their backward) beside the colour branch; joint
-                 kernels: the binning's scans and the small reductions beside the main chain (the decoders stay on the main stream:
-                 decoders_side_by_side); default: yes for a single process; no with a process group, where the branches run one after
-                 the other so that the all-reduce of the colour-table gradient hides behind the sdf branch.
-        """
-        assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
-        assert isinstance(decoders, Decoders)
-        self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
-        self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
-        # opt-in: render-only calls (forward(backward_follows=False)) as ONE launch (us_encode_decode_fwd: both grids, both decoders, the features
-        # kept in LDS) where the model qualifies.  Bit-identical, but measured slower than the four launches (0.20 against 0.18 ms at 4096 x 64:
-        # csrc/encode_decode.inc), so off.
-        self.fused_render = False
-        # The two decoders on two streams (joint path)?  Under graph replay a dependency ACROSS queues costs 10-14 us where kernels that
-        # follow each other on one queue start back to back, and the decoder kernels fill the chip on their own: 0.614 -> 0.59 ms at
-        # 4096 x 64 with the decoders one after the other on the main stream (the scans and the small reductions keep their side streams).
-        self.decoders_side_by_side = False
-        self.render_joint = True
-        self.decoder_pair = True        # ... and, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
-        self._dec_grad_clean = False
-        self._step_advanced = False
-        # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
-        # entries it has just summed (us_hashgrid_bwd_joint_adam); adam_step() then covers the decoders only.  Measured at 4096 x 64: the
-        # accumulate pass grows from 106 to 203 us -- a bin's entries are 128-byte lines 32 KB apart, and six arrays of such lines do not
-        # stream like the dense pass's contiguous 6 TB/s -- against the 60 us the separate pass costs: 0.690 instead of 0.612 ms.  Off.
-        self.fuse_adam = bool(fuse_adam)
-        self._joint_wanted = (group is None) if joint is None else bool(joint)
-        # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
-        # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
-        self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
-        # budget of the table gradient's scratch (it is sized for the worst case, 8 records per point and level: 3 KB per point for
-        # both grids).  A batch that would need more is walked in ranges of rays (us_hashgrid_bwd_*_range), the first range writing
-        # the gradient tables, the others adding: 4096 x 64 needs 0.8 GB, the 32 768-ray sweep point 6.6 GB -> two ranges.
-        self.max_ws = int(max_workspace_bytes)
-        self.count_in_forward, self._counted = True, False
-        # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
-        # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
-        self.scan_in_forward, self._scanned = False, False
-        self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
-        self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
-        if self.sharded_adam and grad_comm in ("bf16", torch.bfloat16):
-            raise L.UniSlamHipError("MapStep: grad_comm='bf16' and sharded_adam=True are exclusive (the reduce-scatter runs in place on "
-                                    "the fp32 gradient buffer); choose one")
-        # 8-byte intermediate records in the binned table gradient (US_GRID_BWD_PACKED; F = 2 grids only)
-        self._packed = L.US_GRID_BWD_PACKED if (packed_records and hash_grid_sdf.desc.n_features == 2 and hash_grid_color.desc.n_features == 2) else 0
-        self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
-        self.zd_rows = None                                                                # scratch of the zero-depth branch, on first use
-        dev = hash_grid_sdf.params.device
-        if dev.type != "cuda":
-            raise L.UniSlamHipError("MapStep needs the model on the GPU")
-        self.device = dev
-        self.S = n_stratified + n_importance
-        self.n_strat, self.n_imp = n_stratified, n_importance
-        self.truncation = float(truncation)
-        self.w5 = L.host_floats([weights["fs"], weights["center"], weights["tail"], weights["color"], weights["depth"]])
-        self.mode = {"original": 0, "no_mask": 1}[mask_mode]
-        self.perturb = perturb
-        self.group = group
-        self.bwd_mode = bwd_mode
-        self.bound = bound.to(dev)
-        self.bhost = bound_host(bound)
-        self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
-        self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
-        self.lr = dict(lr)
-        self.probe = None               # dict name -> [(start_event, end_event)]: per-kernel HIP-event timing (bench.py)
-        self.probe_every = 1            # with self.probe set: every k-th iteration is a probing one (events around the
-        self._it, self._probing = 0, False   # launches, both branches on ONE stream so that durations are the kernels' own)
-        self._adopt_parameters()
-        self._alloc(max_rays)
-        self.reset_optimizer(1.0)
-
-    # ------------------------------------------------------------------------------------------ parameters
-    def _adopt_parameters(self):
-        dec, dev = self.dec, self.device
-        self.desc_s, self.desc_c = dec.mlp_descs()
-        n_s, n_c = mlp_n_params(self.desc_s), mlp_n_params(self.desc_c)
-        self.has_beta = isinstance(dec.beta, nn.Parameter)
-        self.o_dec_s, self.o_dec_c, self.o_beta = 0, n_s, n_s + n_c
-        self.n_dec = _align(n_s + n_c + 1)
-        self.o_tab_s = self.n_dec
-        self.o_tab_c = self.o_tab_s + _align(self.es.desc.n_params)
-        self.n_flat = self.o_tab_c + _align(self.ec.desc.n_params)
-        flat = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
-        grad = torch.zeros_like(flat)
-
-        def adopt(p, off, shape=None):
-            n = p.numel()
-            view = flat[off:off + n].view(p.shape if shape is None else shape)
-            view.copy_(p.detach())
-            p.data = view
-            p.grad = grad[off:off + n].view(view.shape)
-
-        if dec.tcnn_network:
-            adopt(dec.sdf_decoder.params, self.o_dec_s)
-            adopt(dec.color_decoder.params, self.o_dec_c)
-        else:
-            for base, hidden, out in ((self.o_dec_s, dec.linears, dec.output_linear),
-                                      (self.o_dec_c, dec.c_linears, dec.c_output_linear)):
-                o = base
-                for l in hidden:
-                    adopt(l.weight, o); o += l.weight.numel()
-                adopt(out.weight, o); o += 16 * out.weight.shape[1]          # rows n_out..15 stay zero (padding)
-                for l in hidden:
-                    adopt(l.bias, o); o += l.bias.numel()
-                adopt(out.bias, o); o += 16
-        if self.has_beta:
-            adopt(dec.beta, self.o_beta)
-        else:
-            flat[self.o_beta] = float(dec.beta)
-        adopt(self.es.params, self.o_tab_s)
-        adopt(self.ec.params, self.o_tab_c)
-        self.flat, self.grad = flat, grad
-        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
-        self.step_dev = torch.zeros(8, dtype=torch.float32, device=flat.device)    # Adam's step count, kept on the device (graph replay)
-        self._graph = None
-
-    def reset_optimizer(self, lr_factor=1.0):
-        """Mapper.py:358-364: a fresh Adam for every mapped frame (moments and step count restart)."""
-        self.m.zero_(); self.v.zero_()
-        self.opt_step = 0
-        self.step_dev.zero_()
-        self._step_advanced = False
-        self.lr_factor = float(lr_factor)
-        self._graph = None              # a captured iteration holds the old learning rates
-
-    # ------------------------------------------------------------------------------------------ buffers
-    def _alloc(self, R):
-        dev, S = self.device, self.S
-        N = R * S
-        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        self.max_rays = R
-        self._graph = None              # a captured iteration holds the old buffers' addresses: capture() again after a reallocation
-        self.z, self.pts = f(R, S), f(R, S, 3)
-        self.feat_s, self.feat_c = f(N, 32), f(N, 32)
-        self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
-        self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32)
-        self.term, self.unc, self.depth, self.dunc, self.rgb = f(R), f(R), f(R), f(R), f(R, 3)
-        self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
-        self.partials = f(int(L.lib().us_loss_partials_size(R)))
-        self.stats, self.loss = f(10), f(1)
-        self.beta_part = f(R)
-        self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
-        lib = L.lib()
-        self.chunk_rays = 0                                # > 0: the table gradient walks the batch in ranges of this many rays
-        N_all = N
-        need = lambda n: max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), n)),
-                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), n)),
-                             int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), n)))
-        if self.bwd_mode in (-1, 3) and need(N) > self.max_ws and R > 16:
-            parts = 2
-            while need(-(-R // parts) * S) > self.max_ws and -(-R // parts) > 16:
-                parts += 1
-            self.chunk_rays = -(-R // parts)
-            N = self.chunk_rays * S                        # the scratch below is sized for one range
-        self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
-                            int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
-        if self.bwd_mode == -1 and not (lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.es.desc), N) and
-                                        lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.ec.desc), N)):
-            self.bwd_mode = 1               # a table / batch beyond the binned path's budget: LDS-sliced kernels
-        self.joint = bool(self._joint_wanted and self.bwd_mode in (-1, 3) and not self._packed and
-                          lib.us_hashgrid_joint_supported(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
-        if self.joint:                                     # one scratch set: counts of both grids, joint records
-            self.ws_bytes = int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
-            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
-            self.ws_s = self.ws
-        # one scratch set per branch (sdf / colour): the two branches run on two streams
-        mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
-        if not self.joint:
-            self.ws, self.ws_s = mk_ws(), mk_ws()          # the forward pass leaves each branch's binning counts in its own
-        self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
-                                int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
-        self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
-        self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)      # (one per decoder: they may run in one launch)
-        if self.ws_s is None:
-            self.ws_s = self.ws
-        N = N_all
-
-    def _decoder_pair(self):
-        """joint path: run the two decoders as ONE launch each way (us_mlp_fwd_pair / us_mlp_bwd_pair)?  Yes when they have one shape and a
-        bf16 precision and are not asked to run side by side on two streams."""
-        return bool(self.decoder_pair and not self.decoders_side_by_side and
-                    L.lib().us_mlp_pair_supported(ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)))
-
-    class _Branch:
-        """`with step._branch() as st2:` -- the launches inside go to the side stream (st2 = its handle), which first waits
-        for everything queued on the main stream; _join() makes the main stream wait for the side stream.  Without overlap
-        the block simply runs on the main stream."""
-        def __init__(self, step):
-            self.step = step
-
-        def __enter__(self):
-            s = self.step
-            self.on = s.overlap and not s._probing
-            if not self.on:
-                return L.stream()
-            if s.side is None:
-                s.side = torch.cuda.Stream(device=s.device)
-            s.side.wait_stream(torch.cuda.current_stream())
-            self.ctx = torch.cuda.stream(s.side)
-            self.ctx.__enter__()
-            return L.stream()
-
-        def __exit__(self, *a):
-            if self.on:
-                self.ctx.__exit__(*a)
-            return False
-
-    def _branch(self):
-        return MapStep._Branch(self)
-
-    def _join(self):
-        if self.overlap and not self._probing and self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
-
-    def _timed(self, name, rc_fn):
-        """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
-        if not self._probing:
-            L.check(rc_fn(), name)
-            return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        L.check(rc_fn(), name)
-        e1.record()
-        self.probe.setdefault(name, []).append((e0, e1))
-
-    # ------------------------------------------------------------------------------------------ the iteration
-    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None, backward_follows=True):
-        """
-        Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
-        has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
-        knows every ray carries a depth (e.g. checked once per mapped frame on the pixel pools); True -> run the
-        importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
-        zero_depth_draws: (t_rand_uni [n0, n_strat], u [n0, n_imp]) for that branch's rays in row order, to replay a given random stream
-        (tests); default: the in-kernel generator.
-        backward_follows: False for a render-only call (the encoders then skip the bookkeeping they do for the table gradient).
-        """
-        lib, st = L.lib(), L.stream()
-        self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
-        self._it += 1
-        o, d, gd, gc = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()), L.f32(gt_color.detach())
-        R, S = o.shape[0], self.S
-        if R > self.max_rays:
-            self._alloc(R)
-        N = R * S
-        P = L.ptr
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        # pre-filter against the scene box (Mapper.py:396-406) as a validity flag instead of a compaction
-        c_free, s_off, s_span = ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation)
-        # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
-        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-        self.rng_calls += 1
-        seed = lambda k: (self.rng_seed + 0x9E3779B97F4A7C15 * (3 * self.rng_calls + k)) & (2 ** 64 - 1)
-        L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
-                                     c_free, s_off, s_span, tr, seed(0), P(self.step_dev),
-                                     1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
-        fl = self.flat
-        if has_zero_depth is not False:
-            # Renderer.py:104-130 for the rays without a depth measurement, on their compacted rows: coarse uniform pass through the
-            # sdf grid + decoder, importance samples, and the rows of z / pts rewritten in place.  One host sync (the row count).
-            Su = self.n_strat
-            if self.zd_rows is None or self.zd_rows.numel() < R:
-                self.zd_rows = torch.empty(R, dtype=torch.int32, device=self.device)
-                self.zd_count = torch.empty(1, dtype=torch.int32, device=self.device)
-                self.zd_z = torch.empty(R * Su, dtype=torch.float32, device=self.device)
-                self.zd_sdf, self.zd_pts = torch.empty_like(self.zd_z), torch.empty(R * Su * 3, dtype=torch.float32, device=self.device)
-            L.check(lib.us_zero_depth_rows(P(gd), R, P(self.zd_rows), P(self.zd_count), st), "us_zero_depth_rows")
-            n0 = int(self.zd_count.item())
-            if n0:
-                tr0, u0 = zero_depth_draws if zero_depth_draws is not None else (None, None)
-                tr0 = L.f32(tr0) if (tr0 is not None and self.perturb) else None
-                u0 = L.f32(u0) if u0 is not None else None
-                assert tr0 is None or tr0.numel() == n0 * Su
-                assert u0 is None or u0.numel() == n0 * self.n_imp
-                feat = self.d_feat_s                        # free until the backward pass; n0*Su <= R*S rows
-                L.check(lib.us_uniform_points(P(o), P(d), P(self.zd_rows), n0, self.bhost, P(self.t_uni), Su, P(tr0) if tr0 is not None else None,
-                                              seed(1), 1 if self.perturb else 0, P(self.zd_z), P(self.zd_pts), st), "us_uniform_points")
-                L.check(lib.us_hashgrid_fwd(ctypes.byref(self.es.desc), off(fl, self.o_tab_s), P(self.zd_pts), n0 * Su, P(feat), None, 3, st),
-                        "us_hashgrid_fwd")
-                L.check(lib.us_mlp_fwd(ctypes.byref(self.desc_s), off(fl, self.o_dec_s), P(feat), n0 * Su, P(self.zd_sdf), 1, 1, st), "us_mlp_fwd")
-                L.check(lib.us_importance_z_rows(P(self.zd_sdf), P(self.zd_z), off(fl, self.o_beta), P(u0) if u0 is not None else None, seed(2),
-                                                 n0, Su, self.n_imp, P(self.zd_rows), P(self.z), P(o), P(d), self.bhost, P(self.pts), st),
-                        "us_importance_z_rows")
-        fl = self.flat
-        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
-        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        # the sdf and the colour branch are independent between the sample points and the compositing: two streams
-        # with the binned backward the encoder also leaves the binning counts of these points in the branch's workspace
-        # (us_hashgrid_fwd_counted: the gathers bound the kernel, the counting rides along), and the backward skips its count pass
-        if self.chunk_rays:
-            backward_follows = False                             # the counts of a forward pass belong to the whole batch, not to its ranges
-        counted = self.ws is not None and self.count_in_forward and backward_follows
-        self._counted = counted
-        # ... and, if asked for, the two scan passes of the binning, which depend on those counts only, follow the encoder at once (a
-        # probed step keeps them inside the timed gradient call)
-        scan = counted and self.scan_in_forward and not self._probing
-        self._scanned = scan
-        bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed | self._det
-        self._jcounted = False
-        if self.joint and backward_follows:
-            # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
-            # then the two decoders side by side
-            if self.scan_stream is not None:                     # a scan of the previous call may still read the workspace
-                torch.cuda.current_stream().wait_stream(self.scan_stream)
-            self._jcounted = True
-            self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                P(self.feat_s), P(self.feat_c), 3, P(self.ws) if self._jcounted else None,
-                                                                                self.ws_bytes if self._jcounted else 0, st))
-            # the binning's scan passes depend on the counts only: they run beside the decoders (own stream; the backward pass waits for
-            # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
-            scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                             3 | L.US_GRID_BWD_OVERWRITE | self._det, P(self.ws), self.ws_bytes, q)
-            if not self._jcounted:
-                pass
-            elif self._probing or not self.overlap:
-                self._timed("hashgrid_scan_joint", lambda: scan_call(st))
-            else:
-                if self.scan_stream is None:
-                    self.scan_stream = torch.cuda.Stream(device=self.device)
-                self.scan_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.scan_stream):
-                    L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
-                    if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
-                        L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
-                        self._step_advanced = True
-            if self._decoder_pair():                             # both decoders in one launch
-                self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1, st))
-                return self._finish_forward(o, d, gd, gc, R)
-            if self.decoders_side_by_side:
-                with self._branch() as st2:
-                    self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
-            else:
-                self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
-            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
-            if self.decoders_side_by_side:
-                self._join()
-            return self._finish_forward(o, d, gd, gc, R)
-        if not backward_follows and self.fused_render and lib.us_encode_decode_supported(ds, dc, ms, mc):
-            # a render-only call: both grids and both decoders in one launch, the features never leave the CU (csrc/encode_decode.inc)
-            self._timed("encode_decode", lambda: lib.us_encode_decode_fwd(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), ms, mc, off(fl, self.o_dec_s),
-                                                                          off(fl, self.o_dec_c), P(self.pts), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
-            return self._finish_forward(o, d, gd, gc, R)
-        if not backward_follows and self.render_joint and self.joint and self._decoder_pair():
-            # a render-only call on ONE stream: both encoders in one launch (no binning counts), both decoders in one launch
-            self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                P(self.feat_s), P(self.feat_c), 3, None, 0, st))
-            self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1, st))
-            return self._finish_forward(o, d, gd, gc, R)
-        with self._branch() as st2:
-            if counted:
-                self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd_counted(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), 3,
-                                                                                    P(self.ws_s), self.ws_bytes, st2))
-                if scan:
-                    L.check(lib.us_hashgrid_bwd_scan(ds, N, off(self.grad, self.o_tab_s), bflags, P(self.ws_s), self.ws_bytes, st2), "us_hashgrid_bwd_scan")
-            else:
-                self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
-            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
-        if counted:
-            self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd_counted(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), 3,
-                                                                                  P(self.ws), self.ws_bytes, st))
-            if scan:
-                L.check(lib.us_hashgrid_bwd_scan(dc, N, off(self.grad, self.o_tab_c), bflags, P(self.ws), self.ws_bytes, st), "us_hashgrid_bwd_scan")
-        else:
-            self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
-        self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
-        self._join()
-        return self._finish_forward(o, d, gd, gc, R)
-
-    def _finish_forward(self, o, d, gd, gc, R):
-        lib, st, P, S, fl = L.lib(), L.stream(), L.ptr, self.S, self.flat
-        beta = ctypes.c_void_p(fl.data_ptr() + 4 * self.o_beta)
-        # compositing + the loss's sums and counts in one launch (+ the fixed-order reduction)
-        L.check(lib.us_render_loss_fwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), self.truncation,
-                                       P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.stats), st),
-                "us_render_loss_fwd")
-        self._batch = (o, d, gd, gc, R)
-        self.n_rays = R
-        return self.stats
-
-    def backward(self, on_ready=None, ray_grads=False, fuse_adam=False):
-        """
-        Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
-        ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
-        src/Mapper.py:358-374 differentiates through; the positions' gradient re-gathers the tables (no stored dy/dx).
-        The colour branch runs first; on_ready(view) is called when the colour-table segment, and at the end the
-        [decoders | beta | sdf table] segment, of self.grad are final (dist.dp_iterate overlaps their all-reduces).
-        """
-        lib, st = L.lib(), L.stream()
-        o, d, gd, gc, R = self._batch
-        S, N = self.S, R * self.S
-        P = L.ptr
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        fl = self.flat
-        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
-        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        beta = off(fl, self.o_beta)
-        # The binned table backward writes every table entry (US_GRID_BWD_OVERWRITE); the decoder segment, which the MLP
-        # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
-        binned = self.ws is not None
-        # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
-        # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
-        defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing and self.group is None)
-        clear_later = False
-        if self.bwd_mode not in (-1, 3):
-            self.grad.zero_()
-        elif not self._dec_grad_clean:
-            if defer:
-                clear_later = True                               # ... and so is the clearing of the segment they add to (a 6 us fill)
-            else:
-                self.grad[:self.o_tab_s].zero_()
-        self._dec_grad_clean = False
-        gbeta = off(self.grad, self.o_beta) if self.has_beta else None
-        # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
-        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode | (L.US_LOSS_DEFER_BETA if (defer and gbeta is not None) else 0),
-                                       P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
-                                       P(self.unc), self.truncation, self.w5, P(self.stats), P(self.d_raw), gbeta, P(self.beta_part),
-                                       P(self.loss), st), "us_render_loss_bwd")
-
-        def sdf_branch(q):
-            self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                              off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
-                                                              P(self.mlp_ws_s), self.mlp_ws_bytes, q))
-            if binned:
-                self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws_s), self.ws_bytes, q))
-            else:
-                self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
-                                                                                  off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
-
-        def color_branch(q):
-            self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
-            if binned:
-                self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                    3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws), self.ws_bytes, q))
-            else:
-                self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
-                                                                                    off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
-
-        if self.chunk_rays and binned:
-            self._backward_in_ranges(R, on_ready)
-        elif self.joint:
-            # the two decoder backward passes side by side, then ONE binned pass for both tables
-            mflags = 1 | (L.US_MLP_DEFER_REDUCE if defer else 0)
-            mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                                                off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
-                                                                                P(self.mlp_ws_s), self.mlp_ws_bytes, q))
-            if self._decoder_pair():                             # both decoders' backward passes in one launch
-                self._timed("mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c),
-                                                                        off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4, P(self.d_raw), 4, N,
-                                                                        P(self.d_feat_s), P(self.d_feat_c), off(self.grad, self.o_dec_s),
-                                                                        off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws_s), P(self.mlp_ws),
-                                                                        self.mlp_ws_bytes, st))
-            else:
-                if self.decoders_side_by_side:
-                    with self._branch() as st2:
-                        mlp_s(st2)
-                else:
-                    mlp_s(st)
-                self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                                    N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
-                if self.decoders_side_by_side:
-                    self._join()                                 # the main stream waits for the sdf decoder's backward pass, nothing later
-            if defer:
-                with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
-                    if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
-                        self.grad[:self.o_tab_s].zero_()
-                    if self._decoder_pair():                     # (the pair launch's partial rows: reduced by its own function)
-                        L.check(lib.us_mlp_reduce_pair(ms, mc, P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s),
-                                                       off(self.grad, self.o_dec_c), st2), "us_mlp_reduce_pair")
-                    else:
-                        L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
-                        L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
-                    if gbeta is not None:
-                        L.check(lib.us_beta_reduce(P(self.beta_part), R, gbeta, st2), "us_beta_reduce")
-                    if not self._step_advanced:
-                        L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st2), "us_adam_step_inc")
-                        self._step_advanced = True
-            if self.scan_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.scan_stream)
-            jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
-            self._adam_fused = bool(fuse_adam and self.fuse_adam and self.group is None)
-            if self._adam_fused:
-                if not self._step_advanced:                      # (a forward pass that did not queue it: probing / one-stream mode)
-                    L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
-                    self._step_advanced = True
-                f_ = self.lr_factor
-                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint_adam(
-                    ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
-                    P(self.ws), self.ws_bytes, off(fl, self.o_tab_s), off(fl, self.o_tab_c), off(self.m, self.o_tab_s), off(self.m, self.o_tab_c),
-                    off(self.v, self.o_tab_s), off(self.v, self.o_tab_c), self.lr["sdf_grid"] * f_, self.lr["color_grid"] * f_, 0.9, 0.999, 1e-8,
-                    P(self.step_dev), st))
-            else:
-                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
-                                                                                    off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
-                                                                                    P(self.ws), self.ws_bytes, st))
-            if defer:
-                self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
-            if on_ready is not None:
-                on_ready(self.grad[self.o_tab_c:])
-        elif self.overlap and not self._probing:
-            with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
-                sdf_branch(st2)
-            color_branch(st)
-            if on_ready is not None:
-                on_ready(self.grad[self.o_tab_c:])
-            self._join()
-        else:                                                    # one stream: colour first, so that its (large) gradient
-            color_branch(st)                                     # segment can travel while the sdf branch computes
-            if on_ready is not None:
-                on_ready(self.grad[self.o_tab_c:])
-            sdf_branch(st)
-        if on_ready is not None:
-            on_ready(self.grad[:self.o_tab_c])
-        if ray_grads:
-            if not hasattr(self, "d_pts") or self.d_pts.shape[0] < R:
-                f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
-                self.d_pts, self.g_o, self.g_d = f(self.max_rays, S, 3), f(self.max_rays, 3), f(self.max_rays, 3)
-            L.check(lib.us_hashgrid_bwd_input_gather(ds, off(fl, self.o_tab_s), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
-                    "us_hashgrid_bwd_input_gather")
-            L.check(lib.us_hashgrid_bwd_input_gather(dc, off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_c), N, P(self.d_pts),
-                                                     3 | L.US_GRID_ACCUMULATE, st), "us_hashgrid_bwd_input_gather")
-            L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
-        self.n_rays = R
-        return self.loss
-
-    def _backward_in_ranges(self, R, on_ready):
-        """the decoders' backward passes over the whole batch, then the table gradients range by range (scratch within max_workspace_bytes)"""
-        lib, st, P, S, N, fl = L.lib(), L.stream(), L.ptr, self.S, R * self.S, self.flat
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
-        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c),
-                               off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st), "us_mlp_bwd")
-        L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s),
-                               off(self.grad, self.o_dec_s), 1, P(self.mlp_ws_s), self.mlp_ws_bytes, st), "us_mlp_bwd")
-        for k, r0 in enumerate(range(0, R, self.chunk_rays)):
-            n_k, i0 = (min(R, r0 + self.chunk_rays) - r0) * S, r0 * S
-            flags = 3 | self._det | (L.US_GRID_BWD_OVERWRITE if k == 0 else 0)
-            x, dya, dyb = off(self.pts, 3 * i0), off(self.d_feat_s, 2 * i0), off(self.d_feat_c, 2 * i0)
-            if self.joint:
-                L.check(lib.us_hashgrid_bwd_joint_range(ds, dc, x, dya, dyb, n_k, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                        flags, P(self.ws), self.ws_bytes, st), "us_hashgrid_bwd_joint_range")
-            else:
-                L.check(lib.us_hashgrid_bwd_binned_range(dc, x, dyb, n_k, N, off(self.grad, self.o_tab_c), flags | self._packed, P(self.ws),
-                                                         self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
-                L.check(lib.us_hashgrid_bwd_binned_range(ds, x, dya, n_k, N, off(self.grad, self.o_tab_s), flags | self._packed, P(self.ws_s),
-                                                         self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
-        if on_ready is not None:
-            on_ready(self.grad[self.o_tab_c:])
-
-    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, ray_grads=False, zero_depth_draws=None):
-        """single-process forward + backward (no optimiser step); returns loss[1]"""
-        self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, zero_depth_draws)
-        return self.backward(ray_grads=ray_grads)
-
-    def ray_gradients(self):
-        """(dL/d rays_o [R,3], dL/d rays_d [R,3]) of the last backward(ray_grads=True); rays dropped by the pre-filter get 0"""
-        R = self.n_rays
-        return self.g_o[:R], self.g_d[:R]
-
-    def adam_step(self, ranges=None):
-        """
-        torch.optim.Adam over the three param groups (Mapper.py:118-126) in one launch.  ranges: None (everything) or a list of
-        (lo, hi) index ranges of the flat buffer -- the shards this rank owns when the optimiser state is sharded over ranks.
-        """
-        lib, st, P = L.lib(), L.stream(), L.ptr
-        self.opt_step += 1
-        f = self.lr_factor
-        groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
-                  (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
-        if ranges is None:
-            segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
-            self._dec_grad_clean = True                          # cleared on the way
-            if getattr(self, "_adam_fused", False):              # the tables were updated inside the table gradient's accumulate pass
-                segs = segs[:1]
-                self._adam_fused = False
-        else:
-            segs, zero_mask = [], 0
-            for (lo, hi) in ranges:
-                for (o, n, lr) in groups:
-                    a, b = max(lo, o), min(hi, o + n)
-                    if b > a:
-                        segs.append((a, b - a, lr))
-            self._dec_grad_clean = False
-        if not segs:
-            segs = [(0, 0, 0.0)]        # a rank that owns only padding still advances the device-side step count (k_step_inc), so the
-        k = len(segs)                   # bias corrections and the sampler's jitter salt stay in lock-step over the ranks
-        if self._step_advanced:         # backward() already queued the step increment (us_adam_step_inc, beside the table gradient)
-            zero_mask |= L.US_ADAM_STEP_ADVANCED
-            self._step_advanced = False
-        I64, DBL = ctypes.c_int64 * k, ctypes.c_double * k
-        # the step count lives on the device (advanced by the launch itself): nothing in the arguments changes between iterations
-        L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), k, I64(*[g[0] for g in segs]),
-                                              I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, P(self.step_dev),
-                                              zero_mask, st), "us_adam_step_segments_dev")
-
-    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
-        """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
-        if self.group is None and self.fuse_adam:
-            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
-            loss = self.backward(fuse_adam=True)                 # ... which updates the tables where the joint pass runs
-            self.adam_step()
-            return loss
-        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth), self.group)
-
-    def capture(self, n_rays, t_rand=False):
-        """
-        Capture one iteration (rays without the zero-depth branch, single process) into a hipGraph; replay() then runs it with one
-        host call, and the two branch streams are scheduled by the graph instead of by events (0.706 -> 0.685 ms at 4096 x 64).
-        Returns the static input tensors (rays_o [n,3], rays_d [n,3], gt_depth [n], gt_color [n,3][, t_rand [n,S]]): write the
-        next batch INTO them (e.g. let common.get_samples_all's kernel target them), then call replay().  The jitter comes from the
-        in-kernel generator (varied per replay by the device-side step count) unless t_rand=True.  Adam's step count is on the
-        device, so a replay advances the optimiser exactly as an eager iterate() does; eager and replayed iterations can be mixed.
-        """
-        from .graph import CapturedIteration
-        if self.group is not None:
-            raise L.UniSlamHipError("MapStep.capture: single-process only (the data-parallel step waits on RCCL work handles)")
-        dev = self.device
-        f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        ins = [f(n_rays, 3), f(n_rays, 3) + 1.0, f(n_rays) + 1.0, f(n_rays, 3)]
-        tr = f(n_rays, self.S) if t_rand else None
-        was, self.probe = self.probe, None
-        # warm-up iterations would move the parameters: run them with the learning rates at zero and restore the state after
-        keep = (self.flat.clone(), self.m.clone(), self.v.clone(), self.step_dev.clone(), self.opt_step, dict(self.lr), self.rng_calls)
-        self.lr = {k: 0.0 for k in self.lr}
-        fn = lambda: self.iterate(ins[0], ins[1], ins[2], ins[3], t_rand=tr, has_zero_depth=False)
-        try:
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    fn()
-            torch.cuda.current_stream().wait_stream(s)
-        finally:
-            self.lr = keep[5]
-        self.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2]); self.step_dev.copy_(keep[3])
-        self.opt_step, self.rng_calls = keep[4], keep[6]
-        self._dec_grad_clean = False    # the captured backward clears the decoder gradient itself: a replay is then valid after any call
-        self._graph = CapturedIteration(fn, warmup=0)
-        # the capture pass itself does not execute: state is as before.  (opt_step was advanced by the traced call: undo.)
-        self.opt_step = keep[4]
-        self.probe = was
-        return tuple(ins) + ((tr,) if t_rand else ())
-
-    def replay(self):
-        """run the captured iteration on what the static input tensors hold now; returns the loss tensor [1] (static)"""
-        if self._graph is None:
-            raise L.UniSlamHipError("MapStep.replay: call capture() first (and again after reset_optimizer())")
-        self.opt_step += 1
-        return self._graph.replay()
-
-    def rendered(self):
-        """views of the last iteration's per-ray outputs: (term, pixel_unc, depth, rgb, sdf, z_vals, depth_unc)"""
-        R = self.n_rays
-        return (self.term[:R], self.unc[:R], self.depth[:R], self.rgb[:R], self.raw[:R, :, 3], self.z[:R], self.dunc[:R])
-
-
-class TrackStep:
-    """
-    The body of the reference's tracking hot loop (src/Tracker.py:149-244, one call of optimize_tracking) with the
-    render + loss + backward part as a straight-line sequence of HIP launches: decoders and tables are frozen, the only
-    gradient wanted is the one of the camera pose, which arrives as dL/d(rays_o), dL/d(rays_d) and is pushed through the
-    tiny quaternion -> rotation -> ray graph by torch autograd.  No boolean compaction (validity flags instead), no table
-    or decoder gradients (the reference computes and discards them, Tracker.py:110-111), one host-free median.
-    """
-
-    def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation, weights,
-                 mask_mode="original", perturb=True, max_rays=2048):
-        assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
-        self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
-        dev = hash_grid_sdf.params.device
-        if dev.type != "cuda":
-            raise L.UniSlamHipError("TrackStep needs the model on the GPU")
-        self.device = dev
-        self.S, self.n_strat, self.n_imp = n_stratified + n_importance, n_stratified, n_importance
-        self.truncation = float(truncation)
-        self.w5 = L.host_floats([weights["fs"], weights["center"], weights["tail"], weights["color"], weights["depth"]])
-        self.mode = {"original": 2, "no_mask": 3}[mask_mode]
-        self.perturb = perturb
-        self.bound = bound.to(dev)
-        self.bhost = bound_host(bound)
-        self.t_uni = torch.linspace(0., 1., steps=n_stratified).to(dev)
-        self.t_surf = torch.linspace(0., 1., steps=n_importance).to(dev)
-        self.desc_s, self.desc_c = decoders.mlp_descs()
-        self._joint = None
-        self._alloc(max_rays)
-
-    def _alloc(self, R):
-        dev, S = self.device, self.S
-        N = R * S
-        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        self.max_rays = R
-        self.z, self.pts, self.d_pts = f(R, S), f(R, S, 3), f(R, S, 3)
-        self.feat_s, self.feat_c, self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32), f(N, 32), f(N, 32)
-        self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
-        self.term, self.unc, self.depth, self.dunc, self.rgb = f(R), f(R), f(R), f(R), f(R, 3)
-        self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
-        self.g_o, self.g_d = f(R, 3), f(R, 3)
-        self.partials = f(int(L.lib().us_loss_partials_size(R)))
-        self.stats, self.loss, self.median = f(10), f(1), f(1)
-        self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
-
-    def _decoder_params(self):
-        dec = self.dec
-        if dec.tcnn_network:
-            return L.f32(dec.sdf_decoder.params.detach()), L.f32(dec.color_decoder.params.detach())
-        return (Decoders.pack_linear_params(dec.linears, dec.output_linear).detach(),
-                Decoders.pack_linear_params(dec.c_linears, dec.c_output_linear).detach())
-
-    def refresh_parameters(self):
-        """call after the mapper changed the decoders (Tracker.update_params_from_mapping, Tracker.py:246-269)"""
-        self._ps, self._pc = self._decoder_params()
-        b = self.dec.beta
-        self._beta = L.f32(b.detach()).reshape(1) if torch.is_tensor(b) else torch.tensor([float(b)], device=self.device)
-
-    def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None):
-        """render the rays, evaluate the tracking loss, return (loss[1], g_rays_o[R,3], g_rays_d[R,3], pixel_unc[R], valid[R])"""
-        lib, st, P = L.lib(), L.stream(), L.ptr
-        if not hasattr(self, "_ps"):
-            self.refresh_parameters()
-        o, d, gd, gc = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()), L.f32(gt_color.detach())
-        R, S = o.shape[0], self.S
-        if R > self.max_rays:
-            self._alloc(R)
-        N = R * S
-        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
-        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        ts, tc = L.f32(self.es.params.detach()), L.f32(self.ec.params.detach())
-        # Tracker.py:177-184 (inside the box AND a depth measurement, kept as flags) + Renderer.py:81-101,132-137 in one launch;
-        # jitter from t_rand or from the in-kernel generator (the device-side step count varies it between graph replays)
-        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-        self.rng_calls = getattr(self, "rng_calls", 0) + 1
-        seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1)
-        L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
-                                     ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
-                                     P(self.pstep) if hasattr(self, "pstep") else None, 1 if self.perturb else 0, 1, P(self.valid),
-                                     P(self.z), P(self.pts), st), "us_sample_points")
-        # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers.  Both tables in
-        # one launch where the pair of grids qualifies (positions and cells computed once, one launch less in a latency-bound chain)
-        if self._joint is None:
-            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
-        if self._joint:
-            L.check(lib.us_hashgrid_fwd_joint(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), 3, None, 0, st), "us_hashgrid_fwd_joint")
-        else:
-            L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
-            L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
-        pair = bool(lib.us_mlp_pair_supported(ms, mc))             # both decoders in one launch each way
-        if pair:
-            L.check(lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st),
-                    "us_mlp_fwd_pair")
-        else:
-            L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
-            L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
-        L.check(lib.us_composite_fwd(P(self.raw), P(self.z), P(self._beta), R, S, P(self.term), P(self.unc), P(self.depth),
-                                     P(self.rgb), P(self.dunc), None, st), "us_composite_fwd")
-        med = None
-        if self.mode == 2:
-            # Tracker.py:214-215: median of |gt - depth| over the rays that passed the pre-filter (lower median, like
-            # torch.median), without compaction: rejected rays sort to the end as +inf
-            if R <= 8192:
-                L.check(lib.us_masked_median(P(gd), P(self.depth), P(self.valid), R, P(self.median), st), "us_masked_median")
-            else:
-                valid = self.valid[:R].bool()
-                err = torch.where(valid, (gd - self.depth[:R]).abs(), torch.full_like(gd, float("inf")))
-                k = torch.clamp((valid.sum() - 1) // 2, min=0)
-                self.median.copy_(torch.sort(err)[0].gather(0, k.reshape(1)))
-            med = P(self.median)
-        L.check(lib.us_loss_stats(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth), P(self.rgb),
-                                  P(self.unc), med, R, S, self.truncation, P(self.partials), P(self.stats), st), "us_loss_stats")
-        L.check(lib.us_loss_grad(self.mode, off(self.raw, 3), 4, P(self.valid), P(self.z), P(gd), P(gc), P(self.depth), P(self.rgb),
-                                 P(self.unc), med, R, S, self.truncation, self.w5, P(self.stats), P(self.g_sdf), P(self.g_depth),
-                                 P(self.g_rgb), P(self.loss), st), "us_loss_grad")
-        L.check(lib.us_composite_bwd(P(self.raw), P(self.z), P(self._beta), R, S, None, None, P(self.g_depth), P(self.g_rgb), None,
-                                     P(self.g_sdf), P(self.d_raw), None, None, st), "us_composite_bwd")
-        if pair:
-            L.check(lib.us_mlp_bwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
-                                        off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st),
-                    "us_mlp_bwd_pair")
-        else:
-            L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1,
-                                   None, 0, st), "us_mlp_bwd")
-            L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
-                                   None, 0, st), "us_mlp_bwd")
-        L.check(lib.us_hashgrid_bwd_input_gather(ds, P(ts), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
-                "us_hashgrid_bwd_input_gather")
-        L.check(lib.us_hashgrid_bwd_input_gather(dc, P(tc), P(self.pts), P(self.d_feat_c), N, P(self.d_pts), 3 | L.US_GRID_ACCUMULATE, st),
-                "us_hashgrid_bwd_input_gather")
-        L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
-        return self.loss, self.g_o[:R], self.g_d[:R], self.unc[:R], self.valid[:R]
-
-    def iterate(self, cam_pose, gt_color, gt_depth, batch_size, optimizer, H, W, fx, fy, cx, cy, ignore_edge_H, ignore_edge_W,
-                t_rand=None, indices=None):
-        """
-        Tracker.optimize_tracking (Tracker.py:149-244): cam_pose [1,7] (quaternion, translation) with requires_grad,
-        gt_color [1,H,W,3], gt_depth [1,H,W].  Returns (loss tensor[1], pixel_unc of the rays that passed the pre-filter
-        mask applied as in the reference is left to the caller: pixel_unc[valid]).
-        """
-        from .common import cam_pose_to_matrix, get_rays_from_uv
-        dev = self.device
-        c2w = cam_pose_to_matrix(cam_pose)
-        H0, H1, W0, W1 = ignore_edge_H, H - ignore_edge_H, ignore_edge_W, W - ignore_edge_W
-        n_pix = (H1 - H0) * (W1 - W0)
-        if indices is None:
-            indices = torch.randint(n_pix, (batch_size,), device=dev)                     # common.py:116
-        # pixel (i, j) of flat crop index: i = W0 + idx % (W1-W0), j = H0 + idx // (W1-W0)   (common.py:144-148)
-        wi = W1 - W0
-        i = (W0 + indices % wi).float()[None]
-        j = (H0 + torch.div(indices, wi, rounding_mode="floor")).float()[None]
-        gd = gt_depth[0, H0:H1, W0:W1].reshape(-1)[indices]
-        gc = gt_color[0, H0:H1, W0:W1].reshape(-1, 3)[indices]
-        rays_o, rays_d = get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, dev)
-        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
-        loss, g_o, g_d, unc, valid = self.forward_backward(rays_o, rays_d, gd, gc, t_rand)
-        optimizer.zero_grad()
-        torch.autograd.backward([rays_o, rays_d], [g_o, g_d])
-        optimizer.step()
-        return loss, unc, valid
-
-    # ------------------------------------------------------------------------------------------ fully fused tracking
-    def begin_frame(self, pose7, gt_color, gt_depth, lr_T, lr_R, H, W, fx, fy, cx, cy, ignore_edge_H, ignore_edge_W,
-                    betas=(0.5, 0.999)):
-        """
-        Per-frame set-up of the fused tracking loop (Tracker.py:315-329): pose7 = (quaternion[4], translation[3]) initial
-        guess, gt_color [H,W,3], gt_depth [H,W]; a fresh Adam state for the two parameter groups (lr_R for the quaternion,
-        lr_T for the translation).  The buffers are static, so iterate_fused() can be captured into a hipGraph.
-        """
-        dev = self.device
-        if not hasattr(self, "pose"):
-            f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-            self.pose, self.g_pose, self.pm, self.pv, self.pstep = f(7), f(7), f(7), f(7), f(1)
-            self.img_d, self.img_c = torch.empty((H, W), device=dev), torch.empty((H, W, 3), device=dev)
-        self.pose.copy_(pose7.detach().reshape(7))
-        self.img_d.copy_(gt_depth.reshape(H, W)); self.img_c.copy_(gt_color.reshape(H, W, 3))
-        self.pm.zero_(); self.pv.zero_(); self.pstep.zero_()
-        self.lr_T, self.lr_R, self.betas = float(lr_T), float(lr_R), betas
-        self.frame = (H, W, ignore_edge_H, ignore_edge_W)
-        self.intr = L.host_floats([fx, fy, cx, cy])
-        self.refresh_parameters()
-
-    def iterate_fused(self, batch_size, t_rand=None, indices=None):
-        """
-        One Tracker.optimize_tracking call (Tracker.py:149-244) with everything on the device: pixel draw, pose -> rays
-        (us_pose_rays), render + loss + backward, rays -> pose gradient (us_pose_grad) and Adam on the 7 pose numbers
-        (us_adam_step_dev).  Returns (loss[1], pixel_unc[R], valid[R]); the updated pose is self.pose.
-        """
-        lib, st, P = L.lib(), L.stream(), L.ptr
-        H, W, eh, ew = self.frame
-        H0, H1, W0, W1 = eh, H - eh, ew, W - ew
-        n = int(batch_size)
-        if indices is None:
-            indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.device)              # common.py:116
-        if not hasattr(self, "t_ro") or self.t_ro.shape[0] != n:
-            f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
-            self.t_ro, self.t_rd, self.t_dirs, self.t_gd, self.t_gc = f(n, 3), f(n, 3), f(n, 3), f(n), f(n, 3)
-        L.check(lib.us_pose_rays(P(self.pose), P(indices.contiguous()), n, self.intr, W0, H0, W1 - W0, P(self.img_d), P(self.img_c), W,
-                                 P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
-        loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
-        L.check(lib.us_pose_grad(P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.g_pose), st), "us_pose_grad")
-        b1, b2 = self.betas
-        L.check(lib.us_pose_adam_step(P(self.pose), P(self.g_pose), P(self.pm), P(self.pv), self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), st),
-                "us_pose_adam_step")
-        return loss, unc, valid
+from .mapstep import MapStep, _align          # noqa: F401
+from .trackstep import TrackStep              # noqa: F401
