@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
+bench.torch = torch
 import unislam_amd as us
 dev = "cuda:0"
 bound = bench.load_bound(bench.ROOM0_BOUND)

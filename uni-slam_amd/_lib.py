@@ -124,6 +124,8 @@ SIGNATURES = {
     "us_pose_grad": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f]),
     "us_hashgrid_bwd_input_rays_supported": (c_int, [_GP, _GP, c_int]),
     "us_hashgrid_bwd_input_rays": (c_int, [_GP, _GP, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, _HF, c_f, c_f, c_f, c_int, c_f]),
+    "us_hashgrid_fwd_joint_dydx": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_dydx_rays": (c_int, [c_u32, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, _HF, c_f, c_f, c_f, c_f]),
     "us_window_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_pose_window_step": (c_int, [c_f, c_int, c_f, c_f, c_f, c_i64, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl,
                                     c_dbl, c_f, c_int, c_f]),

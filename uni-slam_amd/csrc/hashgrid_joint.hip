@@ -126,10 +126,14 @@ static int make_jlevels(const us_grid_desc* a, const us_grid_desc* b, int64_t n,
 // ---------------------------------------------------------------------------------------------------------------
 // forward (both tables) and / or the counts of the binning: one workgroup = 1024 points x one level
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GATHER, bool COUNT>
+// DYDX: also leave d(features)/d(position) of both grids, level-major planes [L][N][3][2] (= tcnn's dy_dx, which the input gradient
+// contracts with dL/dy: us_hashgrid_dydx_rays) -- the 8 vertices are in registers here, and 24 contiguous bytes per thread and grid
+// stream out coalesced, where a second gather pass over the tables (us_hashgrid_bwd_input_rays) costs as much as the encoder itself.
+template <bool GATHER, bool COUNT, bool DYDX = false>
 __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
-                                                        int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows) {
+                                                        int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
+                                                        float* __restrict__ dydxA = nullptr, float* __restrict__ dydxB = nullptr) {
     constexpr int HALVES = J_FWD_THREADS / J_ROW_POINTS;
     __shared__ uint32_t lcnt[HALVES][J_LVL_BINS];
     __shared__ uint32_t done;
@@ -165,6 +169,26 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
             }
             float* o = (s ? outB : outA) + feat_index(lm, i, n, level, C, 2);
             o[0] = r0; o[1] = r1;
+            if (DYDX) {                                          // k_fwd<F, DYDX>'s arithmetic, value for value
+                float2* dd = reinterpret_cast<float2*>((s ? dydxB : dydxA) + ((int64_t)level * n + i) * 6);
+#pragma unroll
+                for (int gd = 0; gd < 3; ++gd) {
+                    float a0 = 0.0f, a1 = 0.0f;
+                    const int d0 = gd == 0 ? 1 : 0, d1 = gd == 2 ? 1 : 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float w = q.scale;
+                        w *= (e & 1) ? pos[d0] : 1.0f - pos[d0];
+                        w *= (e & 2) ? pos[d1] : 1.0f - pos[d1];
+                        const int cl = ((e & 1) << d0) | (((e >> 1) & 1) << d1);
+                        const int cr = cl | (1 << gd);
+                        a0 += w * (v[cr].x - v[cl].x); a1 += w * (v[cr].y - v[cl].y);
+                    }
+                    const float xin = x[i * 3 + gd];
+                    const bool pass = !clamp || (xin >= 0.0f && xin <= 1.0f);
+                    dd[gd] = pass ? make_float2(a0, a1) : make_float2(0.0f, 0.0f);
+                }
+            }
         }
     }
     if (!COUNT) return;
@@ -982,27 +1006,124 @@ static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n)
                name ": the two grids do not share a geometry this path takes (F = 2, <= %d levels, equal base resolution and " \
                "per-level scale, <= %d bins) or the batch is too large", J_MAX_LEVELS, J_MAX_BINS)
 
-extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
-                                     const float* x, int64_t n, float* outA, float* outB, int flags, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB, const float* x,
+                     int64_t n, float* outA, float* outB, float* dydxA, float* dydxB, int flags, void* workspace, size_t workspace_bytes,
+                     void* stream) {
     if (n < 0) return US_ERR_SHAPE;
-    J_CHECK_PAIR("us_hashgrid_fwd_joint");
+    US_REQUIRE(a && b, US_ERR_NULL, "%s: desc is NULL", fn);
+    JLevels lv;
+    // without a workspace only the geometry matters (the 32-bit record addresses bound the table gradient's batch, not the encoder's)
+    const int TB = make_jlevels(a, b, workspace ? (n > 0 ? n : 1) : 1, &lv);
+    US_REQUIRE(TB > 0 && (!workspace || us_hashgrid_joint_supported(a, b, n > 0 ? n : 1)), US_ERR_CONFIG,
+               "%s: the two grids do not share a geometry this path takes (F = 2, <= %d levels, equal base resolution and per-level "
+               "scale, <= %d bins) or the batch is too large", fn, J_MAX_LEVELS, J_MAX_BINS);
     if (n == 0) return US_OK;
-    US_REQUIRE(paramsA && paramsB && x && outA && outB, US_ERR_NULL, "us_hashgrid_fwd_joint: NULL pointer");
-    US_REQUIRE(((uintptr_t)paramsA & 15u) == 0 && ((uintptr_t)paramsB & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_fwd_joint: params must be 16-byte aligned");
+    US_REQUIRE(paramsA && paramsB && x && outA && outB, US_ERR_NULL, "%s: NULL pointer", fn);
+    US_REQUIRE(((uintptr_t)paramsA & 15u) == 0 && ((uintptr_t)paramsB & 15u) == 0, US_ERR_SHAPE, "%s: params must be 16-byte aligned", fn);
+    US_REQUIRE((dydxA != nullptr) == (dydxB != nullptr), US_ERR_NULL, "%s: dy_dx of both grids or of neither", fn);
+    US_REQUIRE(!dydxA || ((((uintptr_t)dydxA | (uintptr_t)dydxB) & 7u) == 0), US_ERR_SHAPE, "%s: dy_dx must be 8-byte aligned", fn);
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
     dim3 grid((unsigned)us_cdiv(n, J_FWD_THREADS), a->n_levels), block(J_FWD_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (workspace) {
-        US_REQUIRE(((uintptr_t)workspace & 15u) == 0, US_ERR_SHAPE, "us_hashgrid_fwd_joint: workspace must be 16-byte aligned");
+        US_REQUIRE(((uintptr_t)workspace & 15u) == 0, US_ERR_SHAPE, "%s: workspace must be 16-byte aligned", fn);
         US_REQUIRE(workspace_bytes >= us_hashgrid_joint_workspace_bytes(a, b, n), US_ERR_WORKSPACE,
-                   "us_hashgrid_fwd_joint: workspace %zu B < %zu B", workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
+                   "%s: workspace %zu B < %zu B", fn, workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
         const JWorkspace w = j_carve(workspace, a->n_levels, TB, n);
-        hipLaunchKernelGGL((k_jfwd<true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows);
+        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
+        else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
     } else {
-        hipLaunchKernelGGL((k_jfwd<true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u);
+        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, false, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
+        else hipLaunchKernelGGL((k_jfwd<true, false, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
     }
-    US_CHECK_LAUNCH("us_hashgrid_fwd_joint");
+    US_CHECK_LAUNCH(fn);
+    return US_OK;
+}
+
+extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
+                                     const float* x, int64_t n, float* outA, float* outB, int flags, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    return fwd_joint("us_hashgrid_fwd_joint", a, b, paramsA, paramsB, x, n, outA, outB, nullptr, nullptr, flags, workspace, workspace_bytes, stream);
+}
+
+extern "C" int us_hashgrid_fwd_joint_dydx(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
+                                          const float* x, int64_t n, float* outA, float* outB, float* dy_dxA, float* dy_dxB, int flags,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(n <= 0 || (dy_dxA && dy_dxB), US_ERR_NULL, "us_hashgrid_fwd_joint_dydx: NULL pointer");
+    return fwd_joint("us_hashgrid_fwd_joint_dydx", a, b, paramsA, paramsB, x, n, outA, outB, dy_dxA, dy_dxB, flags, workspace, workspace_bytes, stream);
+}
+
+// The input gradient from the stored dy_dx, reduced to the rays: a workgroup = one ray, lanes = 16 samples x 4 level rows, each lane
+// its levels {row, row+4, ...} of grid A, then of grid B -- the summation order of k_bwd_input_rays (hashgrid.hip), so the two paths
+// agree bit for bit -- then the adjoint of us_ray_points.  Pure streaming: 32 B per (point, level, grid), every row of 16 lanes reads
+// 128 + 384 contiguous bytes.
+#define JR_MAX_WAVES 8
+struct JRaySpan { float span[3]; };
+__global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_levels, const float* __restrict__ dyA, const float* __restrict__ dyB,
+                                                                 const float* __restrict__ dydxA, const float* __restrict__ dydxB, int64_t n, int S,
+                                                                 const float* __restrict__ z_vals, JRaySpan bd, float* __restrict__ g_o,
+                                                                 float* __restrict__ g_d, float* __restrict__ dL_dx) {
+    __shared__ float sh[JR_MAX_WAVES][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, pt = lane & 15;
+    const int64_t ray = blockIdx.x;
+    const int s = wave * 16 + pt;
+    const bool in = s < S;
+    const int64_t i = ray * S + s;
+    float rA[3] = {0.f, 0.f, 0.f}, rB[3] = {0.f, 0.f, 0.f};
+    if (in) {
+#pragma unroll
+        for (int gsel = 0; gsel < 2; ++gsel) {
+            const float* dy = gsel ? dyB : dyA; const float* dd = gsel ? dydxB : dydxA;
+            float* r = gsel ? rB : rA;
+            for (uint32_t level = (uint32_t)row; level < n_levels; level += 4) {
+                const int64_t e = (int64_t)level * n + i;
+                const float2 y = *reinterpret_cast<const float2*>(dy + e * 2);
+                const float2* d = reinterpret_cast<const float2*>(dd + e * 6);
+                const float2 d0 = d[0], d1 = d[1], d2 = d[2];
+                float t[3];
+                t[0] = y.x * d0.x; t[1] = y.x * d1.x; t[2] = y.x * d2.x;      // input_grad_level: r[gd] += dy[0] * d[0][gd], then dy[1] * d[1][gd]
+                r[0] += t[0]; r[1] += t[1]; r[2] += t[2];
+                r[0] += y.y * d0.y; r[1] += y.y * d1.y; r[2] += y.y * d2.y;
+            }
+        }
+    }
+    float so[3], sd[3];
+    const float z = (in && row == 0) ? z_vals[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rA[k] += __shfl_xor(rA[k], 16, 64); rA[k] += __shfl_xor(rA[k], 32, 64);
+        rB[k] += __shfl_xor(rB[k], 16, 64); rB[k] += __shfl_xor(rB[k], 32, 64);
+        const float r = rA[k] + rB[k];
+        if (dL_dx && row == 0 && in) dL_dx[i * 3 + k] = r;
+        const float gk = (row == 0 && in) ? r / bd.span[k] : 0.0f;
+        so[k] = wave_sum(gk); sd[k] = wave_sum(gk * z);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = so[k]; sh[wave][3 + k] = sd[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float a = 0.0f;
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) a += sh[w][threadIdx.x];
+        (threadIdx.x < 3 ? g_o : g_d)[ray * 3 + (threadIdx.x % 3)] = a;
+    }
+}
+
+extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, const float* dL_dyB, const float* dy_dxA, const float* dy_dxB,
+                                     int64_t n_rays, int n_samples, const float* z_vals, const float* bound_host, float* dL_do, float* dL_dd,
+                                     float* dL_dx, void* stream) {
+    US_REQUIRE(n_levels >= 1 && n_levels <= US_MAX_LEVELS, US_ERR_CONFIG, "us_hashgrid_dydx_rays: n_levels %u", n_levels);
+    US_REQUIRE(n_samples >= 1 && n_samples <= 16 * JR_MAX_WAVES, US_ERR_SHAPE, "us_hashgrid_dydx_rays: n_samples %d not in 1..%d", n_samples, 16 * JR_MAX_WAVES);
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(dL_dyA && dL_dyB && dy_dxA && dy_dxB && z_vals && bound_host && dL_do && dL_dd, US_ERR_NULL, "us_hashgrid_dydx_rays: NULL pointer");
+    JRaySpan bd;
+    for (int k = 0; k < 3; ++k) bd.span[k] = bound_host[3 + k] - bound_host[k];
+    const int waves = (n_samples + 15) / 16;
+    hipLaunchKernelGGL(k_dydx_rays, dim3((unsigned)n_rays), dim3(64 * waves), 0, (hipStream_t)stream, n_levels, dL_dyA, dL_dyB, dy_dxA, dy_dxB,
+                       n_rays * n_samples, n_samples, z_vals, bd, dL_do, dL_dd, dL_dx);
+    US_CHECK_LAUNCH("us_hashgrid_dydx_rays");
     return US_OK;
 }
 
@@ -1037,7 +1158,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     const int clamp = flags & US_GRID_CLAMP01;
     const uint32_t L = a->n_levels;
     if (!counted)
-        hipLaunchKernelGGL((k_jfwd<false, true>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
+        hipLaunchKernelGGL((k_jfwd<false, true, false>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
                            (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
     if (!scanned) {
         hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,

@@ -70,6 +70,10 @@ class MapStep:
         self.decoder_pair = True        # ... and, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
         self._dec_grad_clean = False
         self._step_advanced = False
+        # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
+        # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
+        # window.MapWindow for the iterations that optimise camera poses (src/Mapper.py:372-376); costs 2 x 24 B per point and level.
+        self.store_dydx, self._dydx_valid, self.dydx_s, self.dydx_c = False, False, None, None
         # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
         # entries it has just summed (us_hashgrid_bwd_joint_adam); adam_step() then covers the decoders only.  Measured at 4096 x 64: the
         # accumulate pass grows from 106 to 203 us -- a bin's entries are 128-byte lines 32 KB apart, and six arrays of such lines do not
@@ -180,6 +184,7 @@ class MapStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
+        self.dydx_s = self.dydx_c = None
         self._graph = None              # a captured iteration holds the old buffers' addresses: capture() again after a reallocation
         self.z, self.pts = f(R, S), f(R, S, 3)
         self.feat_s, self.feat_c = f(N, 32), f(N, 32)
@@ -288,6 +293,7 @@ class MapStep:
         lib, st = L.lib(), L.stream()
         self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
         self._it += 1
+        self._dydx_valid = False
         o, d, gd, gc = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()), L.f32(gt_color.detach())
         R, S = o.shape[0], self.S
         if R > self.max_rays:
@@ -353,9 +359,19 @@ class MapStep:
             if self.scan_stream is not None:                     # a scan of the previous call may still read the workspace
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
             self._jcounted = True
-            self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                P(self.feat_s), P(self.feat_c), 3, P(self.ws) if self._jcounted else None,
-                                                                                self.ws_bytes if self._jcounted else 0, st))
+            self._dydx_valid = False
+            if self.store_dydx:
+                L_ = self.es.desc.n_levels
+                if self.dydx_s is None or self.dydx_s.numel() < L_ * self.max_rays * S * 6:
+                    self.dydx_s = torch.empty(L_ * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+                    self.dydx_c = torch.empty_like(self.dydx_s)
+                self._dydx_valid = True
+                self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint_dydx(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
+                                                                                         P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3,
+                                                                                         P(self.ws), self.ws_bytes, st))
+            else:
+                self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
+                                                                                    P(self.feat_s), P(self.feat_c), 3, P(self.ws), self.ws_bytes, st))
             # the binning's scan passes depend on the counts only: they run beside the decoders (own stream; the backward pass waits for
             # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
             scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
@@ -568,7 +584,12 @@ class MapStep:
             if not hasattr(self, "g_o") or self.g_o.shape[0] < R:
                 f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
                 self.g_o, self.g_d, self.d_pts = f(self.max_rays, 3), f(self.max_rays, 3), None
-            if lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
+            if self._dydx_valid and S <= 128:
+                # the forward pass left dy/dx: one streaming launch contracts it with dL/dy and reduces to the rays
+                self._timed("hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s),
+                                                                                    P(self.dydx_c), R, S, P(self.z), self.bhost, P(self.g_o), P(self.g_d),
+                                                                                    None, st))
+            elif lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
                 # both grids' input gradient and its reduction to the rays in ONE launch (no [N,3] round trip, no second gather launch)
                 self._timed("hashgrid_bwd_input_rays", lambda: lib.us_hashgrid_bwd_input_rays(
                     ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_s), P(self.d_feat_c), R, S, P(self.z),

@@ -46,6 +46,7 @@ class TrackStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
+        self.dydx_s = self.dydx_c = None
         self.z, self.pts, self.d_pts = f(R, S), f(R, S, 3), f(R, S, 3)
         self.feat_s, self.feat_c, self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32), f(N, 32), f(N, 32)
         self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
@@ -97,7 +98,12 @@ class TrackStep:
         if self._joint is None:
             self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
         if self._joint:
-            L.check(lib.us_hashgrid_fwd_joint(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), 3, None, 0, st), "us_hashgrid_fwd_joint")
+            # ... and d(features)/d(position) of both, which the pose gradient contracts at the end (no second gather pass over the tables)
+            if self.dydx_s is None:
+                self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+                self.dydx_c = torch.empty_like(self.dydx_s)
+            L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c),
+                                                   3, None, 0, st), "us_hashgrid_fwd_joint_dydx")
         else:
             L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
             L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
@@ -138,7 +144,10 @@ class TrackStep:
                                    None, 0, st), "us_mlp_bwd")
             L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
                                    None, 0, st), "us_mlp_bwd")
-        if lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
+        if self._joint and S <= 128:
+            L.check(lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), R, S, P(self.z),
+                                              self.bhost, P(self.g_o), P(self.g_d), None, st), "us_hashgrid_dydx_rays")
+        elif lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
             # both grids' input gradient and its reduction to the rays in one launch (was: two gathers + us_ray_points_bwd)
             L.check(lib.us_hashgrid_bwd_input_rays(ds, dc, P(ts), P(tc), P(self.pts), P(self.d_feat_s), P(self.d_feat_c), R, S, P(self.z), self.bhost,
                                                    P(self.g_o), P(self.g_d), None, 3, st), "us_hashgrid_bwd_input_rays")

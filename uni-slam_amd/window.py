@@ -108,7 +108,11 @@ class MapWindow:
             return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero)
         if s.group is not None:
             raise L.UniSlamHipError("MapWindow: joint pose optimisation runs in a single process (the poses are not all-reduced)")
-        s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws)
+        s.store_dydx = True                                      # the encoder leaves dy/dx for the pose gradient (no second gather pass)
+        try:
+            s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws)
+        finally:
+            s.store_dydx = False
         loss = s.backward(ray_grads=True)
         g_o, g_d = s.g_o, s.g_d
         if not s._step_advanced:                                 # the poses are one more group of the SAME optimiser: one step count
