@@ -186,6 +186,7 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
                     }
                     const float xin = x[i * 3 + gd];
                     const bool pass = !clamp || (xin >= 0.0f && xin <= 1.0f);
+                    // (plain stores: as non-temporal 8-byte stores they left the L2 uncombined -- the encoder took 261 us instead of 188)
                     dd[gd] = pass ? make_float2(a0, a1) : make_float2(0.0f, 0.0f);
                 }
             }
@@ -1077,9 +1078,10 @@ __global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_leve
             float* r = gsel ? rB : rA;
             for (uint32_t level = (uint32_t)row; level < n_levels; level += 4) {
                 const int64_t e = (int64_t)level * n + i;
-                const float2 y = *reinterpret_cast<const float2*>(dy + e * 2);
-                const float2* d = reinterpret_cast<const float2*>(dd + e * 6);
-                const float2 d0 = d[0], d1 = d[1], d2 = d[2];
+                typedef float f2_t __attribute__((ext_vector_type(2)));
+                const f2_t y = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(dy + e * 2));
+                const f2_t* d = reinterpret_cast<const f2_t*>(dd + e * 6);
+                const f2_t d0 = __builtin_nontemporal_load(d), d1 = __builtin_nontemporal_load(d + 1), d2 = __builtin_nontemporal_load(d + 2);
                 float t[3];
                 t[0] = y.x * d0.x; t[1] = y.x * d1.x; t[2] = y.x * d2.x;      // input_grad_level: r[gd] += dy[0] * d[0][gd], then dy[1] * d[1][gd]
                 r[0] += t[0]; r[1] += t[1]; r[2] += t[2];
