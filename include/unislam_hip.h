@@ -454,6 +454,28 @@ int us_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, do
 int us_pose_rays(const float* pose, const int64_t* pix, int64_t n, const float* intr_host4, int W0, int H0, int crop_w,
                  const float* depth_img, const float* color_img, int W, float* rays_o, float* rays_d, float* dirs,
                  float* gt_depth, float* gt_color, void* stream);
+/* us_pose_rays + us_sample_points (require_depth) in ONE launch: pose -> pixel rays -> pre-filter flag, sorted + jittered z, unit-cube
+ * points (src/Tracker.py:170-184 + src/utils/Renderer.py:81-101,132-137).  pix NULL: the n pixels are drawn in the kernel (counter-based
+ * uniform draw over the crop_w x crop_h crop, seeded like the jitter: rng_seed mixed with rng_counter), where the reference calls
+ * torch.randint (src/common.py:116).  rays_o / rays_d nullable (nothing downstream of the fused tracking iteration reads them). */
+int us_track_sample(const float* pose, const int64_t* pix, int64_t n_rays, const float* intr_host4, int W0, int H0, int crop_w, int crop_h,
+                    const float* depth_img, const float* color_img, int W, const float* bound_host, const float* t_uni, int n_strat,
+                    const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed,
+                    const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs, float* gt_depth, float* gt_color,
+                    uint8_t* valid, float* z_vals, float* pts, void* stream);
+/* The tracking loss with the 10 x median gate (US_LOSS_TRK_ORIGINAL, src/Tracker.py:206-238) fused around the compositing:
+ *   us_track_loss_fwd  us_composite_fwd that also leaves |gt - depth| per ray (err[R]) and every ray's ten loss partials under the
+ *                      median-free half of the gate, then ONE workgroup: lower median over the pre-filtered rays -> median[1], sums of
+ *                      the partials of the rays with err < 10 median -> stats[10]   (= us_composite_fwd + us_masked_median +
+ *                      us_loss_stats; n_rays <= 8192)
+ *   us_track_loss_bwd  us_loss_grad + us_composite_bwd in one launch, given that median and those statistics. */
+int us_track_loss_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, const uint8_t* valid,
+                      const float* gt_depth, const float* gt_color, double truncation, float* termination, float* pixel_unc, float* depth,
+                      float* rgb, float* depth_unc, float* partials, float* err, float* median, float* stats, void* stream);
+int us_track_loss_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, const uint8_t* valid,
+                      const float* gt_depth, const float* gt_color, const float* depth, const float* rgb, const float* pixel_unc,
+                      const float* median, double truncation, const float* w_host5, const float* stats, float* d_raw, float* loss_out,
+                      void* stream);
 /* g_pose[7] = dL/dpose from dL/d rays_o, dL/d rays_d (closed-form chain rule through R(q) = I + 2 M(q)/|q|^2) */
 int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n, float* g_pose,
                  void* stream);

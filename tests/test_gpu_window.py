@@ -257,3 +257,74 @@ def test_mapwindow_graph_replay_equals_eager():
     assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-6, atol=1e-8)
     assert torch.allclose(outs[1][2], outs[0][2], rtol=0, atol=1e-7)
     assert float((outs[0][2] - O.matrix_to_cam_pose(c2ws[1:]).to(DEV)).abs().max()) > 1e-3       # the poses did move
+
+
+def test_fused_tracking_chain_equals_general_chain():
+    """TrackStep.iterate_fused: the nine-launch chain (us_track_sample, us_hashgrid_fwd_joint_dydx, us_track_loss_fwd / _bwd,
+    us_hashgrid_dydx_rays, us_pose_window_step) against the general chain on the same pixels and jitter, over four iterations"""
+    import unislam_amd as us
+    torch.manual_seed(3)
+    dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+    H, Wd, fx, fy, cx, cy, eh, ew, n = 60, 80, 40.0, 40.0, 39.5, 29.5, 4, 5, 300
+    g = torch.Generator().manual_seed(4)
+    gt_depth = (torch.rand(H, Wd, generator=g) * 1.5 + 0.5).to(DEV); gt_depth[20, 20:30] = 0.0; gt_depth[30:34, 40:50] = 60.0
+    gt_color = torch.rand(H, Wd, 3, generator=g).to(DEV)
+    w = dict(fs=10, center=200, tail=50, color=5, depth=1)
+    pose0 = torch.tensor([0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0], device=DEV)
+    draws = [(torch.randint((H - 2 * eh) * (Wd - 2 * ew), (n,), generator=g).to(DEV), torch.rand(n, 40, generator=g).to(DEV)) for _ in range(4)]
+    steps = []
+    for fast in (True, False):
+        ts = us.TrackStep(es, ec, dec, BOUND, 32, 8, 0.06, w, max_rays=n)
+        ts.fast_path = fast
+        ts.begin_frame(pose0, gt_color, gt_depth, 2e-3, 1e-3, H, Wd, fx, fy, cx, cy, eh, ew)
+        out = []
+        for idx, tr in draws:
+            loss, unc, valid = ts.iterate_fused(n, t_rand=tr, indices=idx)
+            out.append((float(loss), unc.clone(), valid.clone(), ts.g_pose.clone(), ts.pose.clone(), float(ts.median), ts.stats.clone()))
+        steps.append(out)
+    for a, b in zip(*steps):
+        assert torch.equal(a[2], b[2]) and 0 < int(a[2].sum()) < n                       # some rays dropped by the pre-filter
+        assert a[5] == b[5]                                                              # the median is an element of the batch: exact
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
+        assert torch.allclose(a[6], b[6], rtol=1e-6) and torch.allclose(a[1], b[1], rtol=1e-6, atol=1e-9)
+        assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-6 * float(b[3].abs().max()))
+        assert torch.allclose(a[4], b[4], rtol=0, atol=1e-7)
+
+
+def test_track_sample_draws_its_pixels_inside_the_crop():
+    """us_track_sample with pix = NULL: the in-kernel draw stays inside the crop, covers it evenly, changes with the device-side step
+    count, and the gathered depth / colour / direction belong to the drawn pixel"""
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    lib, P_ = L.lib(), L.ptr
+    H, Wd, fx, fy, cx, cy, eh, ew, n = 60, 80, 40.0, 41.0, 39.5, 29.5, 4, 5, 8192
+    g = torch.Generator().manual_seed(1)
+    depth = (torch.rand(H, Wd, generator=g) + 0.5).to(DEV); color = torch.rand(H, Wd, 3, generator=g).to(DEV)
+    pose = torch.tensor([0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0], device=DEV)
+    t_uni, t_surf = torch.linspace(0, 1, 32).to(DEV), torch.linspace(0, 1, 8).to(DEV)
+    f = lambda *s: torch.empty(s, device=DEV)
+    outs = []
+    for step in (0.0, 1.0):
+        ctr = torch.tensor([step], device=DEV)
+        ro, rd, dirs, gd, gc, z, pts = f(n, 3), f(n, 3), f(n, 3), f(n), f(n, 3), f(n, 40), f(n, 40, 3)
+        valid = torch.empty(n, dtype=torch.uint8, device=DEV)
+        L.check(lib.us_track_sample(P_(pose), None, n, L.host_floats([fx, fy, cx, cy]), ew, eh, Wd - 2 * ew, H - 2 * eh, P_(depth), P_(color), Wd,
+                                    us.common.bound_host(BOUND), P_(t_uni), 32, P_(t_surf), 8, L.ctypes.c_float(1.2), L.ctypes.c_float(0.09),
+                                    L.ctypes.c_float(0.18), None, 1234, P_(ctr), 1, P_(ro), P_(rd), P_(dirs), P_(gd), P_(gc), P_(valid), P_(z),
+                                    P_(pts), L.stream()), "us_track_sample")
+        u = torch.round(dirs[:, 0] * fx + cx).long(); v = torch.round(-dirs[:, 1] * fy + cy).long()
+        assert int(u.min()) >= ew and int(u.max()) < Wd - ew and int(v.min()) >= eh and int(v.max()) < H - eh
+        assert torch.equal(gd, depth[v, u]) and torch.equal(gc, color[v, u])
+        assert abs(float((u < Wd // 2).float().mean()) - 0.5) < 0.03 and abs(float((v < H // 2).float().mean()) - 0.5) < 0.03
+        assert len(torch.unique(v * Wd + u)) > 0.6 * (H - 2 * eh) * (Wd - 2 * ew)          # 8192 draws over 3640 pixels: most are hit
+        c2w = us.common.cam_pose_to_matrix(pose[None])
+        o_ref, d_ref = us.common.get_rays_from_uv(u.float()[None], v.float()[None], c2w, H, Wd, fx, fy, cx, cy, DEV)
+        assert torch.allclose(rd, d_ref.reshape(-1, 3), rtol=1e-5, atol=1e-6) and torch.allclose(ro, o_ref.reshape(-1, 3))
+        assert bool((z[:, 1:] >= z[:, :-1]).all())
+        outs.append(v * Wd + u)
+    assert not torch.equal(outs[0], outs[1])

@@ -126,6 +126,10 @@ SIGNATURES = {
     "us_hashgrid_bwd_input_rays": (c_int, [_GP, _GP, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, _HF, c_f, c_f, c_f, c_int, c_f]),
     "us_hashgrid_fwd_joint_dydx": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_dydx_rays": (c_int, [c_u32, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, _HF, c_f, c_f, c_f, c_f]),
+    "us_track_sample": (c_int, [c_f, c_f, c_i64, _HF, c_int, c_int, c_int, c_int, c_f, c_f, c_int, _HF, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt,
+                                c_f, ctypes.c_uint64, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_track_loss_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_dbl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "us_track_loss_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_dbl, _HF, c_f, c_f, c_f, c_f]),
     "us_window_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_pose_window_step": (c_int, [c_f, c_int, c_f, c_f, c_f, c_i64, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl,
                                     c_dbl, c_f, c_int, c_f]),

@@ -28,6 +28,9 @@
 #ifndef J_FWD_THREADS
 #define J_FWD_THREADS 1024               // encoder workgroup: 1024 points x one level (two count rows)
 #endif
+#ifndef J_SMALL_BATCH
+#define J_SMALL_BATCH (1 << 18)          // below this many points the count-free encoder runs 256-thread workgroups
+#endif
 #define J_ROW_POINTS 512                 // points per count row = per k_jwrite workgroup
 #define J_MAX_LEVELS 16
 #define J_MAX_BINS 8192                  // bins over all levels
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, lg16 = lane & (RUN_GROUP - 1);
-    const int64_t i = (int64_t)blockIdx.x * J_FWD_THREADS + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * (COUNT ? J_FWD_THREADS : (int)blockDim.x) + threadIdx.x;   // (the counting side needs its 1024-point rows)
     const bool in = i < n;
     float pos[3]; uint32_t cell[3];
 #pragma unroll
@@ -1034,6 +1037,10 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
         if (dydxA) hipLaunchKernelGGL((k_jfwd<true, true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
         else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
     } else {
+        // small batches (a tracking iteration: 80 000 points = 79 workgroups of 1024 per level) leave a ragged last round over the chip's
+        // 256 CUs: 256-thread workgroups there
+        const int threads = n >= J_SMALL_BATCH ? J_FWD_THREADS : 256;
+        grid = dim3((unsigned)us_cdiv(n, threads), a->n_levels); block = dim3(threads);
         if (dydxA) hipLaunchKernelGGL((k_jfwd<true, false, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
         else hipLaunchKernelGGL((k_jfwd<true, false, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
     }

@@ -259,6 +259,7 @@ __device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
 struct LossW { float w[5]; };
 struct RayGate { bool sdf_depth; bool color; };
 
+// median == nullptr in US_LOSS_TRK_ORIGINAL: the 10 x median test is applied later (k_track_gate_reduce), the gate is its other half
 __device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float unc, const float* median) {
     RayGate g; g.sdf_depth = true; g.color = true;
     const bool alpha_mask = (1.0f - unc) > 0.99f;                       // Mapper.py:414-415 / Tracker.py:210-211
@@ -266,16 +267,17 @@ __device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float u
         g.sdf_depth = (gt > 0.0f) && alpha_mask;                        // Mapper.py:417-419; colour uses all rays (:427)
     } else if (mode == US_LOSS_TRK_ORIGINAL) {
         const float err = fabsf(gt - d);
-        g.sdf_depth = (err < 10.0f * median[0]) && alpha_mask;          // Tracker.py:214-218
+        g.sdf_depth = (median == nullptr || err < 10.0f * median[0]) && alpha_mask;          // Tracker.py:214-218
         g.color = g.sdf_depth;                                          // Tracker.py:225
     }
     return g;
 }
 
 // loss terms riding on the compositing kernels (us_render_loss_fwd / us_render_loss_bwd): enabled == 0 -> plain compositing
-struct LossFwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; float tr, tr04; float* partials; };
+struct LossFwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; float tr, tr04; float* partials;
+                 float* err; };                 // err (US_LOSS_TRK_ORIGINAL): |gt - depth| per ray for the median gate, applied by k_track_gate_reduce
 struct LossBwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; const float* depth; const float* rgb;
-                 const float* unc; float tr, tr04; LossW lw; const float* stats; float* loss_out; };
+                 const float* unc; float tr, tr04; LossW lw; const float* stats; float* loss_out; const float* median; };
 
 template <int EPL>
 __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__
         const float gt = lf.gt_depth[ray], d = s_z;
         RayGate gate = ray_gate(lf.mode, gt, d, (1.0f - s_w) * (1.0f - s_w), nullptr);
         if (lf.valid && !lf.valid[ray]) { gate.sdf_depth = false; gate.color = false; }
+        if (lf.err && lane == 0) lf.err[ray] = fabsf(gt - d);
         float s3[3] = {0.f, 0.f, 0.f}, n3[3] = {0.f, 0.f, 0.f};
         if (gate.sdf_depth) {
 #pragma unroll
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     if (lb.enabled) {
         gt_l = lb.gt_depth[ray];
         const float d = lb.depth[ray];
-        RayGate gate = ray_gate(lb.mode, gt_l, d, lb.unc[ray], nullptr);
+        RayGate gate = ray_gate(lb.mode, gt_l, d, lb.unc[ray], lb.median);
         if (lb.valid && !lb.valid[ray]) { gate.sdf_depth = false; gate.color = false; }
         gate_sdf = gate.sdf_depth;
         k_fs = 2.0f * lb.lw.w[0] / lb.stats[5]; k_ce = 2.0f * lb.lw.w[1] / lb.stats[6]; k_ta = 2.0f * lb.lw.w[2] / lb.stats[7];
@@ -762,24 +765,22 @@ __global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 #define MEDIAN_MAX 8192
 // Radix select on the bit patterns (non-negative floats order like their bits): 4 passes of an 8-bit histogram in LDS.
-__global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict__ a, const float* __restrict__ b,
-                                                        const uint8_t* __restrict__ valid, int n, float* __restrict__ out) {
-    __shared__ uint32_t key[MEDIAN_MAX];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sel[3];                                  // count of flagged elements / prefix / remaining rank
+// b == nullptr: a[] already holds the non-negative values (|gt - depth| left by the compositing kernel).  Every thread returns the median.
+__device__ __forceinline__ float median_select(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ valid, int n,
+                                               uint32_t* key, uint32_t* hist, uint32_t* sel) {
     if (threadIdx.x == 0) sel[0] = 0;
     __syncthreads();
     uint32_t local = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
         uint32_t k = 0xFFFFFFFFu;                                // flagged-out elements never enter a histogram
-        if (!valid || valid[i]) { k = __float_as_uint(fabsf(a[i] - b[i])); ++local; }
+        if (!valid || valid[i]) { k = __float_as_uint(b ? fabsf(a[i] - b[i]) : a[i]); ++local; }
         key[i] = k;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&sel[0], local);
     __syncthreads();
     const uint32_t cnt = sel[0];
-    if (cnt == 0) { if (threadIdx.x == 0) out[0] = INFINITY; return; }
+    if (cnt == 0) return INFINITY;
     if (threadIdx.x == 0) { sel[1] = 0; sel[2] = (cnt - 1u) >> 1; }      // lower median: rank (cnt-1)/2, 0-based
     for (int pass = 3; pass >= 0; --pass) {
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
@@ -808,7 +809,53 @@ __global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict_
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = __uint_as_float(sel[1]);
+    return __uint_as_float(sel[1]);
+}
+
+__global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const uint8_t* __restrict__ valid, int n, float* __restrict__ out) {
+    __shared__ uint32_t key[MEDIAN_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel[3];                                  // count of flagged elements / prefix / remaining rank
+    const float m = median_select(a, b, valid, n, key, hist, sel);
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+// The tracking loss's median gate and its statistics in ONE workgroup (src/Tracker.py:212-238): the compositing kernel left |gt - depth|
+// per ray and the ten loss partials of every ray that passes the OTHER half of the gate (pre-filter, alpha mask); here the lower median
+// over the pre-filtered rays, then the fixed-order sums of the partials of the rays with err < 10 x median.
+__global__ __launch_bounds__(1024) void k_track_gate_reduce(const float* __restrict__ err, const uint8_t* __restrict__ valid,
+                                                            const float* __restrict__ partials, int n, float* __restrict__ median_out,
+                                                            float* __restrict__ stats) {
+    __shared__ uint32_t key[MEDIAN_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel[3];
+    __shared__ double sh[LOSS_NSTAT][16];
+    const float med = median_select(err, nullptr, valid, n, key, hist, sel);
+    if (threadIdx.x == 0) median_out[0] = med;
+    const float thr = 10.0f * med;
+    double acc[LOSS_NSTAT];
+#pragma unroll
+    for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        if ((!valid || valid[i]) && err[i] < thr) {
+#pragma unroll
+            for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] += (double)partials[(int64_t)i * LOSS_NSTAT + k];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < LOSS_NSTAT; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_NSTAT) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += sh[threadIdx.x][w];
+        stats[threadIdx.x] = (float)v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -914,6 +961,88 @@ __global__ __launch_bounds__(256) void k_pose_rays(const float* __restrict__ pos
         gt_depth[t] = depth_img[px];
 #pragma unroll
         for (int k = 0; k < 3; ++k) gt_color[t * 3 + k] = color_img[px * 3 + k];
+    }
+}
+
+// k_pose_rays + k_sample_points in one launch for the tracker (src/Tracker.py:170-184 + src/utils/Renderer.py:81-101,132-137): thread =
+// (ray, sample); every thread of a ray forms the ray from the pose and its pixel (30 flops, nothing to exchange), lane j == 0 leaves
+// what the rest of the iteration reads: camera-frame direction (pose gradient), gt depth / colour, validity.  pix == nullptr: the
+// pixels are drawn here -- a counter-based uniform draw per ray over the crop, like the reference's torch.randint (src/common.py:116).
+// The world-frame rays themselves are not written unless asked for: nothing downstream reads them.
+__global__ __launch_bounds__(256) void k_track_sample(const float* __restrict__ pose, const int64_t* __restrict__ pix, int64_t n_rays, Intr in,
+                                                      int crop_h, const float* __restrict__ depth_img, const float* __restrict__ color_img, int W,
+                                                      Bound3x bd, const float* __restrict__ t_uni, int n_strat, const float* __restrict__ t_surf,
+                                                      int n_imp, float c_free, float surf_off, float surf_span, const float* __restrict__ t_rand,
+                                                      unsigned long long seed, const float* __restrict__ rng_counter, int perturb,
+                                                      float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ dirs,
+                                                      float* __restrict__ gt_depth, float* __restrict__ gt_color, uint8_t* __restrict__ valid,
+                                                      float* __restrict__ z_vals, float* __restrict__ pts, int rays_per_block) {
+    if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
+    extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
+    const int S = n_strat + n_imp;
+    const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
+    const int64_t ray = (int64_t)blockIdx.x * rays_per_block + rl;
+    const bool active = rl < rays_per_block && ray < n_rays;
+    float v = 0.0f, gt = 0.0f, o3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
+    int64_t px = 0;
+    if (active) {
+        int64_t p;
+        if (pix) p = pix[ray];
+        else {                                                   // uniform over the crop's pixels: high 32 bits of a 64-bit hash, scaled
+            unsigned long long zz = (seed ^ 0xA0761D6478BD642Full) + ((unsigned long long)ray + 1ull) * 0x9E3779B97F4A7C15ull;
+            zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull; zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull; zz = zz ^ (zz >> 31);
+            p = (int64_t)(((zz >> 32) * (unsigned long long)((int64_t)in.wi * crop_h)) >> 32);
+        }
+        const int u = in.W0 + (int)(p % in.wi), vv = in.H0 + (int)(p / in.wi);
+        dc[0] = ((float)u - in.cx) / in.fx; dc[1] = -((float)vv - in.cy) / in.fy; dc[2] = -1.0f;
+        float R[9]; quat_rot(pose, R);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d3[k] = (dc[0] * R[k * 3] + dc[1] * R[k * 3 + 1]) + dc[2] * R[k * 3 + 2]; o3[k] = pose[4 + k]; }
+        px = (int64_t)vv * W + u;
+        gt = depth_img[px];
+        const float fg = c_free * gt, sb = gt - surf_off;
+        int rank;
+        if (j < n_strat) {
+            v = fg * t_uni[j];
+            rank = j;
+            for (int k = 0; k < n_imp; ++k) rank += ((sb + surf_span * t_surf[k]) < v) ? 1 : 0;
+        } else {
+            const int k = j - n_strat;
+            v = sb + surf_span * t_surf[k];
+            rank = k;
+            for (int i = 0; i < n_strat; ++i) rank += ((fg * t_uni[i]) <= v) ? 1 : 0;
+        }
+        zs[rl * S + rank] = v;
+    }
+    __syncthreads();
+    if (active) {
+        const float* z = zs + rl * S;
+        float out = z[j];
+        if (perturb) {
+            const float lower = j > 0 ? 0.5f * (z[j] + z[j - 1]) : z[0];
+            const float upper = j < S - 1 ? 0.5f * (z[j + 1] + z[j]) : z[S - 1];
+            const float u = t_rand ? t_rand[ray * S + j] : uniform24(seed, (uint64_t)(ray * S + j));
+            out = lower + (upper - lower) * u;
+        }
+        z_vals[ray * S + j] = out;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p = o3[k] + d3[k] * out;
+            pts[(ray * S + j) * 3 + k] = (p - bd.lo[k]) / bd.span[k];
+        }
+        if (j == 0) {
+            float far = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float t0 = (bd.lo[k] - o3[k]) / d3[k], t1 = (bd.hi[k] - o3[k]) / d3[k];
+                far = fminf(far, fmaxf(t0, t1));
+                dirs[ray * 3 + k] = dc[k];
+                gt_color[ray * 3 + k] = color_img[px * 3 + k];
+                if (rays_o) { rays_o[ray * 3 + k] = o3[k]; rays_d[ray * 3 + k] = d3[k]; }
+            }
+            gt_depth[ray] = gt;
+            valid[ray] = (far >= gt) && (gt > 0.0f) ? 1 : 0;     // Tracker.py:177-184: inside the box AND a depth measurement
+        }
     }
 }
 
@@ -1404,5 +1533,71 @@ extern "C" int us_adam_step_dev(float* p, const float* g, float* m, float* v, in
     hipLaunchKernelGGL(k_adam_dev, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1,
                        (float)beta2, (float)eps, step_dev);
     US_CHECK_LAUNCH("us_adam_step_dev");
+    return US_OK;
+}
+
+extern "C" int us_track_sample(const float* pose, const int64_t* pix, int64_t n_rays, const float* intr_host4, int W0, int H0, int crop_w,
+                               int crop_h, const float* depth_img, const float* color_img, int W, const float* bound_host, const float* t_uni,
+                               int n_strat, const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
+                               uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
+                               float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(pose && intr_host4 && depth_img && color_img && bound_host && t_uni && t_surf && dirs && gt_depth && gt_color && valid && z_vals && pts,
+               US_ERR_NULL, "us_track_sample: NULL pointer");
+    US_REQUIRE((rays_o != nullptr) == (rays_d != nullptr), US_ERR_NULL, "us_track_sample: rays_o and rays_d together or neither");
+    const int S = n_strat + n_imp;
+    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_track_sample: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
+    US_REQUIRE(crop_w >= 1 && crop_h >= 1 && W >= 1 && (int64_t)crop_w * crop_h < (1ll << 31), US_ERR_SHAPE, "us_track_sample: bad image shape");
+    Intr in; in.fx = intr_host4[0]; in.fy = intr_host4[1]; in.cx = intr_host4[2]; in.cy = intr_host4[3]; in.W0 = W0; in.H0 = H0; in.wi = crop_w;
+    const int rpb = 256 / S;
+    hipLaunchKernelGGL(k_track_sample, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float), (hipStream_t)stream, pose,
+                       pix, n_rays, in, crop_h, depth_img, color_img, W, make_bound3x(bound_host), t_uni, n_strat, t_surf, n_imp, c_free, surf_off,
+                       surf_span, t_rand, (unsigned long long)rng_seed, rng_counter, perturb, rays_o, rays_d, dirs, gt_depth, gt_color, valid,
+                       z_vals, pts, rpb);
+    US_CHECK_LAUNCH("us_track_sample");
+    return US_OK;
+}
+
+// the tracking loss (mode US_LOSS_TRK_ORIGINAL: the 10 x median gate) around the compositing in 2 + 1 launches
+extern "C" int us_track_loss_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, const uint8_t* valid,
+                                 const float* gt_depth, const float* gt_color, double truncation, float* term, float* pixel_unc, float* depth,
+                                 float* rgb, float* depth_unc, float* partials, float* err, float* median, float* stats, void* stream) {
+    US_REQUIRE(n_rays >= 1 && n_rays <= MEDIAN_MAX, US_ERR_SHAPE, "us_track_loss_fwd: n_rays %lld not in 1..%d", (long long)n_rays, MEDIAN_MAX);
+    US_REQUIRE(raw && z_vals && beta && gt_depth && gt_color && term && pixel_unc && depth && rgb && depth_unc && partials && err && median && stats,
+               US_ERR_NULL, "us_track_loss_fwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_track_loss_fwd: n_samples %d not in 1..128", n_samples);
+    LossFwd lf{1, US_LOSS_TRK_ORIGINAL, valid, gt_depth, gt_color, (float)truncation, (float)(0.4 * truncation), partials, err};
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_fwd<1>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, (float*)nullptr, lf);
+    else
+        hipLaunchKernelGGL((k_composite_fwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, term, pixel_unc, depth, rgb, depth_unc, (float*)nullptr, lf);
+    US_CHECK_LAUNCH("us_track_loss_fwd");
+    hipLaunchKernelGGL(k_track_gate_reduce, dim3(1), dim3(1024), 0, s, err, valid, partials, (int)n_rays, median, stats);
+    US_CHECK_LAUNCH("us_track_loss_fwd(gate)");
+    return US_OK;
+}
+
+extern "C" int us_track_loss_bwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, const uint8_t* valid,
+                                 const float* gt_depth, const float* gt_color, const float* depth, const float* rgb, const float* pixel_unc,
+                                 const float* median, double truncation, const float* w5_host, const float* stats, float* d_raw, float* loss_out,
+                                 void* stream) {
+    US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_track_loss_bwd: empty batch");
+    US_REQUIRE(raw && z_vals && beta && gt_depth && gt_color && depth && rgb && pixel_unc && median && w5_host && stats && d_raw, US_ERR_NULL,
+               "us_track_loss_bwd: NULL pointer");
+    US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_track_loss_bwd: n_samples %d not in 1..128", n_samples);
+    LossBwd lb{};
+    lb.enabled = 1; lb.mode = US_LOSS_TRK_ORIGINAL; lb.valid = valid; lb.gt_depth = gt_depth; lb.gt_color = gt_color; lb.depth = depth; lb.rgb = rgb;
+    lb.unc = pixel_unc; lb.tr = (float)truncation; lb.tr04 = (float)(0.4 * truncation); lb.stats = stats; lb.loss_out = loss_out; lb.median = median;
+    for (int k = 0; k < 5; ++k) lb.lw.w[k] = w5_host[k];
+    dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float* nul = nullptr; float* nulw = nullptr;
+    if (n_samples <= 64)
+        hipLaunchKernelGGL((k_composite_bwd<1>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, nulw, nulw, lb);
+    else
+        hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, nulw, nulw, lb);
+    US_CHECK_LAUNCH("us_track_loss_bwd");
     return US_OK;
 }

@@ -54,7 +54,7 @@ class TrackStep:
         self.g_sdf, self.g_depth, self.g_rgb = f(R, S), f(R), f(R, 3)
         self.g_o, self.g_d = f(R, 3), f(R, 3)
         self.partials = f(int(L.lib().us_loss_partials_size(R)))
-        self.stats, self.loss, self.median = f(10), f(1), f(1)
+        self.stats, self.loss, self.median, self.err = f(10), f(1), f(1), f(R)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
 
     def _decoder_params(self):
@@ -210,24 +210,80 @@ class TrackStep:
 
     def iterate_fused(self, batch_size, t_rand=None, indices=None):
         """
-        One Tracker.optimize_tracking call (Tracker.py:149-244) with everything on the device: pixel draw, pose -> rays
-        (us_pose_rays), render + loss + backward, rays -> pose gradient (us_pose_grad) and Adam on the 7 pose numbers
-        (us_adam_step_dev).  Returns (loss[1], pixel_unc[R], valid[R]); the updated pose is self.pose.
+        One Tracker.optimize_tracking call (Tracker.py:149-244) with everything on the device.  Returns (loss[1], pixel_unc[R],
+        valid[R]); the updated pose is self.pose.  Where the model qualifies (two F = 2 grids of one geometry, a decoder pair, the
+        'original' mask, <= 8192 rays of <= 128 samples) the iteration is NINE launches:
+            us_track_sample              pixel draw (indices None) + pose -> rays + pre-filter + z + points
+            us_hashgrid_fwd_joint_dydx   both encoders + d(features)/d(position)
+            us_mlp_fwd_pair              both decoders
+            us_track_loss_fwd            compositing + per-ray loss partials | median gate + statistics (one workgroup)
+            us_track_loss_bwd            loss gradients + compositing backward
+            us_mlp_bwd_pair              both decoders' input gradients
+            us_hashgrid_dydx_rays        dL/d(points) contracted from dy/dx and reduced to dL/d(rays_o), dL/d(rays_d)
+            us_pose_window_step          pose gradient + Adam on the 7 numbers (step count included)
+        otherwise the general chain (us_pose_rays + forward_backward + the pose step).
         """
         lib, st, P = L.lib(), L.stream(), L.ptr
         H, W, eh, ew = self.frame
         H0, H1, W0, W1 = eh, H - eh, ew, W - ew
         n = int(batch_size)
-        if indices is None:
-            indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.device)              # common.py:116
-        if not hasattr(self, "t_ro") or self.t_ro.shape[0] != n:
-            f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
-            self.t_ro, self.t_rd, self.t_dirs, self.t_gd, self.t_gc = f(n, 3), f(n, 3), f(n, 3), f(n), f(n, 3)
-        L.check(lib.us_pose_rays(P(self.pose), P(indices.contiguous()), n, self.intr, W0, H0, W1 - W0, P(self.img_d), P(self.img_c), W,
-                                 P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
-        loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
-        # pose gradient (closed-form chain rule through R(q)) + Adam on the 7 numbers, step count included: one launch
+        if n > self.max_rays:
+            self._alloc(n)
+        S, N = self.S, n * self.S
+        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
+        if self._joint is None:
+            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
+        fast = (getattr(self, "fast_path", True) and self._joint and self.mode == 2 and n <= 8192 and S <= 128 and bool(lib.us_mlp_pair_supported(ms, mc)))
         b1, b2 = self.betas
+        if not fast:
+            if indices is None:
+                indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.device)              # common.py:116
+            if not hasattr(self, "t_ro") or self.t_ro.shape[0] != n:
+                f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+                self.t_ro, self.t_rd = f(n, 3), f(n, 3)
+            self._track_inputs(n)
+            L.check(lib.us_pose_rays(P(self.pose), P(indices.contiguous()), n, self.intr, W0, H0, W1 - W0, P(self.img_d), P(self.img_c), W,
+                                     P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
+            loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
+            L.check(lib.us_pose_window_step(P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv),
+                                            P(self.g_pose), self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st),
+                    "us_pose_window_step")
+            return loss, unc, valid
+        self._track_inputs(n)
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        ts, tc = L.f32(self.es.params.detach()), L.f32(self.ec.params.detach())
+        tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
+        self.rng_calls = getattr(self, "rng_calls", 0) + 1
+        seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1)
+        pix = P(indices.contiguous()) if indices is not None else None
+        L.check(lib.us_track_sample(P(self.pose), pix, n, self.intr, W0, H0, W1 - W0, H1 - H0, P(self.img_d), P(self.img_c), W, self.bhost,
+                                    P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation),
+                                    ctypes.c_float(3 * self.truncation), tr, seed, P(self.pstep), 1 if self.perturb else 0, None, None,
+                                    P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st), "us_track_sample")
+        if self.dydx_s is None:
+            self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+            self.dydx_c = torch.empty_like(self.dydx_s)
+        L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c),
+                                               3, None, 0, st), "us_hashgrid_fwd_joint_dydx")
+        L.check(lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st),
+                "us_mlp_fwd_pair")
+        L.check(lib.us_track_loss_fwd(P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), self.truncation,
+                                      P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.err),
+                                      P(self.median), P(self.stats), st), "us_track_loss_fwd")
+        L.check(lib.us_track_loss_bwd(P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), P(self.depth),
+                                      P(self.rgb), P(self.unc), P(self.median), self.truncation, self.w5, P(self.stats), P(self.d_raw),
+                                      P(self.loss), st), "us_track_loss_bwd")
+        L.check(lib.us_mlp_bwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
+                                    off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st),
+                "us_mlp_bwd_pair")
+        L.check(lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), n, S, P(self.z),
+                                          self.bhost, P(self.g_o), P(self.g_d), None, st), "us_hashgrid_dydx_rays")
         L.check(lib.us_pose_window_step(P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose),
                                         self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st), "us_pose_window_step")
-        return loss, unc, valid
+        return self.loss, self.unc[:n], self.valid[:n]
+
+    def _track_inputs(self, n):
+        if not hasattr(self, "t_dirs") or self.t_dirs.shape[0] != n:
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+            self.t_dirs, self.t_gd, self.t_gc = f(n, 3), f(n), f(n, 3)
