@@ -233,7 +233,10 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
     centre = bound.mean(dim=1)
     pose = torch.tensor([[0.9, 0.1, -0.2, 0.3, float(centre[0]), float(centre[1]), float(centre[2])]], device=dev)
     ts = us.TrackStep(es, ec, dec, bound, 32, 8, 0.06, dict(fs=10, center=200, tail=50, color=5, depth=1), max_rays=2000)
-    out = {"workload": "Replica tracking iteration: 2000 rays x 40 samples, pose Adam, fused (pose->rays, pose gradient and pose Adam as HIP kernels)"}
+    out = {"workload": "Replica tracking iteration (src/Tracker.py:149-244): 2000 rays x 40 samples of a 680x1200 frame, 10 x median gate, pose Adam; "
+                       "nine HIP launches (TrackStep.iterate_fused: pixel draw + pose->rays + sampling | encoders + dy/dx | decoder pair | "
+                       "compositing + loss partials | median gate + statistics | loss gradients + compositing backward | decoder pair backward | "
+                       "dy/dx contraction to the rays | pose gradient + Adam)"}
     try:
         ts.begin_frame(pose[0], gt_color[0], gt_depth[0], 2e-3, 1e-3, H, Wd, fx, fy, cx, cy, 75, 75)
         fstep = lambda: ts.iterate_fused(2000)
@@ -256,8 +259,62 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
         torch.cuda.synchronize()
         fg = 1e3 * (time.perf_counter() - t0) / iters
         out.update({"fused_graph_ms_per_iter": fg, "fused_graph_rays_per_s": 2000 / (fg / 1e3), "fused_graph_final_loss": float(loss)})
+        # the kernels' own durations (HIP events around every launch of 20 eager iterations) and the roofline entry of the dominant one
+        ts.probe = {}
+        for _ in range(20):
+            fstep()
+        torch.cuda.synchronize()
+        kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ts.probe.items()}
+        ts.probe = None
+        out["launches_per_iteration"] = len(kern)
+        out["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
+        N = 2000 * 40
+        enc = "us_hashgrid_fwd_joint_dydx"
+        if enc in kern:
+            alg = 2 * 1024 * N                                    # both encoders' gathers (1024 B per point and grid)
+            ach = alg / (kern[enc] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": enc, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern[enc],
+                               "note": "gather bytes only; the launch also writes 2 x 24 B per point and level of dy/dx for the pose gradient"}
     except Exception as e:                                # report, do not hide
         out["fused_error"] = repr(e)[:300]
+    return out
+
+
+def joint_opt_bench(us, build_step, bound, dev, steps, warmup):
+    """
+    The reference's STEADY-STATE mapping iteration: joint_opt (configs/UNISLAM.yaml:50) is on from the fifth keyframe (src/Mapper.py:519),
+    so the window's camera poses are a fourth Adam group and every iteration also runs poses -> rays and rays -> pose gradients
+    (src/Mapper.py:359-376,443-459).  window.MapWindow: poses on the device, the iteration replayed from one hipGraph; a fresh pixel
+    draw per step.  Two shapes: 4096 rays over 16 keyframes (the headline's batch), and the > 20-keyframe batch of src/Mapper.py:385-393
+    (25 frames x 160 pixels + 10 x 200 extra rays from the newest frames = 6000 rays).
+    """
+    out = {}
+    for tag, b, n_per, extra in (("4096_rays_16_keyframes", N_KEYFRAMES, 4096 // N_KEYFRAMES, None), ("6000_rays_25_keyframes_extra_10x200", 25, 160, (10, 200))):
+        try:
+            step = build_step()[0]
+            c2ws, pd, pc, pr = keyframe_pools(b, bound, 2000, dev)
+            win = us.MapWindow(step, c2ws, pd, pc, pr, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=False)
+            win.capture()
+            for _ in range(warmup):
+                win.replay()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = win.replay()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            moved = float((win.c2ws() - c2ws).abs().max())
+            step.probe, step.probe_every, step._it = {}, 1, 0
+            for _ in range(10):
+                win.iterate()
+            torch.cuda.synchronize()
+            kern = {k: round(sum(a.elapsed_time(c) for a, c in v) / len(v), 4) for k, v in sorted(step.probe.items())}
+            step.probe = None
+            out[tag] = {"joint_opt_iteration_ms": ms, "rays": win.R, "rays_per_s": win.R / (ms / 1e3), "final_loss": float(loss),
+                        "launch": "hipGraph replay of MapWindow (poses, pose Adam state and pixel indices on the device)",
+                        "max_pose_matrix_change": moved, "kernel_ms": kern}
+        except Exception as e:                            # report, do not hide
+            out[tag] = {"error": repr(e)[:300]}
     return out
 
 
@@ -401,7 +458,9 @@ def run_rank(args):
                "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: Replica room0, 4096 rays x 64 samples (48 stratified + 16 surface), "
                                       "L=16 F=2 hash grids log2T 16 (sdf) / 19 (colour) res 816, 2 hidden x %d MLP decoders with bias, "
-                                      "mapping iteration = pixel draw+ray gather+sample+encode+decode+composite+loss+backward+dense Adam" % args.hidden,
+                                      "mapping iteration = pixel draw+ray gather+sample+encode+decode+composite+loss+backward+dense Adam, camera poses "
+                                      "fixed (joint_opt off: the iteration of the first five keyframes, src/Mapper.py:519; the joint_opt iteration, "
+                                      "which also optimises the window's poses, is timed beside it under `joint_opt`)" % args.hidden,
                           "rays_per_gpu": R, "samples_per_ray": S, "points_per_gpu": N, "n_params": int(step.n_flat),
                           "batch": (f"fresh per step: {n_per} pixels from each of {N_KEYFRAMES} keyframe pools of {P} pixels (us_gather_rays inside the timed step)"
                                     if fresh else "one fixed batch re-rendered every step"),
@@ -465,6 +524,8 @@ def run_rank(args):
                 rec["fp32_decoders"] = side_run(build_step("fp32")[0])
             # tables with "trained-like" N(0, 0.1) entries: alpha is no longer degenerate, the gradients are dense in value
             rec["trained_like_tables"] = side_run(build_step(args.mlp_precision, table_std=0.1)[0])
+        if world == 1 and not args.no_extras:
+            rec["joint_opt"] = joint_opt_bench(us, lambda: build_step(args.mlp_precision), bound, dev, args.steps, args.warmup)
         if world == 1 and not args.no_tracking:
             rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
         if world == 1 and not args.no_cpu_baseline:

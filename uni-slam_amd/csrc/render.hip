@@ -837,10 +837,25 @@ __global__ __launch_bounds__(1024) void k_track_gate_reduce(const float* __restr
     double acc[LOSS_NSTAT];
 #pragma unroll
     for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        if ((!valid || valid[i]) && err[i] < thr) {
+    // the gate comes from the keys in LDS (0xFFFFFFFF = not pre-filtered in); the ten partials of a ray are five unconditional 8-byte
+    // loads, two rays in flight per thread: one round trip to memory instead of a dependent chain
+    static_assert(LOSS_NSTAT == 10, "five float2 per ray");
+    for (int i0 = threadIdx.x; i0 < n; i0 += 2048) {
+        float2 p[2][5]; bool gate[2];
 #pragma unroll
-            for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] += (double)partials[(int64_t)i * LOSS_NSTAT + k];
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 1024 * u;
+            const bool in = i < n;
+            const uint32_t k = in ? key[i] : 0xFFFFFFFFu;
+            gate[u] = k != 0xFFFFFFFFu && __uint_as_float(k) < thr;
+            const float2* src = reinterpret_cast<const float2*>(partials + (int64_t)(in ? i : 0) * LOSS_NSTAT);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) p[u][q] = src[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { acc[2 * q] += gate[u] ? (double)p[u][q].x : 0.0; acc[2 * q + 1] += gate[u] ? (double)p[u][q].y : 0.0; }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -63,10 +63,11 @@ struct PoseStep {
     int     apply;              // 0: gradient only
 };
 
-__global__ __launch_bounds__(256) void k_pose_window_step(float* __restrict__ poses7, const float* __restrict__ g_o, const float* __restrict__ g_d,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pose_window_step(float* __restrict__ poses7, const float* __restrict__ g_o, const float* __restrict__ g_d,
                                                           const float* __restrict__ dirs, float* __restrict__ m7, float* __restrict__ v7,
                                                           float* __restrict__ g7_out, float* __restrict__ step_dev, PoseStep ps) {
-    __shared__ double sh[12][4];
+    __shared__ double sh[12][THREADS / 64];
     __shared__ float g7[7];
     const int j = blockIdx.x;
     double acc[12];
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pose_window_step(float* __restrict__ po
         int64_t n, r0;
         if (seg == 0) { n = ps.nA; r0 = ps.rowA + (int64_t)j * ps.nA; }
         else { if (ps.nB == 0 || j < ps.jB) break; n = ps.nB; r0 = ps.rowB + (int64_t)(j - ps.jB) * ps.nB; }
-        for (int64_t t = threadIdx.x; t < n; t += 256) {
+        for (int64_t t = threadIdx.x; t < n; t += THREADS) {
             const int64_t r = r0 + t;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -98,7 +99,11 @@ __global__ __launch_bounds__(256) void k_pose_window_step(float* __restrict__ po
     float* pose = poses7 + (int64_t)j * 7;
     if (threadIdx.x == 0) {
         float G[9], gt[3];
-        for (int k = 0; k < 12; ++k) { const double v = ((sh[k][0] + sh[k][1]) + sh[k][2]) + sh[k][3]; if (k < 9) G[k] = (float)v; else gt[k - 9] = (float)v; }
+        for (int k = 0; k < 12; ++k) {
+            double v = 0.0;
+            for (int w = 0; w < THREADS / 64; ++w) v += sh[k][w];
+            if (k < 9) G[k] = (float)v; else gt[k - 9] = (float)v;
+        }
         const float r = pose[0], i = pose[1], jj = pose[2], k = pose[3];
         const float s = 2.0f / (r * r + i * i + jj * jj + k * k);
         const float M[9] = {-(jj * jj + k * k), i * jj - k * r, i * k + jj * r, i * jj + k * r, -(i * i + k * k), jj * k - i * r,
@@ -179,8 +184,12 @@ extern "C" int us_pose_window_step(float* poses7, int n_poses, const float* g_ra
     ps.nA = n_a; ps.rowA = row_a; ps.nB = n_b; ps.rowB = row_b; ps.jB = first_pose_b;
     ps.lr_q = (float)lr_q; ps.lr_t = (float)lr_t; ps.b1 = (float)beta1; ps.b2 = (float)beta2; ps.eps = (float)eps;
     ps.own_step = own; ps.apply = apply;
-    hipLaunchKernelGGL(k_pose_window_step, dim3((unsigned)n_poses), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
-                       g7_out, step_dev, ps);
+    // one pose over thousands of rays (the tracker): one wide workgroup; a window of poses over a few hundred rays each: 256 threads per pose
+    if (n_poses == 1 && n_a + n_b > 1024)
+        hipLaunchKernelGGL(k_pose_window_step<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7, g7_out, step_dev, ps);
+    else
+        hipLaunchKernelGGL(k_pose_window_step<256>, dim3((unsigned)n_poses), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
+                           g7_out, step_dev, ps);
     US_CHECK_LAUNCH("us_pose_window_step");
     return US_OK;
 }
