@@ -90,6 +90,13 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
  * does not see: results repeat bit for bit from run to run (tests/test_gpu_joint.py).  Slower when the batch concentrates on few
  * cells (one workgroup then walks a hot bin alone); meant for diffing runs. */
 #define US_GRID_BWD_DETERMINISTIC 128
+/* US_GRID_BWD_ONLY_A / US_GRID_BWD_ONLY_B (us_hashgrid_bwd_joint): the record pass for both grids, the accumulate pass -- and so the
+ * finished gradient table -- for ONE of them; a second call with the other flag and US_GRID_BWD_RECORDS_READY (same workspace, nothing
+ * in between) sums the other grid from the records the first call left.  The data-parallel step finishes the colour table first and
+ * lets its all-reduce travel while the sdf table is summed (src/Mapper.py:444 on N ranks).  Same results as one call. */
+#define US_GRID_BWD_ONLY_A 256
+#define US_GRID_BWD_ONLY_B 512
+#define US_GRID_BWD_RECORDS_READY 1024
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 

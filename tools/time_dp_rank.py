@@ -1,6 +1,6 @@
 """development: python tools/time_dp_rank.py -- what ONE rank of the data-parallel step costs (4096 rays x 64, room0 tables, bf16 decoders): a
-1-rank RCCL group, so the collectives are issued and waited for but move nothing; MapStep(group=True) with its default (one-grid
-kernels, one stream, colour table first) against the joint kernels, and the single-process step (eager) beside them.  ms per step."""
+1-rank RCCL group, so the collectives are issued and waited for but move nothing; MapStep(group=True) in its two
+dp_modes, and the single-process step (eager) beside them.  ms per step."""
 import os, sys, time
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import torch, torch.distributed as dist
@@ -42,8 +42,10 @@ def timed(fn, k=100):
     return round(1e3 * (time.perf_counter() - t) / k, 4)
 
 out = {}
-for name, kw in (("dp default", dict(group=True)), ("dp joint", dict(group=True, joint=True)), ("dp joint + side streams", dict(group=True, joint=True, overlap=True)),
-                 ("dp one-grid + two streams", dict(group=True, overlap=True))):
+for name, kw in (("dp local_fast (default: joint kernels, side streams, accumulate split per grid)", dict(group=True)),
+                 ("dp colour_first (one-grid kernels, one stream)", dict(group=True, dp_mode="colour_first")),
+                 ("dp local_fast, one stream", dict(group=True, overlap=False)),
+                 ("dp one-grid + two streams", dict(group=True, dp_mode="colour_first", overlap=True))):
     st = build(**kw)
     out[name] = timed(lambda: dp_iterate(st, (ro, rd, gd, gc, None, False), group=True))
 st = build()

@@ -20,6 +20,9 @@ US_GRID_BWD_COUNTED = 16
 US_GRID_BWD_PACKED = 32
 US_GRID_BWD_SCANNED = 64
 US_GRID_BWD_DETERMINISTIC = 128
+US_GRID_BWD_ONLY_A = 256
+US_GRID_BWD_ONLY_B = 512
+US_GRID_BWD_RECORDS_READY = 1024
 US_MLP_LEVEL_MAJOR = 1
 US_MLP_DEFER_REDUCE = 2
 US_LOSS_DEFER_BETA = 256

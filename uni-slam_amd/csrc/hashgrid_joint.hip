@@ -785,7 +785,9 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
                                                             const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
                                                             const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
                                                             const uint32_t* __restrict__ rec, float* __restrict__ gradA,
-                                                            float* __restrict__ gradB, int overwrite) {
+                                                            float* __restrict__ gradB, int overwrite, int side_sel) {
+    // side_sel: -1 both grids' items; 0 / 1: the items of grid A / B only (the data-parallel step finishes the colour table first, so
+    // that its all-reduce travels while the sdf table is summed)
     __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
     __shared__ uint32_t items[JI_FIELDS][J_ACCP_MAXI];           // items with records, in the order they are taken
     __shared__ uint32_t zitems[JI_FIELDS][J_ACCP_MAXI];          // OVERWRITE: bins nothing landed in (their entries get a zero gradient)
@@ -793,8 +795,8 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < J_ACC_DOUBLES + 4 * 8; k += J_ACC_THREADS) acc[k] = 0.0;
     if (tid < 64) {                                              // wave 0, lane i: the workgroup's i-th item
-        const uint32_t T = 2u * (e_max + TB), t = blockIdx.x + tid * gridDim.x;
-        const uint32_t side = t & 1u, slot = t >> 1;
+        const uint32_t T = (side_sel < 0 ? 2u : 1u) * (e_max + TB), t = blockIdx.x + tid * gridDim.x;
+        const uint32_t side = side_sel < 0 ? (t & 1u) : (uint32_t)side_sel, slot = side_sel < 0 ? (t >> 1) : t;
         const uint32_t CH = hdr[1];                              // records per item (k_jscan)
         bool ok = t < T && tid < J_ACCP_MAXI;
         uint32_t b = 0, chunk = 0;
@@ -1179,18 +1181,24 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, chunk0);
     }
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
-    hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                       w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
+    const int side_sel = (flags & US_GRID_BWD_ONLY_A) ? 0 : ((flags & US_GRID_BWD_ONLY_B) ? 1 : -1);
+    US_REQUIRE(!((flags & US_GRID_BWD_ONLY_A) && (flags & US_GRID_BWD_ONLY_B)), US_ERR_CONFIG, "us_hashgrid_bwd_joint: ONLY_A and ONLY_B are exclusive");
+    US_REQUIRE(!(flags & US_GRID_BWD_RECORDS_READY) || (side_sel >= 0 && !adam), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
+    US_REQUIRE(side_sel < 0 || !adam, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: both grids in one call");
+    if (!(flags & US_GRID_BWD_RECORDS_READY))
+        hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
+                           w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
     JAdam ad;
     memset(&ad, 0, sizeof(ad));
     if (adam) {
         US_REQUIRE(overwrite, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: needs US_GRID_BWD_OVERWRITE (the update uses the complete gradient)");
         ad = *adam; ad.enabled = 1;
     }
-    const uint32_t n_acc_items = 2u * (ACC_EXTRA_MAX + (uint32_t)TB);
+    const uint32_t n_acc_items = (side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB);
     if (!adam)
         hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                           (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite);
+                           (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite, side_sel);
     else
         hipLaunchKernelGGL(k_jaccum, dim3(n_acc_items), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
                            w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad);

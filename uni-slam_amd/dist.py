@@ -37,22 +37,30 @@ def dp_iterate(engine, batch, group=None, grad_comm=None):
     launched so far) and overlaps with the rest of the backward pass.  MapStep finishes the 44.7 MB colour-table segment
     first, so its reduction hides behind the SDF decoder + SDF table backward; all segments are waited for before Adam.
     """
-    engine.forward(*batch)
-    if group is not None:
-        dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
     if grad_comm is None:
         grad_comm = getattr(engine, "grad_comm", None)
     narrow = grad_comm in ("bf16", torch.bfloat16)
-    if group is not None and getattr(engine, "sharded_adam", False):
-        if narrow:
-            raise ValueError("dp_iterate: a bf16 gradient payload and sharded Adam are exclusive (the reduce-scatter works in place "
-                             "on the fp32 gradient buffer)")
+    sharded = group is not None and getattr(engine, "sharded_adam", False)
+    if sharded and narrow:                              # refused before any work is queued
+        raise ValueError("dp_iterate: a bf16 gradient payload and sharded Adam are exclusive (the reduce-scatter works in place "
+                         "on the fp32 gradient buffer)")
+    engine.forward(*batch)
+    if group is not None:
+        dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
+    if sharded:
         return _finish_sharded(engine, group)
     works = []
 
     def on_ready(view):
         if group is not None:
-            buf = view.to(torch.bfloat16) if narrow else view
+            buf = view
+            if narrow:                                  # one bf16 image of the gradient buffer, allocated once: its slices are the payloads
+                img = getattr(engine, "_grad_bf16", None)
+                if img is None or img.shape != engine.grad.shape or img.device != engine.grad.device:
+                    img = engine._grad_bf16 = torch.empty_like(engine.grad, dtype=torch.bfloat16)
+                lo = (view.data_ptr() - engine.grad.data_ptr()) // view.element_size()
+                buf = img[lo:lo + view.numel()]
+                buf.copy_(view)
             works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True), view, buf))
 
     loss = engine.backward(on_ready)

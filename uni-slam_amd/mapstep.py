@@ -36,16 +36,15 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30, fuse_adam=False):
+                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30, fuse_adam=False, dp_mode="local_fast"):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
         lr: dict(decoders, sdf_grid, color_grid)        (cfg['mapping']['lr'], src/Mapper.py:123-126);
         group: None | True (default process group) | a torch.distributed group -> data-parallel over ranks.
         joint: encode both grids in one launch and form both table gradients in one binned pass (us_hashgrid_fwd_joint /
-                 us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes for a single process when the pair of
-                 grids qualifies; no with a process group, where the colour table's gradient is finished FIRST so that its all-reduce
-                 hides behind the sdf branch (a joint pass would finish both tables at the same moment, with nothing left to hide behind).
+                 us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes when the pair of grids qualifies (with a
+                 process group: see dp_mode -- the accumulate pass is then split per grid, the colour table first).
                  Measured at 4096 x 64 (room0 tables): the iteration takes the same 0.66 ms either way -- the two one-grid chains overlap on
                  two streams -- but the table gradient itself is 262 us for both grids against 157 + 147; render-only calls
                  (backward_follows=False) run the joint encoder without counts and both decoders in one launch (render_joint).
@@ -57,7 +56,15 @@ class MapStep:
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
         self.es, self.ec, self.dec = hash_grid_sdf, hash_grid_color, decoders
-        self.overlap, self.side, self.scan_stream = (group is None) if overlap is None else bool(overlap), None, None
+        # dp_mode (with a process group, when joint / overlap are left to default): "local_fast" -- the single-process kernels (joint
+        # encoder + joint record pass, side streams for the scans and small reductions) with the accumulate pass split per grid, colour
+        # first, so that the colour table's all-reduce travels behind the sdf table's accumulate pass; "colour_first" -- the one-grid kernels
+        # on one stream, colour branch before sdf branch: a longer cover for that all-reduce (the whole sdf branch) at a higher cost per rank.
+        if dp_mode not in ("local_fast", "colour_first"):
+            raise L.UniSlamHipError(f"MapStep: dp_mode {dp_mode!r} not in ('local_fast', 'colour_first')")
+        self.dp_mode = dp_mode
+        fast_default = group is None or dp_mode == "local_fast"
+        self.overlap, self.side, self.scan_stream = fast_default if overlap is None else bool(overlap), None, None
         # opt-in: render-only calls (forward(backward_follows=False)) as ONE launch (us_encode_decode_fwd: both grids, both decoders, the features
         # kept in LDS) where the model qualifies.  Bit-identical, but measured slower than the four launches (0.20 against 0.18 ms at 4096 x 64:
         # csrc/encode_decode.inc), so off.
@@ -79,7 +86,7 @@ class MapStep:
         # accumulate pass grows from 106 to 203 us -- a bin's entries are 128-byte lines 32 KB apart, and six arrays of such lines do not
         # stream like the dense pass's contiguous 6 TB/s -- against the 60 us the separate pass costs: 0.690 instead of 0.612 ms.  Off.
         self.fuse_adam = bool(fuse_adam)
-        self._joint_wanted = (group is None) if joint is None else bool(joint)
+        self._joint_wanted = fast_default if joint is None else bool(joint)
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
         self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
@@ -467,7 +474,7 @@ class MapStep:
         binned = self.ws is not None
         # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
         # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
-        defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing and self.group is None)
+        defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing)
         clear_later = False
         if self.bwd_mode not in (-1, 3):
             self.grad.zero_()
@@ -558,14 +565,22 @@ class MapStep:
                     P(self.ws), self.ws_bytes, off(fl, self.o_tab_s), off(fl, self.o_tab_c), off(self.m, self.o_tab_s), off(self.m, self.o_tab_c),
                     off(self.v, self.o_tab_s), off(self.v, self.o_tab_c), self.lr["sdf_grid"] * f_, self.lr["color_grid"] * f_, 0.9, 0.999, 1e-8,
                     P(self.step_dev), st))
+            elif on_ready is not None:
+                # someone waits for the segments (the data-parallel step): the record pass for both grids, then the accumulate pass per
+                # grid, colour first -- its 44.7 MB all-reduce starts while the sdf table is still being summed
+                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
+                                                                                    off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                                                    jflags | L.US_GRID_BWD_ONLY_B, P(self.ws), self.ws_bytes, st))
+                on_ready(self.grad[self.o_tab_c:])
+                self._timed("hashgrid_bwd_joint_sdf", lambda: lib.us_hashgrid_bwd_joint(
+                    ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                    jflags | L.US_GRID_BWD_ONLY_A | L.US_GRID_BWD_RECORDS_READY, P(self.ws), self.ws_bytes, st))
             else:
                 self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
                                                                                     P(self.ws), self.ws_bytes, st))
             if defer:
                 self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
-            if on_ready is not None:
-                on_ready(self.grad[self.o_tab_c:])
         elif self.overlap and not self._probing:
             with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
                 sdf_branch(st2)
