@@ -58,6 +58,10 @@ def parse_args(argv=None):
                     help="payload type of the gradient all-reduce (N > 1); bf16 halves the xGMI bytes, not bit-faithful to one process")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
+    ap.add_argument("--dp-mode", default="local_fast", choices=["local_fast", "colour_first"],
+                    help="N > 1: local_fast = the single-process kernels with the accumulate pass split per grid (0.59 ms of rank-local work, the "
+                         "colour table's all-reduce hides behind ~55 us); colour_first = one-grid kernels, colour branch before sdf branch (0.67 ms, "
+                         "~176 us of cover): the better choice once that all-reduce takes more than ~130 us (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help="run the sdf and colour branches on one stream")
     ap.add_argument("--no-decoder-pair", action="store_true", help="the two decoders as two launches each way instead of one (MapStep.decoder_pair)")
     ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
@@ -185,6 +189,12 @@ def keyframe_pools(n_frames, bound, seed, device):
     return st(c2ws), st(depths), st(colors), st(dirs_all)
 
 
+def _median(xs):
+    """median launch duration of a probe pass (a first launch that pays for lazy set-up does not move it)"""
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
 def cpu_baseline(bound, n_strat, n_imp, hidden, rays, budget_s=20.0):
     """the CPU oracle port of the same iteration (oracle/unislam_oracle.py) on the host cores; bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -264,7 +274,7 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
         for _ in range(20):
             fstep()
         torch.cuda.synchronize()
-        kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ts.probe.items()}
+        kern = {k: _median([a.elapsed_time(b) for a, b in v]) for k, v in ts.probe.items()}
         ts.probe = None
         out["launches_per_iteration"] = len(kern)
         out["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
@@ -308,7 +318,7 @@ def joint_opt_bench(us, build_step, bound, dev, steps, warmup):
             for _ in range(10):
                 win.iterate()
             torch.cuda.synchronize()
-            kern = {k: round(sum(a.elapsed_time(c) for a, c in v) / len(v), 4) for k, v in sorted(step.probe.items())}
+            kern = {k: round(_median([a.elapsed_time(c) for a, c in v]), 4) for k, v in sorted(step.probe.items())}
             step.probe = None
             out[tag] = {"joint_opt_iteration_ms": ms, "rays": win.R, "rays_per_s": win.R / (ms / 1e3), "final_loss": float(loss),
                         "launch": "hipGraph replay of MapWindow (poses, pose Adam state and pixel indices on the device)",
@@ -362,7 +372,7 @@ def run_rank(args):
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
                         grad_comm=comm, sharded_adam=sharded, packed_records=args.packed_records,
-                        joint=None if args.joint == "auto" else args.joint == "1")
+                        joint=None if args.joint == "auto" else args.joint == "1", dp_mode=args.dp_mode)
         st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
 
@@ -441,14 +451,14 @@ def run_rank(args):
                                           c2ws, pool_d, pool_c, dev, pool_dirs, indices=idx, out=ins[:4])
             step.iterate(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False)
         torch.cuda.synchronize()
-        kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in step.probe.items()}
+        kern = {k: _median([a.elapsed_time(b) for a, b in v]) for k, v in step.probe.items()}
         step.probe = None
 
     if rank == 0:
         S = n_strat + n_imp
         N = R * S
         comm_desc = ("reduce-scatter + sharded Adam + all-gather" if sharded else "all-reduce") + \
-                    f" of {(4 if comm == 'fp32' else 2) * step.n_flat / 1e6:.1f} MB {comm} grads per step"
+                    f" of {(4 if comm == 'fp32' else 2) * step.n_flat / 1e6:.1f} MB {comm} grads per step" + (f", dp_mode {args.dp_mode}" if world > 1 else "")
         rec = {"metric": "rays/s (64 samples, L=16 hash, 2x32 MLP), Replica room0 mapping iteration",
                "value": world * R / (ms / 1e3), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
@@ -469,11 +479,13 @@ def run_rank(args):
                "launch": "hipGraph replay of MapStep.iterate" if use_graph else "eager"}
         if kern is not None:
             rec["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
-            rec["kernel_ms_note"] = f"{max(1, args.probe_steps)} eager one-stream iterations after the timed region"
+            rec["kernel_ms_note"] = f"median over {max(1, args.probe_steps)} eager one-stream iterations after the timed region"
             # algorithmic bytes per launch: forward gather 16 levels x 8 corners x 2 feat x 4 B = 1024 B/point/grid,
             # backward scatter counted read+write = 2048 B/point/grid; a launch that serves both grids moves both grids' bytes
             alg = {"hashgrid_fwd_sdf": 1024 * N, "hashgrid_fwd_color": 1024 * N, "hashgrid_bwd_sdf": 2048 * N, "hashgrid_bwd_color": 2048 * N,
                    "hashgrid_fwd_joint": 2 * 1024 * N, "hashgrid_bwd_joint": 2 * 2048 * N}
+            if "hashgrid_bwd_joint" in kern and "hashgrid_bwd_joint_sdf" in kern:      # N > 1: the accumulate pass is split per grid
+                kern["hashgrid_bwd_joint"] += kern.pop("hashgrid_bwd_joint_sdf")
             if "hashgrid_bwd_joint" in kern and "hashgrid_scan_joint" in kern:
                 # the two scan passes of the joint table gradient run beside the decoders' forward pass; they belong to the gradient
                 kern["hashgrid_bwd_joint"] += kern.pop("hashgrid_scan_joint")

@@ -863,3 +863,107 @@ def test_mapstep_render_only_in_one_launch_equals_four_launches():
         res[fused] = [t.clone() for t in step.rendered()] + [stats.clone(), step.raw[:R].clone()]
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_bench_path_replay_equals_eager_and_oracle():
+    """Exactly what bench.py builds for its headline -- MapStep joint, mlp_precision bf16, decoder pair, capture(4096), batches drawn from
+    16 keyframe pools by get_samples_all(out = the graph's static inputs) -- replayed five times against five eager iterations on the
+    same pixel indices and jitter (loss 1e-6, parameters allclose), and the first iteration against the CPU oracle (1e-3)."""
+    import bench
+    import unislam_amd as us
+    bench.torch = torch
+    bound = bench.load_bound(bench.ROOM0_BOUND)
+    pls = bench.per_level_scale(int((bound[:, 1] - bound[:, 0]).max() / 0.01))
+    R, S, nk = 4096, 64, bench.N_KEYFRAMES
+    c2ws, pool_d, pool_c, pool_dirs = bench.keyframe_pools(nk, bound, 1000, DEV)
+    P, n_per = pool_d.shape[1], R // nk
+    g = torch.Generator().manual_seed(12)
+    draws = [(torch.randint(P, (nk, n_per), generator=g).to(DEV), torch.rand(R, S, generator=g).to(DEV)) for _ in range(5)]
+    cam = bench.CAM
+
+    def build():
+        torch.manual_seed(0)
+        cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": "bf16"}}
+        dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        mk = lambda l2: us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2,
+                                                "base_resolution": 16, "per_level_scale": pls}).to(DEV)
+        es, ec = mk(16), mk(19)
+        with torch.no_grad():                                   # a non-trivial surface instead of the initial U(+-1e-4)
+            es.params.normal_(0.0, 0.1); ec.params.normal_(0.0, 0.1)
+        return us.MapStep(es, ec, dec, bound, 48, 16, 0.06, bench.W, bench.LR, max_rays=R), es, ec, dec
+
+    gather = lambda idx, out: us.common.get_samples_all(0, cam["H"], 0, cam["W"], n_per, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
+                                                        cam["cy"], c2ws, pool_d, pool_c, DEV, pool_dirs, indices=idx, out=out)
+    # ---- eager
+    step_e, es_e, ec_e, dec_e = build()
+    assert step_e.joint and step_e._decoder_pair() and step_e.overlap
+    ins_e = tuple(torch.zeros(s, device=DEV) for s in ((R, 3), (R, 3), (R,), (R, 3)))
+    # the first iteration also against the oracle: same rays, same jitter
+    gather(draws[0][0], ins_e)
+    od = O.DecodersOracle(hidden_size=32, n_blocks=2); od.load_state_dict({k: v.cpu() for k, v in dec_e.state_dict().items()})
+    oes, oec = O.HashGridOracle(3, es_e.encoding_config), O.HashGridOracle(3, ec_e.encoding_config)
+    with torch.no_grad():
+        oes.params.copy_(es_e.params.cpu()); oec.params.copy_(ec_e.params.cpu())
+    ro, rd, gd, gc = [t.cpu() for t in ins_e]
+    inside = O.bbox_far(ro, rd, bound) >= gd
+    assert bool(inside.all())                                   # the pools' depths are clipped inside the box
+    ret_o = O.render_batch_ray(([oes], [oec]), od, rd, ro, 0.06, gd, bound, 48, 16, True, {"z": draws[0][1].cpu()})
+    loss_o = O.mapping_loss(ret_o, gd, gc, 0.06, bench.W)
+    losses_e = []
+    for idx, tr in draws:
+        gather(idx, ins_e)
+        losses_e.append(float(step_e.iterate(*ins_e, t_rand=tr, has_zero_depth=False)))
+        if len(losses_e) == 1:
+            depth, rgb = step_e.rendered()[2].cpu(), step_e.rendered()[3].cpu()
+            np.testing.assert_allclose(depth.numpy(), ret_o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(rgb.numpy(), ret_o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(losses_e[0], float(loss_o), rtol=1e-3)
+    # ---- the same five iterations replayed from the captured graph
+    step_g, es_g, ec_g, dec_g = build()
+    ins_g = step_g.capture(R, t_rand=True)
+    losses_g = []
+    for idx, tr in draws:
+        gather(idx, ins_g[:4])
+        ins_g[4].copy_(tr)
+        losses_g.append(float(step_g.replay()))
+    np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
+    assert torch.allclose(step_g.flat, step_e.flat, rtol=1e-5, atol=1e-7), float((step_g.flat - step_e.flat).abs().max())
+    assert float(step_g.step_dev[0]) == 5.0 == float(step_e.step_dev[0])
+
+
+def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():
+    """A 15-iteration mapping window (src/Mapper.py:366-445; Replica's `mapping.iters`) from identical state with fp32 and with bf16
+    decoders (split-operand forward products, bf16 operands in the gradient products), same pixel draws and jitter: depth and colour
+    of a held-out view rendered from the two resulting maps -- each with its own decoders -- agree within 1e-3 norm-wise."""
+    import unislam_amd as us
+    from unislam_amd.synthetic import SyntheticRoom
+    R, iters, nf = 2048, 15, 4
+    room = SyntheticRoom(n_frames=12, H=96, W=128, device=DEV)
+    bound = O.load_bound([[-0.5, 6.5], [-1.1, 3.5], [-1.7, 1.5]])
+    frames = [room[k] for k in (0, 3, 6, 9)]
+    held = room[5]
+    c2ws = torch.stack([f[3] for f in frames])
+    depths = torch.stack([f[2].reshape(-1) for f in frames]); colors = torch.stack([f[1].reshape(-1, 3) for f in frames])
+    dirs = torch.stack([f[4].reshape(-1, 3) for f in frames])
+    ecfg = lambda l2: {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2, "base_resolution": 16,
+                       "per_level_scale": O.per_level_scale(int((bound[:, 1] - bound[:, 0]).max() / 0.02))}
+    outs = []
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": prec}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, ecfg(14)).to(DEV), us.HashGridEncoding(3, ecfg(15)).to(DEV)
+        step = us.MapStep(es, ec, dec, bound, 32, 8, 0.06, W, LR, max_rays=R)
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, R // nf, joint_opt=False, has_zero_depth=False)
+        g = torch.Generator().manual_seed(1)
+        losses = []
+        for _ in range(iters):
+            idx = torch.randint(depths.shape[1], (nf, R // nf), generator=g).to(DEV)
+            losses.append(float(win.iterate(idx, t_rand=torch.rand(R, 40, generator=g).to(DEV))))
+        assert losses[-1] < 0.5 * losses[0]                                      # the window does converge
+        rend = us.Renderer({"rendering": {"perturb": False, "n_stratified": 32, "n_importance": 8}, "scale": 1, "grid_mode": "hash_grid"},
+                           types.SimpleNamespace(bound=bound, device=DEV, H=room.H, W=room.W, fx=room.fx, fy=room.fy, cx=room.cx, cy=room.cy))
+        out = rend.render_img(([es], [ec]), dec, held[3], 0.06, DEV, gt_depth=held[2])
+        outs.append((out[0].float(), out[1].float()))
+    (d0, c0), (d1, c1) = outs
+    assert float((d0 - d1).norm() / d0.norm()) < 1e-3, float((d0 - d1).norm() / d0.norm())
+    assert float((c0 - c1).norm() / c0.norm()) < 1e-3, float((c0 - c1).norm() / c0.norm())
