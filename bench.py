@@ -390,22 +390,18 @@ def run_rank(args):
         P, n_per = pool_d.shape[1], R // N_KEYFRAMES
 
     def make_runner(st):
-        """returns (next_step() -> loss, static inputs): one call = draw + gather + iteration"""
-        if use_graph:
-            ins = st.capture(R)
-        else:
-            ins = (f32(R, 3), f32(R, 3), f32(R), f32(R, 3))
-        if not fresh:
-            for dst, src in zip(ins, synthetic_rays(R, bound, 1000 + rank, dev)):
-                dst.copy_(src)
-
-        def nxt():
-            if fresh:
-                idx = torch.randint(P, (N_KEYFRAMES, n_per), device=dev)                                       # common.py:155
-                us.common.get_samples_all(0, CAM["H"], 0, CAM["W"], n_per, CAM["H"], CAM["W"], CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"],
-                                          c2ws, pool_d, pool_c, dev, pool_dirs, indices=idx, out=ins[:4])
-            return st.replay() if use_graph else st.iterate(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False)
-        return nxt, ins
+        """returns (next_step() -> loss, static ray tensors): one call = pixel draw + ray assembly + iteration.  Fresh batches: a
+        window.MapWindow over the keyframe pools with the poses held fixed (joint_opt off) -- the draw, the gather + rotation and the
+        sampling are ONE launch inside the replayed graph (us_window_sample)."""
+        if fresh:
+            win = us.MapWindow(st, c2ws, pool_d, pool_c, pool_dirs, n_per, joint_opt=False, has_zero_depth=False)
+            if use_graph:
+                win.capture()
+            return (win.replay if use_graph else win.iterate), (win.ro, win.rd, win.gd, win.gc)
+        ins = st.capture(R) if use_graph else (f32(R, 3), f32(R, 3), f32(R), f32(R, 3))
+        for dst, src in zip(ins, synthetic_rays(R, bound, 1000 + rank, dev)):
+            dst.copy_(src)
+        return (st.replay if use_graph else (lambda: st.iterate(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False))), ins
 
     def barrier():
         if world > 1:
@@ -444,12 +440,10 @@ def run_rank(args):
         #      collectives), eager, both branches on one stream, HIP events (torch.cuda.Event on the stream the kernels are
         #      launched on) around every hot launch
         step.probe, step.probe_every, step._it = {}, 1, 0
+        eager = us.MapWindow(step, c2ws, pool_d, pool_c, pool_dirs, n_per, joint_opt=False, has_zero_depth=False).iterate if fresh else \
+            (lambda: step.iterate(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False))
         for _ in range(max(1, args.probe_steps)):
-            if fresh:
-                idx = torch.randint(P, (N_KEYFRAMES, n_per), device=dev)
-                us.common.get_samples_all(0, CAM["H"], 0, CAM["W"], n_per, CAM["H"], CAM["W"], CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"],
-                                          c2ws, pool_d, pool_c, dev, pool_dirs, indices=idx, out=ins[:4])
-            step.iterate(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False)
+            eager()
         torch.cuda.synchronize()
         kern = {k: _median([a.elapsed_time(b) for a, b in v]) for k, v in step.probe.items()}
         step.probe = None
@@ -472,11 +466,13 @@ def run_rank(args):
                                       "fixed (joint_opt off: the iteration of the first five keyframes, src/Mapper.py:519; the joint_opt iteration, "
                                       "which also optimises the window's poses, is timed beside it under `joint_opt`)" % args.hidden,
                           "rays_per_gpu": R, "samples_per_ray": S, "points_per_gpu": N, "n_params": int(step.n_flat),
-                          "batch": (f"fresh per step: {n_per} pixels from each of {N_KEYFRAMES} keyframe pools of {P} pixels (us_gather_rays inside the timed step)"
+                          "batch": (f"fresh per step: {n_per} pixels from each of {N_KEYFRAMES} keyframe pools of {P} pixels, drawn inside the step (us_window_sample: "
+                                    f"counter-based draw + gather + rotation + sampling, one launch of the replayed graph)"
                                     if fresh else "one fixed batch re-rendered every step"),
                           "parallelism": f"dp{world} (frames/rays sharded, {comm_desc})"},
                "rays_per_s_per_gpu": R / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss),
-               "launch": "hipGraph replay of MapStep.iterate" if use_graph else "eager"}
+               "launch": ("hipGraph replay of MapWindow.iterate (joint_opt off): pixel draw + gather + sampling in one launch, then MapStep.iterate"
+                          if (use_graph and fresh) else "hipGraph replay of MapStep.iterate" if use_graph else "eager")}
         if kern is not None:
             rec["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
             rec["kernel_ms_note"] = f"median over {max(1, args.probe_steps)} eager one-stream iterations after the timed region"

@@ -500,6 +500,18 @@ int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d
 int us_window_rays(const float* c2w_first, const float* poses7, const float* pool_depth, const float* pool_color, const float* pool_dirs,
                    const int64_t* idx, int64_t pool_size, int f_begin, int f_count, int64_t n_per_frame, float* rays_o, float* rays_d,
                    float* depth, float* color, float* dirs, void* stream);
+/* us_window_rays (both blocks) + us_sample_points in ONE launch: window poses -> pool pixels -> rays -> pre-filter flag, sorted + jittered
+ * z, unit-cube points (src/Mapper.py:372-406 + src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  Rows
+ * [0, b * n_per_frame) hold frame row / n_per_frame; behind them n_extra pixels from each of the newest n_extra_frames frames
+ * (src/Mapper.py:385-393; 0: none).  idx_a[b][n_per_frame] / idx_b[n_extra_frames][n_extra]: pool pixels; both NULL: drawn in the
+ * kernel (counter-based uniform draw over the pool, seeded like the jitter: rng_seed mixed with rng_counter), where the reference
+ * calls torch.randint (src/common.py:155).  Outputs as us_window_rays + us_sample_points (dirs nullable). */
+int us_window_sample(const float* c2w_first, const float* poses7, int b, int64_t n_per_frame, int n_extra_frames, int64_t n_extra,
+                     const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size, const int64_t* idx_a,
+                     const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat, const float* t_surf, int n_imp,
+                     float c_free, float surf_off, float surf_span, const float* t_rand, uint64_t rng_seed, const float* rng_counter,
+                     int perturb, float* rays_o, float* rays_d, float* dirs, float* gt_depth, float* gt_color, uint8_t* valid,
+                     float* z_vals, float* pts, void* stream);
 /* Pose gradient and Adam step of n_poses poses in one launch (one workgroup per pose).  Pose j owns rows
  * [row_a + j*n_a, row_a + (j+1)*n_a) of g_rays_o / g_rays_d / dirs and, if n_b > 0 and j >= first_pose_b, rows
  * [row_b + (j-first_pose_b)*n_b, ... + n_b).  g7 = dL/dpose by the closed-form chain rule through R(q) = I + 2 M(q)/|q|^2 (fixed-order

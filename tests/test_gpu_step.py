@@ -866,9 +866,10 @@ def test_mapstep_render_only_in_one_launch_equals_four_launches():
 
 
 def test_bench_path_replay_equals_eager_and_oracle():
-    """Exactly what bench.py builds for its headline -- MapStep joint, mlp_precision bf16, decoder pair, capture(4096), batches drawn from
-    16 keyframe pools by get_samples_all(out = the graph's static inputs) -- replayed five times against five eager iterations on the
-    same pixel indices and jitter (loss 1e-6, parameters allclose), and the first iteration against the CPU oracle (1e-3)."""
+    """Exactly what bench.py builds for its headline -- MapStep joint, mlp_precision bf16, decoder pair, a MapWindow (joint_opt off) over
+    16 keyframe pools whose captured graph holds ray assembly + sampling + the iteration -- replayed five times against five eager
+    iterations on the same pixel indices and jitter (loss 1e-6, parameters allclose), and the first iteration against the CPU oracle
+    (1e-3)."""
     import bench
     import unislam_amd as us
     bench.torch = torch
@@ -879,7 +880,6 @@ def test_bench_path_replay_equals_eager_and_oracle():
     P, n_per = pool_d.shape[1], R // nk
     g = torch.Generator().manual_seed(12)
     draws = [(torch.randint(P, (nk, n_per), generator=g).to(DEV), torch.rand(R, S, generator=g).to(DEV)) for _ in range(5)]
-    cam = bench.CAM
 
     def build():
         torch.manual_seed(0)
@@ -890,45 +890,45 @@ def test_bench_path_replay_equals_eager_and_oracle():
         es, ec = mk(16), mk(19)
         with torch.no_grad():                                   # a non-trivial surface instead of the initial U(+-1e-4)
             es.params.normal_(0.0, 0.1); ec.params.normal_(0.0, 0.1)
-        return us.MapStep(es, ec, dec, bound, 48, 16, 0.06, bench.W, bench.LR, max_rays=R), es, ec, dec
+        step = us.MapStep(es, ec, dec, bound, 48, 16, 0.06, bench.W, bench.LR, max_rays=R)
+        return step, us.MapWindow(step, c2ws, pool_d, pool_c, pool_dirs, n_per, joint_opt=False, has_zero_depth=False), es, ec, dec
 
-    gather = lambda idx, out: us.common.get_samples_all(0, cam["H"], 0, cam["W"], n_per, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
-                                                        cam["cy"], c2ws, pool_d, pool_c, DEV, pool_dirs, indices=idx, out=out)
     # ---- eager
-    step_e, es_e, ec_e, dec_e = build()
+    step_e, win_e, es_e, ec_e, dec_e = build()
     assert step_e.joint and step_e._decoder_pair() and step_e.overlap
-    ins_e = tuple(torch.zeros(s, device=DEV) for s in ((R, 3), (R, 3), (R,), (R, 3)))
     # the first iteration also against the oracle: same rays, same jitter
-    gather(draws[0][0], ins_e)
+    win_e.draw(draws[0][0])
+    ro, rd, gd, gc = [t.cpu() for t in win_e.rays()]
     od = O.DecodersOracle(hidden_size=32, n_blocks=2); od.load_state_dict({k: v.cpu() for k, v in dec_e.state_dict().items()})
     oes, oec = O.HashGridOracle(3, es_e.encoding_config), O.HashGridOracle(3, ec_e.encoding_config)
     with torch.no_grad():
         oes.params.copy_(es_e.params.cpu()); oec.params.copy_(ec_e.params.cpu())
-    ro, rd, gd, gc = [t.cpu() for t in ins_e]
-    inside = O.bbox_far(ro, rd, bound) >= gd
-    assert bool(inside.all())                                   # the pools' depths are clipped inside the box
+    assert bool((O.bbox_far(ro, rd, bound) >= gd).all())        # the pools' depths are clipped inside the box
     ret_o = O.render_batch_ray(([oes], [oec]), od, rd, ro, 0.06, gd, bound, 48, 16, True, {"z": draws[0][1].cpu()})
     loss_o = O.mapping_loss(ret_o, gd, gc, 0.06, bench.W)
     losses_e = []
     for idx, tr in draws:
-        gather(idx, ins_e)
-        losses_e.append(float(step_e.iterate(*ins_e, t_rand=tr, has_zero_depth=False)))
+        losses_e.append(float(win_e.iterate(idx, t_rand=tr)))
         if len(losses_e) == 1:
             depth, rgb = step_e.rendered()[2].cpu(), step_e.rendered()[3].cpu()
             np.testing.assert_allclose(depth.numpy(), ret_o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
             np.testing.assert_allclose(rgb.numpy(), ret_o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
-            np.testing.assert_allclose(losses_e[0], float(loss_o), rtol=1e-3)
+            np.testing.assert_allclose(losses_e[0], float(loss_o.detach()), rtol=1e-3)
     # ---- the same five iterations replayed from the captured graph
-    step_g, es_g, ec_g, dec_g = build()
-    ins_g = step_g.capture(R, t_rand=True)
+    step_g, win_g, es_g, ec_g, dec_g = build()
+    win_g.capture(t_rand=True, device_draw=False)
     losses_g = []
     for idx, tr in draws:
-        gather(idx, ins_g[:4])
-        ins_g[4].copy_(tr)
-        losses_g.append(float(step_g.replay()))
+        win_g.t_rand.copy_(tr)
+        losses_g.append(float(win_g.replay(idx)))
     np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
     assert torch.allclose(step_g.flat, step_e.flat, rtol=1e-5, atol=1e-7), float((step_g.flat - step_e.flat).abs().max())
     assert float(step_g.step_dev[0]) == 5.0 == float(step_e.step_dev[0])
+    # ... and with the draw inside the graph (what bench.py replays): fresh batches, finite losses
+    step_d, win_d, *_ = build()
+    win_d.capture()
+    l_d = [float(win_d.replay()) for _ in range(3)]
+    assert all(np.isfinite(l_d)) and float(step_d.step_dev[0]) == 3.0
 
 
 def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():

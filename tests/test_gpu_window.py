@@ -242,7 +242,7 @@ def test_mapwindow_graph_replay_equals_eager():
         losses = [float(win.iterate(draws[0][0], draws[0][1], t_rand=draws[0][2]))]          # one eager step first: moments are non-zero
         if mode == "graph":
             before = (step.flat.clone(), step.m.clone(), win.poses.clone(), win.pm.clone(), float(step.step_dev[0]))
-            win.capture(t_rand=True)
+            win.capture(t_rand=True, device_draw=False)
             assert torch.equal(step.flat, before[0]) and torch.equal(step.m, before[1]) and torch.equal(win.poses, before[2])
             assert torch.equal(win.pm, before[3]) and float(step.step_dev[0]) == before[4] == 1.0
         for ia, ib, tr in draws[1:]:
@@ -328,3 +328,67 @@ def test_track_sample_draws_its_pixels_inside_the_crop():
         assert bool((z[:, 1:] >= z[:, :-1]).all())
         outs.append(v * Wd + u)
     assert not torch.equal(outs[0], outs[1])
+
+
+def test_window_sample_equals_rays_then_sample_points():
+    """us_window_sample (pose -> rays -> pre-filter, z, points in one launch) == us_window_rays (both blocks) + us_sample_points, bit for
+    bit, on given indices and jitter; with NULL indices it draws its pixels inside the pools and differently per device-side step count"""
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    for b, n_per, extra in ((6, 20, None), (12, 10, (10, 37)), (3, 50, (10, 8)), (1, 64, None)):
+        c2ws, depths, colors, dirs = _window(b, 300, 80 + b)
+        torch.manual_seed(0)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(12)).to(DEV), us.HashGridEncoding(3, _ecfg(12)).to(DEV)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=64)
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=b > 1, extra=extra, has_zero_depth=False)
+        g = torch.Generator().manual_seed(b)
+        nf = win.extra[0] if win.extra else 0
+        idx = torch.randint(300, (b, n_per), generator=g).to(DEV)
+        idx2 = torch.randint(300, (nf, extra[1]), generator=g).to(DEV) if extra else None
+        t_rand = torch.rand(win.R, 40, generator=g).to(DEV)
+        # reference: the two-step path
+        win.draw(idx, idx2)
+        ro, rd, gd, gc = [t.clone() for t in win.rays()]
+        dirs_ref = win.dirs.clone()
+        step.forward(ro, rd, gd, gc, t_rand, False, backward_follows=False)
+        ref = (step.valid[:win.R].clone(), step.z[:win.R].clone(), step.pts[:win.R].clone())
+        for t in (win.ro, win.rd, win.gd, win.gc, win.dirs, step.z, step.pts):
+            t.zero_()
+        step.valid.zero_()
+        step.lr = {k: 0.0 for k in step.lr}; win.cam_lr = 0.0
+        win.iterate(idx, idx2, t_rand=t_rand)
+        for a, r in zip((win.ro, win.rd, win.gd, win.gc, win.dirs, step.valid[:win.R], step.z[:win.R], step.pts[:win.R]), (ro, rd, gd, gc, dirs_ref) + ref):
+            assert torch.equal(a, r), (b, extra)
+        # in-kernel draw
+        win.iterate()
+        g1 = win.gd.clone()
+        pool = win.pool_d
+        rows = torch.arange(b, device=DEV).repeat_interleave(n_per)
+        if extra:
+            rows = torch.cat([rows, (b - nf + torch.arange(nf, device=DEV)).repeat_interleave(extra[1])])
+        assert bool(((pool[rows] - g1[:, None]).abs().min(dim=1)[0] == 0).all())              # every drawn depth is in its frame's pool
+        win.iterate()
+        assert not torch.equal(win.gd, g1)                                                      # the step count advanced: another draw
+
+
+def test_mapwindow_graph_with_device_side_draw():
+    """capture() (default): the replayed graph draws its own pixels -- replays see different batches, the optimiser advances, no host call
+    between them but the graph launch"""
+    import unislam_amd as us
+    b, P, n_per = 8, 500, 64
+    c2ws, depths, colors, dirs = _window(b, P, 9)
+    torch.manual_seed(0)
+    dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+    es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per)
+    win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, has_zero_depth=False)
+    win.capture()
+    with pytest.raises(us.UniSlamHipError):
+        win.replay(torch.zeros(b, n_per, dtype=torch.int64, device=DEV))
+    seen, losses = [], []
+    for _ in range(4):
+        losses.append(float(win.replay()))
+        seen.append(win.gd.clone())
+    assert all(np.isfinite(losses)) and float(step.step_dev[0]) == 4.0
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])

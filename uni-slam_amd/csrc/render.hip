@@ -1061,6 +1061,102 @@ __global__ __launch_bounds__(256) void k_track_sample(const float* __restrict__ 
     }
 }
 
+// The mapping counterpart: us_window_rays (both blocks) + us_sample_points in one launch (src/Mapper.py:372-406 + Renderer.py:81-101,
+// 132-137): thread = (ray, sample); the ray's frame follows from its row (rows [0, b n_per): frame row / n_per; the extra block behind
+// it: the newest n_extra_frames frames, n_extra pixels each, src/Mapper.py:385-393), its pool pixel from idx_a / idx_b or, when those
+// are NULL, from a counter-based uniform draw over the pool (the reference's torch.randint, src/common.py:155).
+struct WinShape { int b; long long n_per, P; int xf; long long xn; };
+__global__ __launch_bounds__(256) void k_window_sample(const float* __restrict__ c2w_first, const float* __restrict__ poses7, WinShape ws,
+                                                       const float* __restrict__ pool_depth, const float* __restrict__ pool_color,
+                                                       const float* __restrict__ pool_dirs, const int64_t* __restrict__ idx_a,
+                                                       const int64_t* __restrict__ idx_b, int64_t n_rays, Bound3x bd,
+                                                       const float* __restrict__ t_uni, int n_strat, const float* __restrict__ t_surf, int n_imp,
+                                                       float c_free, float surf_off, float surf_span, const float* __restrict__ t_rand,
+                                                       unsigned long long seed, const float* __restrict__ rng_counter, int perturb,
+                                                       float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ dirs,
+                                                       float* __restrict__ gt_depth, float* __restrict__ gt_color, uint8_t* __restrict__ valid,
+                                                       float* __restrict__ z_vals, float* __restrict__ pts, int rays_per_block) {
+    if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
+    extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
+    const int S = n_strat + n_imp;
+    const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
+    const int64_t ray = (int64_t)blockIdx.x * rays_per_block + rl;
+    const bool active = rl < rays_per_block && ray < n_rays;
+    float v = 0.0f, gt = 0.0f, o3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
+    int64_t src = 0;
+    if (active) {
+        const int64_t ra = (int64_t)ws.b * ws.n_per;
+        int64_t f, p;
+        const int64_t* ix;
+        int64_t k;
+        if (ray < ra) { f = ray / ws.n_per; ix = idx_a; k = ray; }
+        else { k = ray - ra; f = (ws.b - ws.xf) + k / ws.xn; ix = idx_b; }
+        if (idx_a) p = ix[k];
+        else {
+            unsigned long long zz = (seed ^ 0x8CB92BA72F3D8DD7ull) + ((unsigned long long)ray + 1ull) * 0x9E3779B97F4A7C15ull;
+            zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull; zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull; zz = zz ^ (zz >> 31);
+            p = (int64_t)(((zz >> 32) * (unsigned long long)ws.P) >> 32);
+        }
+        src = f * ws.P + p;
+        float R[9];
+        if (f == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { R[a * 3] = c2w_first[a * 4]; R[a * 3 + 1] = c2w_first[a * 4 + 1]; R[a * 3 + 2] = c2w_first[a * 4 + 2]; o3[a] = c2w_first[a * 4 + 3]; }
+        } else {
+            const float* q = poses7 + (f - 1) * 7;
+            quat_rot(q, R);
+            o3[0] = q[4]; o3[1] = q[5]; o3[2] = q[6];
+        }
+        dc[0] = pool_dirs[src * 3]; dc[1] = pool_dirs[src * 3 + 1]; dc[2] = pool_dirs[src * 3 + 2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d3[a] = (dc[0] * R[a * 3] + dc[1] * R[a * 3 + 1]) + dc[2] * R[a * 3 + 2];
+        gt = pool_depth[src];
+        const float fg = c_free * gt, sb = gt - surf_off;
+        int rank;
+        if (j < n_strat) {
+            v = fg * t_uni[j];
+            rank = j;
+            for (int a = 0; a < n_imp; ++a) rank += ((sb + surf_span * t_surf[a]) < v) ? 1 : 0;
+        } else {
+            const int a = j - n_strat;
+            v = sb + surf_span * t_surf[a];
+            rank = a;
+            for (int i = 0; i < n_strat; ++i) rank += ((fg * t_uni[i]) <= v) ? 1 : 0;
+        }
+        zs[rl * S + rank] = v;
+    }
+    __syncthreads();
+    if (active) {
+        const float* z = zs + rl * S;
+        float out = z[j];
+        if (perturb) {
+            const float lower = j > 0 ? 0.5f * (z[j] + z[j - 1]) : z[0];
+            const float upper = j < S - 1 ? 0.5f * (z[j + 1] + z[j]) : z[S - 1];
+            const float u = t_rand ? t_rand[ray * S + j] : uniform24(seed, (uint64_t)(ray * S + j));
+            out = lower + (upper - lower) * u;
+        }
+        z_vals[ray * S + j] = out;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float p = o3[a] + d3[a] * out;
+            pts[(ray * S + j) * 3 + a] = (p - bd.lo[a]) / bd.span[a];
+        }
+        if (j == 0) {
+            float far = INFINITY;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float t0 = (bd.lo[a] - o3[a]) / d3[a], t1 = (bd.hi[a] - o3[a]) / d3[a];
+                far = fminf(far, fmaxf(t0, t1));
+                rays_o[ray * 3 + a] = o3[a]; rays_d[ray * 3 + a] = d3[a];
+                if (dirs) dirs[ray * 3 + a] = dc[a];
+                gt_color[ray * 3 + a] = pool_color[src * 3 + a];
+            }
+            gt_depth[ray] = gt;
+            valid[ray] = (far >= gt) ? 1 : 0;                    // Mapper.py:396-402 (rays without a depth pass: gt = 0)
+        }
+    }
+}
+
 // one workgroup: G = sum_rays g_d (x) dir, gt = sum_rays g_o, then the closed-form chain rule through R(q)
 __global__ __launch_bounds__(1024) void k_pose_grad(const float* __restrict__ pose, const float* __restrict__ g_o,
                                                     const float* __restrict__ g_d, const float* __restrict__ dirs, int64_t n,
@@ -1614,5 +1710,31 @@ extern "C" int us_track_loss_bwd(const float* raw, const float* z_vals, const fl
     else
         hipLaunchKernelGGL((k_composite_bwd<2>), grid, block, 0, s, raw, z_vals, beta, n_rays, n_samples, nul, nul, nul, nul, nul, nul, d_raw, nulw, nulw, lb);
     US_CHECK_LAUNCH("us_track_loss_bwd");
+    return US_OK;
+}
+
+extern "C" int us_window_sample(const float* c2w_first, const float* poses7, int b, int64_t n_per_frame, int n_extra_frames, int64_t n_extra,
+                                const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size,
+                                const int64_t* idx_a, const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat,
+                                const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
+                                uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
+                                float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, void* stream) {
+    US_REQUIRE(b >= 1 && n_per_frame >= 0 && n_extra_frames >= 0 && n_extra_frames <= b && n_extra >= 0 && pool_size >= 1, US_ERR_SHAPE,
+               "us_window_sample: bad window shape");
+    if (n_extra_frames == 0 || n_extra == 0) { n_extra_frames = 0; n_extra = 1; }
+    const int64_t n_rays = (int64_t)b * n_per_frame + (int64_t)n_extra_frames * (n_extra_frames ? n_extra : 0);
+    if (n_rays == 0) return US_OK;
+    US_REQUIRE(c2w_first && (b == 1 || poses7) && pool_depth && pool_color && pool_dirs && bound_host && t_uni && t_surf && rays_o && rays_d &&
+               gt_depth && gt_color && valid && z_vals && pts, US_ERR_NULL, "us_window_sample: NULL pointer");
+    US_REQUIRE(!n_extra_frames || ((idx_a == nullptr) == (idx_b == nullptr)), US_ERR_NULL, "us_window_sample: idx_a and idx_b together, or neither (in-kernel draw)");
+    const int S = n_strat + n_imp;
+    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_window_sample: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
+    WinShape ws; ws.b = b; ws.n_per = n_per_frame; ws.P = pool_size; ws.xf = n_extra_frames; ws.xn = n_extra;
+    const int rpb = 256 / S;
+    hipLaunchKernelGGL(k_window_sample, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float), (hipStream_t)stream,
+                       c2w_first, poses7, ws, pool_depth, pool_color, pool_dirs, idx_a, idx_b, n_rays, make_bound3x(bound_host), t_uni, n_strat,
+                       t_surf, n_imp, c_free, surf_off, surf_span, t_rand, (unsigned long long)rng_seed, rng_counter, perturb, rays_o, rays_d, dirs,
+                       gt_depth, gt_color, valid, z_vals, pts, rpb);
+    US_CHECK_LAUNCH("us_window_sample");
     return US_OK;
 }

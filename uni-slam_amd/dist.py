@@ -63,7 +63,7 @@ def dp_iterate(engine, batch, group=None, grad_comm=None):
                 buf.copy_(view)
             works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True), view, buf))
 
-    loss = engine.backward(on_ready)
+    loss = engine.backward(on_ready if group is not None else None)     # (a single process has no use for per-segment readiness)
     if group is not None:
         if not works:                                   # an engine that does not announce segments: one reduction at the end
             on_ready(engine.grad)

@@ -287,7 +287,12 @@ class MapStep:
         self.probe.setdefault(name, []).append((e0, e1))
 
     # ------------------------------------------------------------------------------------------ the iteration
-    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None, backward_follows=True):
+    def _seed(self, k):
+        """seed of the k-th in-kernel random stream of the current call (rng_calls counts the calls)"""
+        return (self.rng_seed + 0x9E3779B97F4A7C15 * (3 * self.rng_calls + k)) & (2 ** 64 - 1)
+
+    def forward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, zero_depth_draws=None, backward_follows=True,
+                presampled=False):
         """
         Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
         has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
@@ -296,6 +301,8 @@ class MapStep:
         zero_depth_draws: (t_rand_uni [n0, n_strat], u [n0, n_imp]) for that branch's rays in row order, to replay a given random stream
         (tests); default: the in-kernel generator.
         backward_follows: False for a render-only call (the encoders then skip the bookkeeping they do for the table gradient).
+        presampled: the pre-filter flags, z and the unit-cube points of these rays are already in self.valid / self.z / self.pts
+        (window.MapWindow forms rays and samples in one launch).
         """
         lib, st = L.lib(), L.stream()
         self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
@@ -312,11 +319,12 @@ class MapStep:
         c_free, s_off, s_span = ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation)
         # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
         tr = P(L.f32(t_rand)) if (self.perturb and t_rand is not None) else None
-        self.rng_calls += 1
-        seed = lambda k: (self.rng_seed + 0x9E3779B97F4A7C15 * (3 * self.rng_calls + k)) & (2 ** 64 - 1)
-        L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
-                                     c_free, s_off, s_span, tr, seed(0), P(self.step_dev),
-                                     1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
+        seed = self._seed
+        if not presampled:                                       # presampled: the caller's kernel (us_window_sample) has filled valid, z and
+            self.rng_calls += 1                                  # pts for these rays and advanced rng_calls
+            L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
+                                         c_free, s_off, s_span, tr, seed(0), P(self.step_dev),
+                                         1 if self.perturb else 0, 0, P(self.valid), P(self.z), P(self.pts), st), "us_sample_points")
         fl = self.flat
         if has_zero_depth is not False:
             # Renderer.py:104-130 for the rays without a depth measurement, on their compacted rows: coarse uniform pass through the
@@ -691,14 +699,14 @@ class MapStep:
                                               I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, P(self.step_dev),
                                               zero_mask, st), "us_adam_step_segments_dev")
 
-    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None):
+    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, presampled=False):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
         if self.group is None and self.fuse_adam:
-            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth)
+            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, presampled=presampled)
             loss = self.backward(fuse_adam=True)                 # ... which updates the tables where the joint pass runs
             self.adam_step()
             return loss
-        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth), self.group)
+        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled), self.group)
 
     def capture(self, n_rays, t_rand=False):
         """

@@ -64,7 +64,7 @@ class MapWindow:
 
     # ------------------------------------------------------------------------------------------ one iteration
     def draw(self, indices=None, indices_extra=None):
-        """the pixel draw of common.get_samples_all (src/common.py:155) into the static index tensors"""
+        """the pixel draw of common.get_samples_all (src/common.py:155) into the static index tensors (torch.randint, or given indices)"""
         if indices is None:
             torch.randint(self.P, (self.b, self.n_per), device=self.idx_a.device, out=self.idx_a)
         else:
@@ -76,23 +76,8 @@ class MapWindow:
                 self.idx_b.copy_(indices_extra.reshape(self.extra))
 
     def rays(self):
-        """(rays_o, rays_d, gt_depth, gt_color) of the current draw at the current poses (the launches of _launches() up to the render)"""
-        self._rays_only = True
-        try:
-            self._launches()
-        finally:
-            self._rays_only = False
-        return self.ro, self.rd, self.gd, self.gc
-
-    def _off(self, t, rows, width):
-        return ctypes.c_void_p(t.data_ptr() + 4 * rows * width)
-
-    def _launches(self, t_rand=None, zero_depth_draws=None):
-        """everything after the draw: rays from the current poses, render + loss + backward, pose step, Adam"""
-        lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
-        b = self.b
-        if t_rand is None:
-            t_rand = self.t_rand                                 # the static jitter tensor of capture(t_rand=True), if any
+        """(rays_o, rays_d, gt_depth, gt_color) of the drawn pixels (self.idx_a / idx_b) at the current poses: us_window_rays alone"""
+        lib, st, P, b = L.lib(), L.stream(), L.ptr, self.b
         poses = P(self.poses) if b > 1 else None
         L.check(lib.us_window_rays(P(self.c2w_first), poses, P(self.pool_d), P(self.pool_c), P(self.pool_r), P(self.idx_a), self.P, 0, b,
                                    self.n_per, P(self.ro), P(self.rd), P(self.gd), P(self.gc), P(self.dirs), st), "us_window_rays")
@@ -102,15 +87,37 @@ class MapWindow:
             L.check(lib.us_window_rays(P(self.c2w_first), poses, P(self.pool_d), P(self.pool_c), P(self.pool_r), P(self.idx_b), self.P, b - nf, nf,
                                        ne, self._off(self.ro, r0, 3), self._off(self.rd, r0, 3), self._off(self.gd, r0, 1), self._off(self.gc, r0, 3),
                                        self._off(self.dirs, r0, 3), st), "us_window_rays")
-        if getattr(self, "_rays_only", False):
-            return None
+        return self.ro, self.rd, self.gd, self.gc
+
+    def _off(self, t, rows, width):
+        return ctypes.c_void_p(t.data_ptr() + 4 * rows * width)
+
+    def _launches(self, t_rand=None, zero_depth_draws=None, device_draw=False):
+        """everything after the draw: rays from the current poses + samples (ONE launch: us_window_sample; with device_draw it also
+        draws the pixels, like the jitter from a counter-based generator salted with the device-side step count), render + loss +
+        backward, pose step, Adam"""
+        lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
+        b = self.b
+        if t_rand is None:
+            t_rand = self.t_rand                                 # the static jitter tensor of capture(t_rand=True), if any
+        poses = P(self.poses) if b > 1 else None
+        nf, ne = self.extra if self.extra else (0, 0)
+        if self.R > s.max_rays:
+            s._alloc(self.R)
+        s.rng_calls += 1
+        tr = P(L.f32(t_rand)) if (s.perturb and t_rand is not None) else None
+        ia, ib = (None, None) if device_draw else (P(self.idx_a), P(self.idx_b) if self.extra else None)
+        L.check(lib.us_window_sample(P(self.c2w_first), poses, b, self.n_per, nf, ne, P(self.pool_d), P(self.pool_c), P(self.pool_r), self.P, ia, ib,
+                                     s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation),
+                                     ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
+                                     P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
         if not self.joint_opt:
-            return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero)
+            return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero, presampled=True)
         if s.group is not None:
             raise L.UniSlamHipError("MapWindow: joint pose optimisation runs in a single process (the poses are not all-reduced)")
         s.store_dydx = True                                      # the encoder leaves dy/dx for the pose gradient (no second gather pass)
         try:
-            s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws)
+            s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws, presampled=True)
         finally:
             s.store_dydx = False
         loss = s.backward(ray_grads=True)
@@ -118,7 +125,6 @@ class MapWindow:
         if not s._step_advanced:                                 # the poses are one more group of the SAME optimiser: one step count
             L.check(lib.us_adam_step_inc(P(s.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
             s._step_advanced = True
-        nf, ne = self.extra if self.extra else (0, 0)
         lr = self.cam_lr                                         # the pose group is appended with its plain lr (src/Mapper.py:362): no lr_factor
         # pose j = window frame j + 1: rows [(j+1) n_per, (j+2) n_per) of the first block, and rows of the extra block for the newest nf frames
         L.check(lib.us_pose_window_step(P(self.poses), b - 1, P(g_o), P(g_d), P(self.dirs), self.n_per, self.n_per, max(b - nf - 1, 0),
@@ -128,16 +134,17 @@ class MapWindow:
         return loss
 
     def iterate(self, indices=None, indices_extra=None, t_rand=None, zero_depth_draws=None):
-        """one eager iteration; returns the loss tensor [1] (device)"""
-        self.draw(indices, indices_extra)
-        return self._launches(t_rand, zero_depth_draws)
+        """one eager iteration; returns the loss tensor [1] (device).  indices None: the pixels are drawn inside us_window_sample"""
+        if indices is not None:
+            self.draw(indices, indices_extra)
+        return self._launches(t_rand, zero_depth_draws, device_draw=indices is None)
 
     # ------------------------------------------------------------------------------------------ hipGraph
-    def capture(self, t_rand=False):
-        """capture _launches() (no zero-depth branch: that one reads a row count on the host) into a hipGraph; replay() = draw + one
-        graph launch.  The jitter comes from the in-kernel generator (varied per replay by the device-side step count) unless
-        t_rand=True: then self.t_rand [R,S] is a static input to fill.  The model, the optimiser state and the poses are left as
-        they were."""
+    def capture(self, t_rand=False, device_draw=True):
+        """capture _launches() (no zero-depth branch: that one reads a row count on the host) into a hipGraph: replay() is ONE graph
+        launch, pixel draw included (device_draw; False: replay(indices) / torch.randint fill the static index tensors first).  The
+        jitter comes from the in-kernel generator (varied per replay by the device-side step count) unless t_rand=True: then
+        self.t_rand [R,S] is a static input to fill.  The model, the optimiser state and the poses are left as they were."""
         from .graph import CapturedIteration
         s = self.step
         if self.has_zero:
@@ -152,12 +159,14 @@ class MapWindow:
         s.lr = {k: 0.0 for k in s.lr}
         self.cam_lr = 0.0
         self.draw()
+        self._device_draw = bool(device_draw)
+        run = lambda: self._launches(device_draw=self._device_draw)
         try:
             side = torch.cuda.Stream(device=s.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._launches()
+                    run()
             torch.cuda.current_stream().wait_stream(side)
         finally:
             s.lr, self.cam_lr = keep[5], keep[10]
@@ -165,14 +174,18 @@ class MapWindow:
         self.poses.copy_(keep[7]); self.pm.copy_(keep[8]); self.pv.copy_(keep[9])
         s.opt_step, s.rng_calls = keep[4], keep[6]
         s._dec_grad_clean = False
-        self._graph = CapturedIteration(self._launches, warmup=0)
+        self._graph = CapturedIteration(run, warmup=0)
         s.opt_step = keep[4]
         s.probe = was
 
     def replay(self, indices=None, indices_extra=None):
         if self._graph is None:
             raise L.UniSlamHipError("MapWindow.replay: call capture() first")
-        self.draw(indices, indices_extra)
+        if self._device_draw:
+            if indices is not None:
+                raise L.UniSlamHipError("MapWindow.replay: this graph draws its pixels itself; capture(device_draw=False) to pass indices")
+        else:
+            self.draw(indices, indices_extra)
         self.step.opt_step += 1
         return self._graph.replay()
 
