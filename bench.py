@@ -66,7 +66,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-decoder-pair", action="store_true", help="the two decoders as two launches each way instead of one (MapStep.decoder_pair)")
     ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
                     help="both grids in one encoder launch and one binned table-gradient pass (csrc/hashgrid_joint.hip); auto = MapStep's default")
-    ap.add_argument("--packed-records", action="store_true", help="8-byte intermediate records in the table gradient (US_GRID_BWD_PACKED)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: launch every iteration eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--fixed-batch", action="store_true", help="re-render one fixed batch every step (round 1's bench) instead of a fresh draw")
     ap.add_argument("--probe-steps", type=int, default=10, help="eager iterations with HIP events around the hot kernels, after the timed region")
@@ -371,7 +370,7 @@ def run_rank(args):
                 es.params.normal_(0.0, table_std); ec.params.normal_(0.0, table_std)
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
-                        grad_comm=comm, sharded_adam=sharded, packed_records=args.packed_records,
+                        grad_comm=comm, sharded_adam=sharded,
                         joint=None if args.joint == "auto" else args.joint == "1", dp_mode=args.dp_mode)
         st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
@@ -510,11 +509,8 @@ def run_rank(args):
                 return 1e3 * (time.perf_counter() - t1) / k
             render = lambda: step.forward(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False, backward_follows=False)
             fwd_ms = timed(render)
-            step.fused_render = True                             # ... and as ONE launch (us_encode_decode_fwd; opt-in: measured slower)
-            fwd1_ms = timed(render)
-            step.fused_render = False
             fb_ms = timed(lambda: step.forward_backward(ins[0], ins[1], ins[2], ins[3], has_zero_depth=False))
-            rec["extra"] = {"forward_only_ms": fwd_ms, "forward_only_rays_per_s": R / (fwd_ms / 1e3), "forward_only_one_launch_ms": fwd1_ms,
+            rec["extra"] = {"forward_only_ms": fwd_ms, "forward_only_rays_per_s": R / (fwd_ms / 1e3),
                             "iteration_without_adam_ms": fb_ms}
 
             def side_run(st):

@@ -78,12 +78,7 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
 /* US_GRID_BWD_SCANNED (with US_GRID_BWD_COUNTED): us_hashgrid_bwd_scan has already run on this workspace, the gradient call starts at
  * its record pass. */
 #define US_GRID_BWD_SCANNED 64
-/* US_GRID_BWD_PACKED (us_hashgrid_bwd_binned, n_features == 2 only): the intermediate records of the binned pass are kept in 8 bytes
- * { local entry, the two contributions rounded to 26 / 27 significant fp32 bits } instead of 12; the sums are still formed in f64.
- * Relative rounding per contribution <= 2^-18: far inside the 1e-3 parity bound, but not bit-equal to the unpacked pass.
- * Measured on MI355X (4096 x 64 points, room0 tables): 186 -> 179 us per colour-table gradient -- the two passes are bound by LDS
- * atomics and per-workgroup latency, not by their bytes, so the default keeps the exact 12-byte records. */
-#define US_GRID_BWD_PACKED 32
+/* (flag value 32, US_GRID_BWD_PACKED, belongs to the experiments build: include/unislam_hip_experiments.h) */
 /* US_GRID_BWD_DETERMINISTIC (us_hashgrid_bwd_binned, us_hashgrid_bwd_joint, and their scan calls): no bin is split over several
  * accumulate workgroups, so no float atomic takes part: every table-gradient entry is ONE f64 sum of its fp32 contributions, rounded
  * to fp32 once.  The order in which LDS atomics add the terms can then only move the sum at the 2^-53 level, which the final rounding
@@ -159,17 +154,6 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
  * produce zero records), so the counts depend on x only. */
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
-
-/* us_hashgrid_bwd_joint + torch.optim.Adam of the two tables in one pass (single process; flags must carry US_GRID_BWD_OVERWRITE): the
- * workgroup that has summed a bin's gradient entries updates params / m / v of exactly those entries (every table entry belongs to one
- * bin), so the 6 x n_params floats of optimiser traffic stream under the LDS atomics that bound the accumulate pass instead of in a
- * pass of their own (src/Mapper.py:443-445: backward, then optimizer.step() over the table param groups of :118-126).  The gradient
- * tables are still written.  step_dev: the device-side step count of us_adam_step_segments_dev, ALREADY advanced for this step
- * (us_adam_step_inc); lrA / lrB: the two tables' learning rates.  Same arithmetic as us_adam_step_segments_dev. */
-int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
-                               int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes,
-                               float* paramsA, float* paramsB, float* mA, float* mB, float* vA, float* vB, double lrA, double lrB,
-                               double beta1, double beta2, double eps, const float* step_dev, void* stream);
 
 /* The table gradient of a RANGE of the batch: x / dL_dy* point at the range's first point, n = points in the range, plane_stride =
  * points of the whole batch (the distance between the level planes of a level-major dL_dy).  The gradient is additive over points,
@@ -267,16 +251,6 @@ size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d);
 int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out, int64_t out_stride,
                const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din, float* grad_params, int flags,
                void* workspace, size_t workspace_bytes, void* stream);
-
-/* Render-only encode + decode in one launch: outA = decoder A(grid A(x)), outB = decoder B(grid B(x)) -- what Decoders.forward
- * (src/networks/decoders.py:158-188) computes for Renderer.render_img / Mesher.eval_points, calls that need no gradient.  The features
- * stay in LDS.  Needs two 16-level F = 2 grids of equal base resolution and per-level scale, and two bf16 decoders (US_PREC_BF16 or
- * US_PREC_BF16_PLAIN, the same for both) of equal width and depth: us_encode_decode_supported() says whether a pair qualifies; results
- * are bit-identical to us_hashgrid_fwd + us_mlp_fwd.  flags: US_GRID_CLAMP01. */
-int us_encode_decode_supported(const us_grid_desc* a, const us_grid_desc* b, const us_mlp_desc* ma, const us_mlp_desc* mb);
-int us_encode_decode_fwd(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
-                         const us_mlp_desc* ma, const us_mlp_desc* mb, const float* mlp_paramsA, const float* mlp_paramsB,
-                         const float* x, int64_t n, float* outA, int64_t strideA, float* outB, int64_t strideB, int flags, void* stream);
 
 /* Two decoders of equal shape (32 inputs, the same width, depth and bf16 precision: us_mlp_pair_supported) in ONE launch each way --
  * the sdf and the colour decoder of Decoders.forward.  Arguments and results as two us_mlp_fwd / us_mlp_bwd calls (bit-identical);

@@ -16,8 +16,8 @@ def built():
     return unislam_amd
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "unislam_hip.h")).read()
+def header_functions(name="unislam_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(us_[a-z0-9_]+)\s*\(", src)))
 
@@ -31,6 +31,10 @@ def test_every_declared_symbol_is_exported_and_bound(built):
     from unislam_amd import _lib
     assert sorted(_lib.SIGNATURES.keys()) == names            # the ctypes table covers exactly the header
     assert _lib.lib().us_abi_version() == 1
+    # the measured-slower variants live in their own header and are NOT part of the shipped library
+    exp = header_functions("unislam_hip_experiments.h")
+    assert sorted(_lib.EXPERIMENT_SIGNATURES.keys()) == exp and not set(exp) & set(names)
+    assert not _lib.has_experiments() and not any(hasattr(lib, n) for n in exp)
 
 
 def test_descriptor_and_argument_errors_without_gpu(built):

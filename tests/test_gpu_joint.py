@@ -182,38 +182,3 @@ def test_deterministic_table_gradient_repeats_bit_for_bit(us, joint):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for k in range(2):
         assert torch.allclose(outs[0][k], outs[2][k], rtol=1e-4, atol=2e-6 * float(outs[2][k].abs().max()))
-
-
-@pytest.mark.parametrize("l2a,l2b,res,n", [(16, 19, 816, 70001), (16, 16, 456, 4096), (19, 19, 816, 1), (14, 15, 816, 63)])
-@pytest.mark.parametrize("width,n_hidden,bias,prec", [(32, 2, True, "bf16"), (32, 2, False, "bf16_plain"), (16, 1, True, "bf16"), (64, 2, True, "bf16"),
-                                                      (64, 1, False, "bf16_plain")])
-def test_encode_decode_in_one_launch_equals_the_four_launches(us, l2a, l2b, res, n, width, n_hidden, bias, prec):
-    """us_encode_decode_fwd (csrc/encode_decode.inc: both grids and both decoders in one kernel, features kept in LDS) against
-    us_hashgrid_fwd + us_mlp_fwd per grid / decoder on the same points and parameters: bit-identical outputs, written into one
-    raw[N][4] the way the render path does (sdf -> column 3, rgb -> columns 0..2)."""
-    from unislam_amd import _lib as L
-    lib, st, P = L.lib(), L.stream(), L.ptr
-    x, g = _ray_points(n, 300 + n)
-    ea, eb = _pair(us, l2a, l2b, res, g)
-    da, db = ctypes.byref(ea.desc), ctypes.byref(eb.desc)
-    ma = us.make_mlp_desc(32, width, n_hidden, 1, "none", bias, prec)
-    mb = us.make_mlp_desc(32, width, n_hidden, 3, "sigmoid", bias, prec)
-    pa = ((torch.rand(us.network.mlp_n_params(ma), device=DEV, generator=g) * 2 - 1) * 0.4)
-    pb = ((torch.rand(us.network.mlp_n_params(mb), device=DEV, generator=g) * 2 - 1) * 0.4)
-    assert lib.us_encode_decode_supported(da, db, ctypes.byref(ma), ctypes.byref(mb)) == 1
-    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
-    for clamp in (1, 0):
-        xin = x if clamp else x.clamp(0, 1)
-        fa, fb = torch.empty((16, n, 2), device=DEV), torch.empty((16, n, 2), device=DEV)
-        ref, out = torch.full((n, 4), -7.0, device=DEV), torch.full((n, 4), -7.0, device=DEV)
-        L.check(lib.us_hashgrid_fwd(da, P(ea.params.detach()), P(xin), n, P(fa), None, clamp | 2, st), "fwd a")
-        L.check(lib.us_hashgrid_fwd(db, P(eb.params.detach()), P(xin), n, P(fb), None, clamp | 2, st), "fwd b")
-        L.check(lib.us_mlp_fwd(ctypes.byref(ma), P(pa), P(fa), n, off(ref, 3), 4, 1, st), "mlp a")
-        L.check(lib.us_mlp_fwd(ctypes.byref(mb), P(pb), P(fb), n, P(ref), 4, 1, st), "mlp b")
-        L.check(lib.us_encode_decode_fwd(da, db, P(ea.params.detach()), P(eb.params.detach()), ctypes.byref(ma), ctypes.byref(mb), P(pa), P(pb),
-                                         P(xin), n, off(out, 3), 4, P(out), 4, clamp, st), "encode_decode")
-        assert torch.equal(out, ref)
-    # fp32 decoders, decoders of different shapes: not this path's
-    assert lib.us_encode_decode_supported(da, db, ctypes.byref(us.make_mlp_desc(32, width, n_hidden, 1, "none", bias, "fp32")), ctypes.byref(mb)) == 0
-    assert lib.us_encode_decode_supported(da, db, ctypes.byref(us.make_mlp_desc(32, {16: 32, 32: 16, 64: 32}[width], n_hidden, 1, "none", bias, prec)),
-                                          ctypes.byref(mb)) == 0

@@ -1034,58 +1034,6 @@ def test_zero_depth_rows_uniform_points_and_scatter(us):
     assert torch.equal(pf[want.to(DEV)], ref_pts)
 
 
-@pytest.mark.parametrize("log2T", [14, 19])
-def test_binned_backward_packed_records(us, log2T):
-    """US_GRID_BWD_PACKED: 8-byte records (values rounded to 26 / 27 significant bits) against the oracle and the unpacked pass;
-    a NaN and an inf in the incoming gradient reach exactly the entries they reach unpacked; F != 2 is refused."""
-    import ctypes
-    from unislam_amd import _lib as L
-    rng = np.random.default_rng(21)
-    n = 50000
-    x = rng.random((n, 3), dtype=np.float32)
-    x[:20000] = (0.3 + 0.05 * rng.random((20000, 3))).astype(np.float32)             # long runs and hot bins
-    dy = (rng.standard_normal((n, 32)) * np.exp(rng.uniform(-12, 4, (n, 1)))).astype(np.float32)    # 7 decades of magnitudes
-    d = O.make_grid_desc(16, 2, log2T, 16, PLS816)
-    enc = us.HashGridEncoding(3, enc_cfg(log2T)).to(DEV)
-    gp = O.hashgrid_bwd_params(d, x, dy)
-    xd, dyd = T(x).to(DEV), T(dy).to(DEV)
-    lib, P, st = L.lib(), L.ptr, L.stream()
-    nbytes = int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(enc.desc), n))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    run = lambda dy_t, flags: (lambda g: (L.check(lib.us_hashgrid_bwd_binned(ctypes.byref(enc.desc), P(xd), P(dy_t), n, P(g),
-                                                                            L.US_GRID_BWD_OVERWRITE | flags, P(ws), nbytes, st), "binned"), g)[1])(
-        torch.full((d.n_params,), 7.0, device=DEV))
-    g_exact, g_packed = run(dyd, 0), run(dyd, L.US_GRID_BWD_PACKED)
-    scale = np.abs(gp).max()
-    np.testing.assert_allclose(g_packed.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * scale)
-    # against the unpacked pass: every record is off by <= 2^-18 relative (17 mantissa bits kept), so a sum is off by <= 2^-18 * sum |records|
-    mag = torch.full((d.n_params,), 0.0, device=DEV)
-    L.check(lib.us_hashgrid_bwd_binned(ctypes.byref(enc.desc), P(xd), P(dyd.abs().contiguous()), n, P(mag), L.US_GRID_BWD_OVERWRITE, P(ws), nbytes, st), "binned")
-    err = (g_packed - g_exact).abs()
-    assert bool((err <= (2.0 ** -18 + 2.0 ** -22) * mag + 1e-30).all())      # + the fp32 casts of the two sums, float((err / (mag + 1e-30)).max())
-    assert float(err.max()) > 0                                                     # and it is a different pass
-    # non-finite gradients propagate to the same entries
-    dy_bad = dyd.clone(); dy_bad[123, 5] = float("nan"); dy_bad[456, 20] = float("inf"); dy_bad[789, 31] = -float("inf")
-    b_exact, b_packed = run(dy_bad, 0), run(dy_bad, L.US_GRID_BWD_PACKED)
-    assert torch.equal(torch.isnan(b_exact), torch.isnan(b_packed)) and torch.equal(torch.isinf(b_exact), torch.isinf(b_packed))
-    assert int(torch.isnan(b_exact).sum()) > 0 and int(torch.isinf(b_exact).sum()) > 0
-    # counted forward + packed
-    feat = torch.empty(n, 32, device=DEV)
-    L.check(lib.us_hashgrid_fwd_counted(ctypes.byref(enc.desc), P(enc.params.detach()), P(xd), n, P(feat), 0, P(ws), nbytes, st), "fwd counted")
-    g_c = torch.empty(d.n_params, device=DEV)
-    L.check(lib.us_hashgrid_bwd_binned(ctypes.byref(enc.desc), P(xd), P(dyd), n, P(g_c), L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_PACKED,
-                                       P(ws), nbytes, st), "counted packed")
-    np.testing.assert_allclose(g_c.cpu().numpy(), gp, rtol=1e-4, atol=2e-6 * scale)
-    # other feature widths are refused loudly
-    cfg1 = dict(enc_cfg(14)); cfg1["n_features_per_level"] = 4
-    enc4 = us.HashGridEncoding(3, cfg1).to(DEV)
-    dy4 = torch.zeros(64, 64, device=DEV); x4 = torch.rand(64, 3, device=DEV)
-    nb4 = int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(enc4.desc), 64))
-    ws4 = torch.empty(nb4, dtype=torch.uint8, device=DEV); g4 = torch.zeros(enc4.params.numel(), device=DEV)
-    rc = lib.us_hashgrid_bwd_binned(ctypes.byref(enc4.desc), P(x4), P(dy4), 64, P(g4), L.US_GRID_BWD_PACKED, P(ws4), nb4, st)
-    assert rc == L.US_ERR_CONFIG
-
-
 @pytest.mark.parametrize("width,n_hidden,bias,prec,n", [(32, 2, True, "bf16", 70001), (32, 2, False, "bf16_plain", 4096), (16, 1, True, "bf16", 100),
                                                         (64, 2, True, "bf16", 5000), (64, 1, False, "bf16_plain", 1)])
 def test_mlp_pair_equals_two_launches(us, width, n_hidden, bias, prec, n):

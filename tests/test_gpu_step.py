@@ -711,25 +711,6 @@ def test_mapstep_graph_replay_equals_eager():
     assert not torch.equal(z1, z2) and bool((z1[:, 1:] >= z1[:, :-1]).all())
 
 
-def test_mapstep_scans_in_forward_option():
-    """scan_in_forward: the binning's scan passes issued right after the encoders give the same iteration"""
-    import unislam_amd as us
-    R, S = 300, 40
-    ro, rd, gd, gc = _rays(R, seed=41)
-    t_rand = torch.rand(R, S, generator=torch.Generator().manual_seed(4)).to(DEV)
-    outs = []
-    for early in (False, True):
-        dec, es, ec = _scene(us, False, seed=40)
-        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
-        step.scan_in_forward = early
-        losses = [float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)) for _ in range(3)]
-        assert step._scanned == early
-        outs.append((step.flat.clone(), losses))
-    # (bins hot enough to be split are summed with float atomics: equal up to their order)
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
-    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
-
-
 @pytest.mark.parametrize("pair", [(14, 15), (16, 19), (16, 16)])
 def test_mapstep_joint_grids_equal_separate_grids(pair):
     """MapStep(joint=True) -- both encoders in one launch, both table gradients in one binned pass (csrc/hashgrid_joint.hip) -- against
@@ -797,72 +778,6 @@ def test_mapstep_table_gradient_in_ranges(joint):
     assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6 * float(a[0].abs().max()))
     close = torch.isclose(a[2], b[2], rtol=1e-5, atol=1e-6)
     assert float((~close).float().mean()) < 1e-4
-
-
-@pytest.mark.parametrize("pair", [(16, 19), (16, 16)])
-def test_mapstep_fused_adam_equals_the_separate_optimiser_pass(pair):
-    """MapStep(fuse_adam=True).iterate() of a single process applies Adam to the two tables inside the accumulate pass of the joint table
-    gradient (us_hashgrid_bwd_joint_adam: the workgroup that summed a bin updates that bin's entries; opt-in, measured slower).  Same parameters, moments and losses as
-    the separate dense pass (k_adam_segs) -- over several iterations, a fresh optimiser in between (Mapper.py:358-364), a degenerate
-    batch whose hot bins take the k_jadam_hot route, and with the one-grid kernels as a third reference."""
-    import unislam_amd as us
-    R, S = 700, 40
-    batches = [_rays(R, seed=40 + k, outside=True) for k in range(3)]
-    hot = list(_rays(R, seed=50))
-    hot[0] = hot[0][:1].repeat(R, 1).contiguous(); hot[1] = hot[1][:1].repeat(R, 1).contiguous()    # every ray the same: hot bins
-    batches.append(tuple(hot))
-    res = {}
-    for name, kw in (("fused", dict(joint=True, fuse_adam=True)), ("joint", dict(joint=True, fuse_adam=False)), ("single", dict(joint=False))):
-        torch.manual_seed(4)
-        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
-        es, ec = us.HashGridEncoding(3, _ecfg(pair[0])).to(DEV), us.HashGridEncoding(3, _ecfg(pair[1])).to(DEV)
-        with torch.no_grad():
-            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
-        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, **kw)
-        losses = []
-        for k, (ro, rd, gd, gc) in enumerate(batches):
-            t_rand = torch.rand(R, S, generator=torch.Generator().manual_seed(60 + k)).to(DEV)
-            losses.append(float(step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)))
-            if k == 1:
-                step.reset_optimizer(5.0)
-            if k == 2:
-                before_hot = step.flat.clone()                   # (the hot batch's bins are summed with float atomics: order-dependent rounding)
-        res[name] = (losses, step.flat.clone(), step.m.clone(), step.v.clone(), float(step.step_dev[0]), before_hot)
-    for other in ("joint", "single"):
-        a, b = res["fused"], res[other]
-        np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
-        assert a[4] == b[4] == 2.0                                              # two steps since the optimiser was reset
-        for k in (1, 2, 3):
-            close = torch.isclose(a[k], b[k], rtol=1e-5, atol=1e-7)
-            assert float((~close).float().mean()) < 1e-4, (other, k, float((~close).float().mean()))
-    # same gradients up to the order of the f64 LDS additions (two accumulate kernels), same optimiser arithmetic
-    close = torch.isclose(res["fused"][5], res["joint"][5], rtol=1e-6, atol=1e-9)
-    assert float((~close).float().mean()) < 1e-5
-
-
-def test_mapstep_render_only_in_one_launch_equals_four_launches():
-    """MapStep.fused_render (opt-in): a render-only call through us_encode_decode_fwd -- both grids and both decoders in one kernel, the
-    features kept in LDS -- renders bit for bit what the encoders and decoders launched one by one render."""
-    import unislam_amd as us
-    torch.manual_seed(5)
-    cfg = _cfg(False, 48, 16)
-    cfg["model"] = {"mlp_precision": "bf16"}
-    dec = us.Decoders(cfg, c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
-    es, ec = us.HashGridEncoding(3, _ecfg(16)).to(DEV), us.HashGridEncoding(3, _ecfg(19)).to(DEV)
-    with torch.no_grad():
-        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
-    R = 777
-    step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=R)
-    ro, rd, gd, gc = _rays(R, seed=8, outside=True)
-    t_rand = torch.rand(R, 64, device=DEV)
-    res = {}
-    for fused in (False, True):
-        step.fused_render = fused
-        stats = step.forward(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False, backward_follows=False)
-        torch.cuda.synchronize()
-        res[fused] = [t.clone() for t in step.rendered()] + [stats.clone(), step.raw[:R].clone()]
-    for a, b in zip(res[True], res[False]):
-        assert torch.equal(a, b)
 
 
 def test_bench_path_replay_equals_eager_and_oracle():

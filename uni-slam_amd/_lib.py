@@ -76,8 +76,6 @@ SIGNATURES = {
     "us_hashgrid_bwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_range": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_binned_range": (c_int, [_GP, c_f, c_f, c_i64, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
-    "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f, c_f, c_f, c_f, c_f, c_f,
-                                           c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_hashgrid_joint_scan": (c_int, [_GP, _GP, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_input": (c_int, [c_f, c_f, c_i64, c_u32, c_f, c_f]),
     "us_hashgrid_bwd_input_gather": (c_int, [_GP, c_f, c_f, c_f, c_i64, c_f, c_int, c_f]),
@@ -88,8 +86,6 @@ SIGNATURES = {
     "us_mlp_fwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_bwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_int,
                                 c_f, c_f, ctypes.c_size_t, c_f]),
-    "us_encode_decode_supported": (c_int, [_GP, _GP, _MP, _MP]),
-    "us_encode_decode_fwd": (c_int, [_GP, _GP, c_f, c_f, _MP, _MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [_MP]),
     "us_mlp_reduce": (c_int, [_MP, c_f, ctypes.c_size_t, c_i64, c_f, c_f]),
     "us_beta_reduce": (c_int, [c_f, c_i64, c_f, c_f]),
@@ -140,6 +136,12 @@ SIGNATURES = {
                                     c_dbl, c_f, c_int, c_f]),
 }
 
+# the experiments build (tools/build_experiments.sh, include/unislam_hip_experiments.h): bound when the loaded library exports them
+EXPERIMENT_SIGNATURES = {
+    "us_encode_decode_supported": (c_int, [_GP, _GP, _MP, _MP]),
+    "us_encode_decode_fwd": (c_int, [_GP, _GP, c_f, c_f, _MP, _MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
+}
+
 _lib = None
 
 
@@ -160,8 +162,18 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+            fn = getattr(l, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = l
     return _lib
+
+
+def has_experiments():
+    """True when the loaded library is the experiments build (exports the measured-slower variants)"""
+    return hasattr(lib(), "us_encode_decode_fwd")
 
 
 def check(rc, what=""):

@@ -640,8 +640,12 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
     const uint32_t chunk0 = (flags & US_GRID_BWD_DETERMINISTIC) ? 0xFFFFFFFFu : (uint32_t)ACC_CHUNK;
     US_REQUIRE(!(scan_only && !counted) && !(scanned && !counted), US_ERR_CONFIG,
                "us_hashgrid_bwd_binned: the scan passes can only run ahead on counts left by us_hashgrid_fwd_counted (US_GRID_BWD_COUNTED)");
+#ifdef US_EXPERIMENTS
     US_REQUIRE(!packed || (d->n_features == 2 && bin_entries(2) <= 2048u), US_ERR_CONFIG,
                "us_hashgrid_bwd_binned: US_GRID_BWD_PACKED needs n_features == 2 (got %u)", d->n_features);
+#else
+    US_REQUIRE(!packed, US_ERR_CONFIG, "us_hashgrid_bwd_binned: US_GRID_BWD_PACKED is part of the experiments build only (tools/build_experiments.sh)");
+#endif
     // (Splitting the levels into groups of ~100 MB of records, so that the accumulate pass would read them from the Infinity
     //  Cache, was measured SLOWER: 0.46 vs 0.36 ms per grid -- the fixed costs of four more passes outweigh the cache hits.)
 #define LAUNCH_BIN_P(F, P)                                                                                                     \
@@ -658,7 +662,11 @@ static int bwd_binned(const us_grid_desc* d, const float* x, const float* dL_dy,
 #define LAUNCH_BIN(F) LAUNCH_BIN_P(F, false)
     switch (d->n_features) {
         case 1: LAUNCH_BIN(1) break;
+#ifdef US_EXPERIMENTS                    // packed 8-byte records: measured (-7 us per grid), not bit-equal; only in the experiments build
         case 2: if (packed) { LAUNCH_BIN_P(2, true) } else { LAUNCH_BIN(2) } break;
+#else
+        case 2: LAUNCH_BIN(2) break;
+#endif
         default: LAUNCH_BIN(4) break;
     }
 #undef LAUNCH_BIN

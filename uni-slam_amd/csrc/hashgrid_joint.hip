@@ -19,8 +19,8 @@
 //                         sorted by bin with their final address, flat copy-out.  The per-level cursors come from the count rows one
 //                         level ahead (wave scans + one LDS fix-up) instead of whole-kernel counter arrays, the gradients of the next
 //                         level are prefetched and consumed before the level's first store;
-//   k_jaccum              one workgroup per (bin, grid): f64 accumulators in LDS (ds_add_f64), the bin's lines of the gradient
-//                         table written once.
+//   k_jaccum_p            persistent workgroups, each one record pipeline over its (bin, grid) items: f64 accumulators in LDS
+//                         (ds_add_f64), the bin's lines of the gradient table written once.
 // Results are those of us_hashgrid_fwd / us_hashgrid_bwd_binned on each grid (tests/test_gpu_joint.py).
 #include "binned_dev.h"
 #include <string.h>
@@ -608,162 +608,6 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// accumulate: one workgroup per (bin, grid) (+ one per extra chunk of a hot bin and grid; those come first in the launch)
-// ---------------------------------------------------------------------------------------------------------------
-// Dense Adam of the two tables fused into the accumulate pass (single process, OVERWRITE): the workgroup that has just summed a bin's
-// entries holds their gradient, and every table entry belongs to exactly one bin -- so it updates p, m, v of its entries on the spot
-// (torch.optim.Adam's arithmetic, as k_adam_segs in render.hip).  The 6 x 51.7 MB of optimiser traffic then flow UNDER the LDS atomics
-// that bound this pass (the entries' p, m, v are requested before the record stream starts) instead of in a 60 us pass of their own.
-// Entries of bins that several workgroups add into (hot bins) are updated by k_jadam_hot afterwards.
-struct JAdam {
-    float *p[2], *m[2], *v[2];                                   // parameters and moments of table A / B (indexed like the gradient tables)
-    float lr[2];
-    float one_minus_b1, b2, one_minus_b2, eps;
-    const float* step_dev;                                       // {count, -, bc1 (double), sqrt(bc2) (double)}, already advanced for this step
-    int enabled;
-};
-__device__ __forceinline__ void adam_entry(float g, float& p, float& m, float& v, float step_size, float bc2_sqrt, const JAdam& ad) {
-    const float mi = m + ad.one_minus_b1 * (g - m);
-    const float vi = v * ad.b2 + (ad.one_minus_b2 * g) * g;
-    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
-    p = p + (-step_size) * (mi / denom);
-    m = mi; v = vi;
-}
-
-__global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum(JLevels lv, uint32_t n_levels, uint32_t e_max,
-                                                          const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
-                                                          const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
-                                                          const uint32_t* __restrict__ rec, float* __restrict__ gradA,
-                                                          float* __restrict__ gradB, int overwrite, JAdam ad) {
-    // accumulators by component: acc[f * nl + loc] (bank spread).  A slice of few entries (the 2^16-entry sdf table: 256 per bin, ~25
-    // records each) is kept in REP copies, lane l adding into copy l % REP: lanes that meet on one entry no longer serialise on one
-    // address; the copies are REP_PAD doubles apart in bank phase and summed in the sweep.
-    __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
-    const uint32_t side = blockIdx.x & 1u, slot = blockIdx.x >> 1;  // side 0: grid A, 1: grid B
-    uint32_t b, chunk = 0;
-    const uint32_t CH = hdr[1];                                  // records per workgroup (k_jscan)
-    if (slot < e_max) {
-        if (slot >= hdr[0]) return;
-        const uint32_t pk = extra[slot];
-        b = pk & 0xFFFFu; chunk = pk >> 16;
-    } else {
-        b = slot - e_max;
-    }
-    const JBin jb = j_bin_of(lv, n_levels, b);
-    if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) return;     // a single-grid bin has no records of the other grid
-    const JLevel q = j_level(lv, jb.level);
-    const uint32_t hs = side ? q.hsB : q.hsA, lg = side ? q.lgB : q.lgA;
-    const uint32_t nl = bin_n_local(hs, jb.bl, lg);
-    const uint32_t REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u, rstride = 2u * nl + 8u;       // copies and their distance in doubles
-    double* my = acc + (threadIdx.x & (REP - 1u)) * rstride;
-    float* gl = (side ? gradB : gradA) + (size_t)(side ? q.offB : q.offA) * 2u;
-    const uint32_t b0 = rec_off[b], b1 = rec_off[b + 1];
-    const bool hot = (b1 - b0) > CH;                             // several workgroups add into this bin's entries
-    // ---- fused Adam: this workgroup's entries (loc = thread + 512 k, k < 4) and their p, m, v, requested now, used in the sweep
-    constexpr int EPT = J_ACC_DOUBLES / 2 / J_ACC_THREADS;       // entries per thread
-    const bool fuse = ad.enabled && overwrite && !hot;
-    float step_size = 0.0f, bc2_sqrt = 1.0f;
-    float2 pp[EPT], mm[EPT], vv[EPT];
-    const size_t eoff = (size_t)(side ? q.offB : q.offA) * 2u;
-    if (fuse) {
-        const double* aux = reinterpret_cast<const double*>(ad.step_dev + 2);
-        step_size = (float)((double)ad.lr[side] / aux[0]);
-        bc2_sqrt = (float)aux[1];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const uint32_t loc = threadIdx.x + k * J_ACC_THREADS, e = entry_of(loc, jb.bl, lg);
-            pp[k] = mm[k] = vv[k] = make_float2(0.0f, 0.0f);
-            if (loc < nl && e < hs) {
-                pp[k] = *reinterpret_cast<const float2*>(ad.p[side] + eoff + (size_t)e * 2u);
-                mm[k] = *reinterpret_cast<const float2*>(ad.m[side] + eoff + (size_t)e * 2u);
-                vv[k] = *reinterpret_cast<const float2*>(ad.v[side] + eoff + (size_t)e * 2u);
-            }
-        }
-    }
-    auto finish = [&](int k, uint32_t e, float g0, float g1) {   // gradient of entry e of this thread's k-th slot: write it, and update
-        float* p = gl + (size_t)e * 2u;
-        *reinterpret_cast<float2*>(p) = make_float2(g0, g1);
-        if (fuse) {
-            adam_entry(g0, pp[k].x, mm[k].x, vv[k].x, step_size, bc2_sqrt, ad);
-            adam_entry(g1, pp[k].y, mm[k].y, vv[k].y, step_size, bc2_sqrt, ad);
-            *reinterpret_cast<float2*>(ad.p[side] + eoff + (size_t)e * 2u) = pp[k];
-            *reinterpret_cast<float2*>(ad.m[side] + eoff + (size_t)e * 2u) = mm[k];
-            *reinterpret_cast<float2*>(ad.v[side] + eoff + (size_t)e * 2u) = vv[k];
-        }
-    };
-    if (b0 == b1) {                                              // nothing landed in this bin (wave-uniform): zero gradient (Adam still moves)
-        if (overwrite) {
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const uint32_t loc = threadIdx.x + k * J_ACC_THREADS, e = entry_of(loc, jb.bl, lg);
-                if (loc < nl && e < hs) finish(k, e, 0.0f, 0.0f);
-            }
-        }
-        return;
-    }
-    const uint32_t r0 = b0 + chunk * CH;
-    const uint32_t r1 = (b1 - r0 > CH) ? r0 + CH : b1;
-    const uint32_t r_last = r1 - 1u;
-    // the bin's region: [A records][B records] for a joint bin, the one grid's records otherwise
-    const uint32_t* base = rec + (size_t)dw_off[b] + ((jb.kind == 0u && side == 1u) ? (size_t)(b1 - b0) * 3u : (size_t)0);
-    constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL;
-    // Software-pipelined record stream, two register buffers, every load unconditional (past the end it re-reads the last record):
-    // a load behind a branch of its own is waited for at the end of that branch (see hashgrid_binned.hip).
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-    u32x3 w3[2][J_ACC_UNROLL];
-    auto fetch = [&](int buf, uint32_t at) {
-#pragma unroll
-        for (int u = 0; u < J_ACC_UNROLL; ++u) {
-            const uint32_t r = min(at + u * J_ACC_THREADS + threadIdx.x, r_last);
-            w3[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(base + (size_t)(r - b0) * 3u));
-        }
-    };
-    auto add = [&](int buf, uint32_t at) {
-#pragma unroll
-        for (int u = 0; u < J_ACC_UNROLL; ++u) {
-            if (at + u * J_ACC_THREADS + threadIdx.x <= r_last) {
-                const uint32_t lc = w3[buf][u].x;
-                if (lc < nl) {
-                    atomicAdd(&my[lc], (double)__uint_as_float(w3[buf][u].y));                // ds_add_f64
-                    atomicAdd(&my[nl + lc], (double)__uint_as_float(w3[buf][u].z));
-                }
-            }
-        }
-    };
-    fetch(0, r0);                                                // in flight while the accumulators are cleared
-    for (uint32_t k = threadIdx.x; k < REP * rstride; k += J_ACC_THREADS) acc[k] = 0.0;
-    __syncthreads();
-    for (uint32_t at = r0;;) {
-        fetch(1, at + STEP); add(0, at); at += STEP;
-        if (at >= r1) break;
-        fetch(0, at + STEP); add(1, at); at += STEP;
-        if (at >= r1) break;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const uint32_t loc = threadIdx.x + k * J_ACC_THREADS;
-        if (loc >= nl) continue;
-        const uint32_t e = entry_of(loc, jb.bl, lg);
-        if (e >= hs) continue;
-        float* p = gl + (size_t)e * 2u;
-        double s0 = acc[loc], s1 = acc[nl + loc];
-        for (uint32_t r = 1; r < REP; ++r) { s0 += acc[r * rstride + loc]; s1 += acc[r * rstride + nl + loc]; }   // fixed order
-        const float v0 = (float)s0, v1 = (float)s1;
-        if (hot) {
-            if (v0 != 0.0f) atomicAdd(p, v0);
-            if (v1 != 0.0f) atomicAdd(p + 1, v1);
-        } else if (overwrite) {
-            finish(k, e, v0, v1);
-        } else if (v0 != 0.0f || v1 != 0.0f) {                   // this workgroup is the only writer of its entries
-            float2 o = *reinterpret_cast<const float2*>(p);
-            o.x += v0; o.y += v1;
-            *reinterpret_cast<float2*>(p) = o;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // accumulate, persistent form: J_ACCP_GROUPS workgroups (four per CU), each takes the items t = blockIdx.x + k * gridDim.x
 // (item = (bin or extra chunk of a hot bin, grid), the extra chunks -- the largest items -- first).  One workgroup per item spends most
 // of its life outside the record stream: arguments, offsets, first records, clear, two barriers, sweep -- ~12 us for ~50 KB of
@@ -839,9 +683,9 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
     // ---- the request side of the pipeline: item fk, records from fa on
     uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
     auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
-    auto fetch = [&](auto tag) {                                 // every load unconditional (a load behind a branch of its own costs the waits
-        constexpr int buf = decltype(tag)::value;                // their order: see k_jaccum): past the end of an item, and past the last
-                                                                 // item of the workgroup, it re-reads the last record
+    auto fetch = [&](auto tag) {                                 // every load unconditional (the compiler closes a conditional block with
+        constexpr int buf = decltype(tag)::value;                // s_waitcnt vmcnt(0): ONE record in flight per thread): past the end of an
+                                                                 // item, and past the last item of the workgroup, it re-reads the last record
         const uint32_t* base = rec + (size_t)f_base;
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
@@ -856,7 +700,9 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
     double* my = acc;
     auto a_load = [&]() {
         a = field(JI_C0, k); c1 = field(JI_C1, k); nl = field(JI_NL, k); misc = field(JI_MISC, k); hs = field(JI_HS, k); goff = field(JI_GOFF, k);
-        REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;                   // as in k_jaccum
+        // slices of few entries (the sdf table: 256 per bin, 25 records per entry) are kept in 4 copies, which thins out same-address
+        // collisions of the LDS atomics; the copies sit 2 nl + 8 doubles apart (bank spread)
+        REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;
         my = acc + (tid & (REP - 1u)) * rstride;
     };
     auto sweep = [&]() {                                         // sums of the item -> gradient table; the accumulators return to zero
@@ -927,37 +773,6 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
             const uint32_t e = entry_of(loc, zm & 0xFFFFu, (zm >> 16) & 0xFFu);
             if (e < zhs) *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
         }
-    }
-}
-
-// fused Adam, the entries of hot bins: their gradient was added by several workgroups of k_jaccum; one workgroup per hot bin and grid
-__global__ __launch_bounds__(J_ACC_THREADS) void k_jadam_hot(JLevels lv, uint32_t n_levels, const uint32_t* __restrict__ extra,
-                                                             const uint32_t* __restrict__ hdr, const float* __restrict__ gradA,
-                                                             const float* __restrict__ gradB, JAdam ad) {
-    const uint32_t side = blockIdx.y;
-    if (blockIdx.x >= hdr[0]) return;
-    const uint32_t pk = extra[blockIdx.x];
-    if ((pk >> 16) != 1u) return;                                // the first extra chunk of a bin stands for the bin
-    const JBin jb = j_bin_of(lv, n_levels, pk & 0xFFFFu);
-    if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) return;
-    const JLevel q = j_level(lv, jb.level);
-    const uint32_t hs = side ? q.hsB : q.hsA, lg = side ? q.lgB : q.lgA, nl = bin_n_local(hs, jb.bl, lg);
-    const size_t eoff = (size_t)(side ? q.offB : q.offA) * 2u;
-    const float* g = (side ? gradB : gradA) + eoff;
-    const double* aux = reinterpret_cast<const double*>(ad.step_dev + 2);
-    const float step_size = (float)((double)ad.lr[side] / aux[0]), bc2_sqrt = (float)aux[1];
-    for (uint32_t loc = threadIdx.x; loc < nl; loc += J_ACC_THREADS) {
-        const uint32_t e = entry_of(loc, jb.bl, lg);
-        if (e >= hs) continue;
-        const float2 gg = *reinterpret_cast<const float2*>(g + (size_t)e * 2u);
-        float2 pp = *reinterpret_cast<const float2*>(ad.p[side] + eoff + (size_t)e * 2u);
-        float2 mm = *reinterpret_cast<const float2*>(ad.m[side] + eoff + (size_t)e * 2u);
-        float2 vv = *reinterpret_cast<const float2*>(ad.v[side] + eoff + (size_t)e * 2u);
-        adam_entry(gg.x, pp.x, mm.x, vv.x, step_size, bc2_sqrt, ad);
-        adam_entry(gg.y, pp.y, mm.y, vv.y, step_size, bc2_sqrt, ad);
-        *reinterpret_cast<float2*>(ad.p[side] + eoff + (size_t)e * 2u) = pp;
-        *reinterpret_cast<float2*>(ad.m[side] + eoff + (size_t)e * 2u) = mm;
-        *reinterpret_cast<float2*>(ad.v[side] + eoff + (size_t)e * 2u) = vv;
     }
 }
 
@@ -1140,7 +955,7 @@ extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, con
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
                      float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
-                     int64_t plane_stride = 0, const JAdam* adam = nullptr) {
+                     int64_t plane_stride = 0) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -1183,26 +998,14 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
     const int side_sel = (flags & US_GRID_BWD_ONLY_A) ? 0 : ((flags & US_GRID_BWD_ONLY_B) ? 1 : -1);
     US_REQUIRE(!((flags & US_GRID_BWD_ONLY_A) && (flags & US_GRID_BWD_ONLY_B)), US_ERR_CONFIG, "us_hashgrid_bwd_joint: ONLY_A and ONLY_B are exclusive");
-    US_REQUIRE(!(flags & US_GRID_BWD_RECORDS_READY) || (side_sel >= 0 && !adam), US_ERR_CONFIG,
+    US_REQUIRE(!(flags & US_GRID_BWD_RECORDS_READY) || side_sel >= 0, US_ERR_CONFIG,
                "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
-    US_REQUIRE(side_sel < 0 || !adam, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: both grids in one call");
     if (!(flags & US_GRID_BWD_RECORDS_READY))
         hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
                            w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
-    JAdam ad;
-    memset(&ad, 0, sizeof(ad));
-    if (adam) {
-        US_REQUIRE(overwrite, US_ERR_CONFIG, "us_hashgrid_bwd_joint_adam: needs US_GRID_BWD_OVERWRITE (the update uses the complete gradient)");
-        ad = *adam; ad.enabled = 1;
-    }
     const uint32_t n_acc_items = (side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB);
-    if (!adam)
-        hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                           (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite, side_sel);
-    else
-        hipLaunchKernelGGL(k_jaccum, dim3(n_acc_items), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, w.rec_off, w.dw_off,
-                           w.extra, w.hdr, w.rec, gradA, gradB, overwrite, ad);
-    if (adam) hipLaunchKernelGGL(k_jadam_hot, dim3(ACC_EXTRA_MAX, 2), dim3(J_ACC_THREADS), 0, s, lv, L, w.extra, w.hdr, gradA, gradB, ad);
+    hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
+                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite, side_sel);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
 }
@@ -1227,19 +1030,4 @@ extern "C" int us_hashgrid_bwd_joint_range(const us_grid_desc* a, const us_grid_
     US_REQUIRE(!(flags & (US_GRID_BWD_COUNTED | US_GRID_BWD_SCANNED)), US_ERR_CONFIG,
                "us_hashgrid_bwd_joint_range: the counts of a forward pass belong to the whole batch, not to a range of it");
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, plane_stride);
-}
-
-extern "C" int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
-                                          const float* dL_dyB, int64_t n, float* gradA, float* gradB, int flags, void* workspace,
-                                          size_t workspace_bytes, float* paramsA, float* paramsB, float* mA, float* mB, float* vA, float* vB,
-                                          double lrA, double lrB, double beta1, double beta2, double eps, const float* step_dev, void* stream) {
-    US_REQUIRE(paramsA && paramsB && mA && mB && vA && vB && step_dev, US_ERR_NULL, "us_hashgrid_bwd_joint_adam: NULL pointer");
-    US_REQUIRE(n > 0, US_ERR_SHAPE, "us_hashgrid_bwd_joint_adam: empty batch (use us_adam_step_segments)");
-    JAdam ad;
-    memset(&ad, 0, sizeof(ad));
-    ad.p[0] = paramsA; ad.p[1] = paramsB; ad.m[0] = mA; ad.m[1] = mB; ad.v[0] = vA; ad.v[1] = vB;
-    ad.lr[0] = (float)lrA; ad.lr[1] = (float)lrB;
-    ad.one_minus_b1 = (float)(1.0 - beta1); ad.b2 = (float)beta2; ad.one_minus_b2 = (float)(1.0 - beta2); ad.eps = (float)eps;
-    ad.step_dev = step_dev;
-    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, &ad);
 }

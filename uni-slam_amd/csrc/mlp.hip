@@ -771,4 +771,6 @@ extern "C" int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, 
 }
 
 #include <string.h>
+#ifdef US_EXPERIMENTS                    // measured-slower variants, kept buildable: tools/build_experiments.sh (include/unislam_hip_experiments.h)
 #include "encode_decode.inc"
+#endif

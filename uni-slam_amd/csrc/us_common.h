@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/unislam_hip.h"
+#include "../../include/unislam_hip_experiments.h"   // declarations only; the definitions are compiled with -DUS_EXPERIMENTS
 
 #define US_WAVE 64
 

@@ -36,7 +36,7 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 class MapStep:
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
-                 packed_records=False, joint=None, deterministic=False, max_workspace_bytes=4 << 30, fuse_adam=False, dp_mode="local_fast"):
+                 joint=None, deterministic=False, max_workspace_bytes=4 << 30, dp_mode="local_fast"):
         """
         hash_grid_sdf / hash_grid_color: HashGridEncoding;  decoders: Decoders (either parameterisation);
         weights: dict(fs, center, tail, color, depth)   (cfg['mapping']['w_*'], src/Mapper.py:63-67);
@@ -45,13 +45,13 @@ class MapStep:
         joint: encode both grids in one launch and form both table gradients in one binned pass (us_hashgrid_fwd_joint /
                  us_hashgrid_bwd_joint: the grids share cells, runs and hashes).  Default: yes when the pair of grids qualifies (with a
                  process group: see dp_mode -- the accumulate pass is then split per grid, the colour table first).
-                 Measured at 4096 x 64 (room0 tables): the iteration takes the same 0.66 ms either way -- the two one-grid chains overlap on
-                 two streams -- but the table gradient itself is 262 us for both grids against 157 + 147; render-only calls
-                 (backward_follows=False) run the joint encoder without counts and both decoders in one launch (render_joint).
+                 Measured at 4096 x 64 (room0 tables): the table gradient is 262 us for both grids against 157 + 147; render-only calls
+                 (backward_follows=False) run the joint encoder without counts and both decoders in one launch.
         overlap: use side streams -- one-grid kernels: the sdf branch (encode, decode and their backward) beside the colour branch; joint
-                 kernels: the binning's scans and the small reductions beside the main chain (the decoders stay on the main stream:
-                 decoders_side_by_side); default: yes for a single process; no with a process group, where the branches run one after
-                 the other so that the all-reduce of the colour-table gradient hides behind the sdf branch.
+                 kernels: the binning's scans and the small reductions beside the main chain (the decoders stay on the main stream: a
+                 dependency across queues costs 10-14 us, and the decoder kernels fill the chip on their own).  Default: see dp_mode.
+        max_workspace_bytes: budget of ONE scratch set of the table gradient (the joint path has one; the one-grid path two, one per
+                 branch): a batch that would need more is walked in ranges of rays.  Default 4 GiB.
         """
         assert isinstance(hash_grid_sdf, HashGridEncoding) and isinstance(hash_grid_color, HashGridEncoding)
         assert isinstance(decoders, Decoders)
@@ -65,27 +65,13 @@ class MapStep:
         self.dp_mode = dp_mode
         fast_default = group is None or dp_mode == "local_fast"
         self.overlap, self.side, self.scan_stream = fast_default if overlap is None else bool(overlap), None, None
-        # opt-in: render-only calls (forward(backward_follows=False)) as ONE launch (us_encode_decode_fwd: both grids, both decoders, the features
-        # kept in LDS) where the model qualifies.  Bit-identical, but measured slower than the four launches (0.20 against 0.18 ms at 4096 x 64:
-        # csrc/encode_decode.inc), so off.
-        self.fused_render = False
-        # The two decoders on two streams (joint path)?  Under graph replay a dependency ACROSS queues costs 10-14 us where kernels that
-        # follow each other on one queue start back to back, and the decoder kernels fill the chip on their own: 0.614 -> 0.59 ms at
-        # 4096 x 64 with the decoders one after the other on the main stream (the scans and the small reductions keep their side streams).
-        self.decoders_side_by_side = False
-        self.render_joint = True
-        self.decoder_pair = True        # ... and, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
+        self.decoder_pair = True        # the two decoders, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
         self._dec_grad_clean = False
         self._step_advanced = False
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
         # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
         # window.MapWindow for the iterations that optimise camera poses (src/Mapper.py:372-376); costs 2 x 24 B per point and level.
         self.store_dydx, self._dydx_valid, self.dydx_s, self.dydx_c = False, False, None, None
-        # fuse_adam (opt-in): iterate() of a single process lets the accumulate pass of the joint table gradient apply Adam to the table
-        # entries it has just summed (us_hashgrid_bwd_joint_adam); adam_step() then covers the decoders only.  Measured at 4096 x 64: the
-        # accumulate pass grows from 106 to 203 us -- a bin's entries are 128-byte lines 32 KB apart, and six arrays of such lines do not
-        # stream like the dense pass's contiguous 6 TB/s -- against the 60 us the separate pass costs: 0.690 instead of 0.612 ms.  Off.
-        self.fuse_adam = bool(fuse_adam)
         self._joint_wanted = fast_default if joint is None else bool(joint)
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
@@ -95,16 +81,11 @@ class MapStep:
         # the gradient tables, the others adding: 4096 x 64 needs 0.8 GB, the 32 768-ray sweep point 6.6 GB -> two ranges.
         self.max_ws = int(max_workspace_bytes)
         self.count_in_forward, self._counted = True, False
-        # opt-in: issue the binning's two scan passes right after each encoder (us_hashgrid_bwd_scan) instead of inside the gradient call.
-        # Measured at 4096 x 64: eager 0.722 -> 0.714 ms, nothing under graph replay, forward-only 0.202 -> 0.214 ms: off by default.
-        self.scan_in_forward, self._scanned = False, False
         self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
         self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
         if self.sharded_adam and grad_comm in ("bf16", torch.bfloat16):
             raise L.UniSlamHipError("MapStep: grad_comm='bf16' and sharded_adam=True are exclusive (the reduce-scatter runs in place on "
                                     "the fp32 gradient buffer); choose one")
-        # 8-byte intermediate records in the binned table gradient (US_GRID_BWD_PACKED; F = 2 grids only)
-        self._packed = L.US_GRID_BWD_PACKED if (packed_records and hash_grid_sdf.desc.n_features == 2 and hash_grid_color.desc.n_features == 2) else 0
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
         self.zd_rows = None                                                                # scratch of the zero-depth branch, on first use
         dev = hash_grid_sdf.params.device
@@ -178,6 +159,7 @@ class MapStep:
 
     def reset_optimizer(self, lr_factor=1.0):
         """Mapper.py:358-364: a fresh Adam for every mapped frame (moments and step count restart)."""
+        self._join_side_streams()
         self.m.zero_(); self.v.zero_()
         self.opt_step = 0
         self.step_dev.zero_()
@@ -185,8 +167,17 @@ class MapStep:
         self.lr_factor = float(lr_factor)
         self._graph = None              # a captured iteration holds the old learning rates
 
+    def _join_side_streams(self):
+        """the main stream waits for whatever a previous call left on the scan / side streams (the scans of a forward pass whose backward
+        pass never came read the workspace; a queued step increment touches step_dev)"""
+        for q in (getattr(self, "scan_stream", None), getattr(self, "side", None)):
+            if q is not None:
+                torch.cuda.current_stream().wait_stream(q)
+
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self, R):
+        self._join_side_streams()
+        self._step_advanced = False
         dev, S = self.device, self.S
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -204,44 +195,41 @@ class MapStep:
         self.beta_part = f(R)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
         lib = L.lib()
+        da, db = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        one_grid = lambda n: max(int(lib.us_hashgrid_bwd_workspace_bytes(da, n)), int(lib.us_hashgrid_bwd_workspace_bytes(db, n)))
+        joint_ok = lambda n: bool(self._joint_wanted and self.bwd_mode in (-1, 3) and lib.us_hashgrid_joint_supported(da, db, n))
+        binned_ok = lambda n: bool(lib.us_hashgrid_bwd_binned_supported(da, n) and lib.us_hashgrid_bwd_binned_supported(db, n))
+        # scratch of the path actually taken: ONE set for the joint kernels, two (one per branch: they run on two streams) for the
+        # one-grid kernels; max_workspace_bytes bounds a set.  A batch whose set would be larger (or whose records outgrow the 32-bit
+        # record addresses) is walked in ranges of chunk_rays rays; a TABLE beyond the bin budget takes the LDS-sliced kernels.
+        need = lambda n: int(lib.us_hashgrid_joint_workspace_bytes(da, db, n)) if joint_ok(n) else one_grid(n)
         self.chunk_rays = 0                                # > 0: the table gradient walks the batch in ranges of this many rays
-        N_all = N
-        need = lambda n: max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), n)),
-                             int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), n)),
-                             int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), n)))
-        if self.bwd_mode in (-1, 3) and need(N) > self.max_ws and R > 16:
-            parts = 2
-            while need(-(-R // parts) * S) > self.max_ws and -(-R // parts) > 16:
+        if self.bwd_mode in (-1, 3):
+            parts = 1
+            while True:
+                r_k = -(-R // parts)
+                if ((joint_ok(r_k * S) or binned_ok(r_k * S)) and need(r_k * S) <= self.max_ws) or r_k <= 16:
+                    break
                 parts += 1
-            self.chunk_rays = -(-R // parts)
-            N = self.chunk_rays * S                        # the scratch below is sized for one range
-        self.ws_bytes = max(int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.es.desc), N)),
-                            int(lib.us_hashgrid_bwd_workspace_bytes(ctypes.byref(self.ec.desc), N)))
-        if self.bwd_mode == -1 and not (lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.es.desc), N) and
-                                        lib.us_hashgrid_bwd_binned_supported(ctypes.byref(self.ec.desc), N)):
-            self.bwd_mode = 1               # a table / batch beyond the binned path's budget: LDS-sliced kernels
-        self.joint = bool(self._joint_wanted and self.bwd_mode in (-1, 3) and not self._packed and
-                          lib.us_hashgrid_joint_supported(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
-        if self.joint:                                     # one scratch set: counts of both grids, joint records
-            self.ws_bytes = int(lib.us_hashgrid_joint_workspace_bytes(ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc), N))
-            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
-            self.ws_s = self.ws
-        # one scratch set per branch (sdf / colour): the two branches run on two streams
+            if parts > 1:
+                self.chunk_rays = r_k
+                N = r_k * S                                # the scratch below is sized for one range
+            if self.bwd_mode == -1 and not (joint_ok(N) or binned_ok(N)):
+                self.bwd_mode, self.chunk_rays, N = 1, 0, R * S
+        self.joint = joint_ok(N)
+        self.ws_bytes = need(N) if self.bwd_mode in (-1, 3) else 0
         mk_ws = lambda: torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev) if self.bwd_mode in (-1, 3) else None
-        if not self.joint:
-            self.ws, self.ws_s = mk_ws(), mk_ws()          # the forward pass leaves each branch's binning counts in its own
+        self.ws = mk_ws()
+        self.ws_s = self.ws if (self.joint or self.ws is None) else mk_ws()    # the forward pass leaves each branch's binning counts in its own
         self.mlp_ws_bytes = max(int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_s))),
                                 int(lib.us_mlp_bwd_workspace_bytes(ctypes.byref(self.desc_c))))
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
         self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)      # (one per decoder: they may run in one launch)
-        if self.ws_s is None:
-            self.ws_s = self.ws
-        N = N_all
 
     def _decoder_pair(self):
         """joint path: run the two decoders as ONE launch each way (us_mlp_fwd_pair / us_mlp_bwd_pair)?  Yes when they have one shape and a
-        bf16 precision and are not asked to run side by side on two streams."""
-        return bool(self.decoder_pair and not self.decoders_side_by_side and
+        bf16 precision."""
+        return bool(self.decoder_pair and
                     L.lib().us_mlp_pair_supported(ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)))
 
     class _Branch:
@@ -303,6 +291,10 @@ class MapStep:
         backward_follows: False for a render-only call (the encoders then skip the bookkeeping they do for the table gradient).
         presampled: the pre-filter flags, z and the unit-cube points of these rays are already in self.valid / self.z / self.pts
         (window.MapWindow forms rays and samples in one launch).
+        Side effects with backward_follows (joint kernels, side streams): the call is the first half of ONE optimiser step -- it queues the
+        binning's scans (which in OVERWRITE mode clear the entries of hot bins in self.grad) and Adam's step increment on the scan
+        stream and notes that in self._step_advanced; backward() joins that stream and adam_step() consumes the note.  Pair every such
+        forward() with backward() and adam_step() (iterate() / MapWindow do); use backward_follows=False for a render-only call.
         """
         lib, st = L.lib(), L.stream()
         self._probing = self.probe is not None and (self._it % max(1, self.probe_every) == 0)
@@ -362,11 +354,6 @@ class MapStep:
             backward_follows = False                             # the counts of a forward pass belong to the whole batch, not to its ranges
         counted = self.ws is not None and self.count_in_forward and backward_follows
         self._counted = counted
-        # ... and, if asked for, the two scan passes of the binning, which depend on those counts only, follow the encoder at once (a
-        # probed step keeps them inside the timed gradient call)
-        scan = counted and self.scan_in_forward and not self._probing
-        self._scanned = scan
-        bflags = 3 | L.US_GRID_BWD_OVERWRITE | self._packed | self._det
         self._jcounted = False
         if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
@@ -391,9 +378,7 @@ class MapStep:
             # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
             scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                                                              3 | L.US_GRID_BWD_OVERWRITE | self._det, P(self.ws), self.ws_bytes, q)
-            if not self._jcounted:
-                pass
-            elif self._probing or not self.overlap:
+            if self._probing or not self.overlap:
                 self._timed("hashgrid_scan_joint", lambda: scan_call(st))
             else:
                 if self.scan_stream is None:
@@ -408,21 +393,11 @@ class MapStep:
                 self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
                                                                         off(self.raw, 3), 4, P(self.raw), 4, 1, st))
                 return self._finish_forward(o, d, gd, gc, R)
-            if self.decoders_side_by_side:
-                with self._branch() as st2:
-                    self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
-            else:
-                self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
+            # decoders of different shapes: one after the other on the main stream
+            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
             self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
-            if self.decoders_side_by_side:
-                self._join()
             return self._finish_forward(o, d, gd, gc, R)
-        if not backward_follows and self.fused_render and lib.us_encode_decode_supported(ds, dc, ms, mc):
-            # a render-only call: both grids and both decoders in one launch, the features never leave the CU (csrc/encode_decode.inc)
-            self._timed("encode_decode", lambda: lib.us_encode_decode_fwd(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), ms, mc, off(fl, self.o_dec_s),
-                                                                          off(fl, self.o_dec_c), P(self.pts), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
-            return self._finish_forward(o, d, gd, gc, R)
-        if not backward_follows and self.render_joint and self.joint and self._decoder_pair():
+        if not backward_follows and self.joint and self._decoder_pair():
             # a render-only call on ONE stream: both encoders in one launch (no binning counts), both decoders in one launch
             self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
                                                                                 P(self.feat_s), P(self.feat_c), 3, None, 0, st))
@@ -433,16 +408,12 @@ class MapStep:
             if counted:
                 self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd_counted(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), 3,
                                                                                     P(self.ws_s), self.ws_bytes, st2))
-                if scan:
-                    L.check(lib.us_hashgrid_bwd_scan(ds, N, off(self.grad, self.o_tab_s), bflags, P(self.ws_s), self.ws_bytes, st2), "us_hashgrid_bwd_scan")
             else:
                 self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
             self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
         if counted:
             self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd_counted(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), 3,
                                                                                   P(self.ws), self.ws_bytes, st))
-            if scan:
-                L.check(lib.us_hashgrid_bwd_scan(dc, N, off(self.grad, self.o_tab_c), bflags, P(self.ws), self.ws_bytes, st), "us_hashgrid_bwd_scan")
         else:
             self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
         self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
@@ -460,7 +431,7 @@ class MapStep:
         self.n_rays = R
         return self.stats
 
-    def backward(self, on_ready=None, ray_grads=False, fuse_adam=False):
+    def backward(self, on_ready=None, ray_grads=False):
         """
         Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
         ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
@@ -505,7 +476,7 @@ class MapStep:
                                                               P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
-                                                                                  3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws_s), self.ws_bytes, q))
+                                                                                  3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws_s), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_params(ds, P(self.pts), P(self.d_feat_s), N,
                                                                                   off(self.grad, self.o_tab_s), self.bwd_mode, 3, q))
@@ -515,7 +486,7 @@ class MapStep:
                                                                 N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
-                                                                                    3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0) | (L.US_GRID_BWD_SCANNED if self._scanned else 0) | self._packed, P(self.ws), self.ws_bytes, q))
+                                                                                    3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws), self.ws_bytes, q))
             else:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_params(dc, P(self.pts), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_c), self.bwd_mode, 3, q))
@@ -535,15 +506,9 @@ class MapStep:
                                                                         off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws_s), P(self.mlp_ws),
                                                                         self.mlp_ws_bytes, st))
             else:
-                if self.decoders_side_by_side:
-                    with self._branch() as st2:
-                        mlp_s(st2)
-                else:
-                    mlp_s(st)
+                mlp_s(st)
                 self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                                     N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
-                if self.decoders_side_by_side:
-                    self._join()                                 # the main stream waits for the sdf decoder's backward pass, nothing later
             if defer:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
                     if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
@@ -562,18 +527,7 @@ class MapStep:
             if self.scan_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.scan_stream)
             jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
-            self._adam_fused = bool(fuse_adam and self.fuse_adam and self.group is None)
-            if self._adam_fused:
-                if not self._step_advanced:                      # (a forward pass that did not queue it: probing / one-stream mode)
-                    L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
-                    self._step_advanced = True
-                f_ = self.lr_factor
-                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint_adam(
-                    ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
-                    P(self.ws), self.ws_bytes, off(fl, self.o_tab_s), off(fl, self.o_tab_c), off(self.m, self.o_tab_s), off(self.m, self.o_tab_c),
-                    off(self.v, self.o_tab_s), off(self.v, self.o_tab_c), self.lr["sdf_grid"] * f_, self.lr["color_grid"] * f_, 0.9, 0.999, 1e-8,
-                    P(self.step_dev), st))
-            elif on_ready is not None:
+            if on_ready is not None:
                 # someone waits for the segments (the data-parallel step): the record pass for both grids, then the accumulate pass per
                 # grid, colour first -- its 44.7 MB all-reduce starts while the sdf table is still being summed
                 self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
@@ -646,9 +600,9 @@ class MapStep:
                 L.check(lib.us_hashgrid_bwd_joint_range(ds, dc, x, dya, dyb, n_k, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                                                         flags, P(self.ws), self.ws_bytes, st), "us_hashgrid_bwd_joint_range")
             else:
-                L.check(lib.us_hashgrid_bwd_binned_range(dc, x, dyb, n_k, N, off(self.grad, self.o_tab_c), flags | self._packed, P(self.ws),
+                L.check(lib.us_hashgrid_bwd_binned_range(dc, x, dyb, n_k, N, off(self.grad, self.o_tab_c), flags, P(self.ws),
                                                          self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
-                L.check(lib.us_hashgrid_bwd_binned_range(ds, x, dya, n_k, N, off(self.grad, self.o_tab_s), flags | self._packed, P(self.ws_s),
+                L.check(lib.us_hashgrid_bwd_binned_range(ds, x, dya, n_k, N, off(self.grad, self.o_tab_s), flags, P(self.ws_s),
                                                          self.ws_bytes, st), "us_hashgrid_bwd_binned_range")
         if on_ready is not None:
             on_ready(self.grad[self.o_tab_c:])
@@ -676,9 +630,6 @@ class MapStep:
         if ranges is None:
             segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
             self._dec_grad_clean = True                          # cleared on the way
-            if getattr(self, "_adam_fused", False):              # the tables were updated inside the table gradient's accumulate pass
-                segs = segs[:1]
-                self._adam_fused = False
         else:
             segs, zero_mask = [], 0
             for (lo, hi) in ranges:
@@ -701,11 +652,6 @@ class MapStep:
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, presampled=False):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
-        if self.group is None and self.fuse_adam:
-            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, presampled=presampled)
-            loss = self.backward(fuse_adam=True)                 # ... which updates the tables where the joint pass runs
-            self.adam_step()
-            return loss
         return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled), self.group)
 
     def capture(self, n_rays, t_rand=False):
@@ -720,6 +666,10 @@ class MapStep:
         from .graph import CapturedIteration
         if self.group is not None:
             raise L.UniSlamHipError("MapStep.capture: single-process only (the data-parallel step waits on RCCL work handles)")
+        if self._step_advanced:
+            raise L.UniSlamHipError("MapStep.capture: a forward pass is pending (its step increment is queued): finish the optimiser step "
+                                    "(backward + adam_step) first -- the captured iteration carries its own increment")
+        self._join_side_streams()
         dev = self.device
         f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         ins = [f(n_rays, 3), f(n_rays, 3) + 1.0, f(n_rays) + 1.0, f(n_rays, 3)]

@@ -152,6 +152,9 @@ class MapWindow:
                                     "the host); run iterate() for this window")
         if s.group is not None:
             raise L.UniSlamHipError("MapWindow.capture: single-process only")
+        if s._step_advanced:
+            raise L.UniSlamHipError("MapWindow.capture: a forward pass of the MapStep is pending; finish its optimiser step first")
+        s._join_side_streams()
         was, s.probe = s.probe, None
         self.t_rand = torch.zeros((self.R, s.S), dtype=torch.float32, device=s.device) if t_rand else None
         keep = (s.flat.clone(), s.m.clone(), s.v.clone(), s.step_dev.clone(), s.opt_step, dict(s.lr), s.rng_calls, self.poses.clone(),
