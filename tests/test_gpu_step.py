@@ -773,7 +773,7 @@ def test_mapstep_table_gradient_in_ranges(joint):
         step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
         res[budget] = (g, loss.clone(), step.flat.clone(), step.ws_bytes)
     a, b = res[4 << 30], res[48 << 20]
-    assert b[3] * 2 < a[3]
+    assert b[3] < 0.6 * a[3]                                  # (one-grid kernels: 63 MB per scratch set -> two ranges of 31 MB)
     assert torch.equal(a[1], b[1])
     assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6 * float(a[0].abs().max()))
     close = torch.isclose(a[2], b[2], rtol=1e-5, atol=1e-6)
