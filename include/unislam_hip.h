@@ -182,9 +182,9 @@ int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uin
 int us_hashgrid_bwd_input_gather(const us_grid_desc* desc_host, const float* params, const float* x, const float* dL_dy,
                                  int64_t n, float* dL_dx, int flags, void* stream);
 
-/* us_hashgrid_fwd_joint that also leaves d(features)/d(position) of both grids: dy_dxA / dy_dxB = level-major planes [L][N][3][2]
- * (plane l, point i, dimension gd: the two features' derivatives; tcnn's dy_dx with the clamp's zero gradient folded in), 24 B per
- * (point, level, grid), written coalesced by the threads that hold the 8 vertices anyway.  us_hashgrid_dydx_rays contracts them with
+/* us_hashgrid_fwd_joint that also leaves d(features)/d(position) of both grids: dy_dxA / dy_dxB = planes [L][3][N][2]
+ * (level l, dimension gd, point i: the two features' derivatives; tcnn's dy_dx with the clamp's zero gradient folded in), 24 B per
+ * (point, level, grid), written in whole lines by the threads that hold the 8 vertices anyway.  us_hashgrid_dydx_rays contracts them with
  * dL/dy and reduces to the rays: dL_do, dL_dd (and the per-point dL_dx, nullable) are bit-identical to us_hashgrid_bwd_input_rays, at
  * the price of a stream instead of a second gather pass over the tables (MI355X, 2000 x 40 points: 20 against 65 us).  For the
  * iterations that differentiate with respect to the camera: src/Tracker.py:170-174,241 and src/Mapper.py:372-376,444. */

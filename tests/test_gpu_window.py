@@ -131,9 +131,9 @@ def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
                                            P_(go2), P_(gd2), None, 3, L.stream()), "us_hashgrid_bwd_input_rays")
     assert torch.equal(go2, go) and torch.equal(gd2, gd)
     assert lib.us_hashgrid_bwd_input_rays_supported(ds, dc, 129) == 0
-    # the stored-derivative path: the joint encoder leaves dy/dx (level-major [L][N][3][2]), one streaming launch contracts it
+    # the stored-derivative path: the joint encoder leaves dy/dx (planes [L][3][N][2]), one streaming launch contracts it
     fa, fb, fa0, fb0 = f(16, N, 2), f(16, N, 2), f(16, N, 2), f(16, N, 2)
-    dda, ddb = f(16, N, 3, 2), f(16, N, 3, 2)
+    dda, ddb = f(16, 3, N, 2), f(16, 3, N, 2)                                   # planes [L][3][N][2]
     L.check(lib.us_hashgrid_fwd_joint(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), N, P_(fa0), P_(fb0), 3, None, 0, L.stream()), "fwd")
     L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), N, P_(fa), P_(fb), P_(dda), P_(ddb), 3,
                                            None, 0, L.stream()), "us_hashgrid_fwd_joint_dydx")
@@ -141,7 +141,7 @@ def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
     # dy/dx against the one-grid encoder's stored tensor [N][C][3]
     ref_dd = f(N, 32, 3); tmp = f(N, 32)
     L.check(lib.us_hashgrid_fwd(dc, P_(ec.params.detach()), P_(x), N, P_(tmp), P_(ref_dd), 1, L.stream()), "us_hashgrid_fwd")
-    assert torch.equal(ddb.permute(1, 0, 3, 2).reshape(N, 32, 3), ref_dd)
+    assert torch.equal(ddb.permute(2, 0, 3, 1).reshape(N, 32, 3), ref_dd)
     d3, go3, gd3 = f(N, 3), f(R, 3), f(R, 3)
     L.check(lib.us_hashgrid_dydx_rays(16, P_(dya), P_(dyb), P_(dda), P_(ddb), R, S, P_(z), bh, P_(go3), P_(gd3), P_(d3), L.stream()), "us_hashgrid_dydx_rays")
     assert torch.equal(d3, d_ref) and torch.equal(go3, go) and torch.equal(gd3, gd)

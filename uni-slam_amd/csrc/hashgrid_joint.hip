@@ -28,6 +28,10 @@
 #ifndef J_FWD_THREADS
 #define J_FWD_THREADS 1024               // encoder workgroup: 1024 points x one level (two count rows)
 #endif
+#ifndef J_DYDX_NT
+#define J_DYDX_NT 1                      // dy/dx is written once and read once: non-temporal stores.  Measured (MI355X, 4096 x 64): with the
+#endif                                   // planes [L][3][N][2] a store instruction covers whole 128-byte lines and the encoder takes 169 us (plain
+                                         // stores: 177); as [L][N][3][2] -- 8 bytes of every 24 per instruction -- 198 plain and 261 non-temporal
 #ifndef J_SMALL_BATCH
 #define J_SMALL_BATCH (1 << 18)          // below this many points the count-free encoder runs 256-thread workgroups
 #endif
@@ -129,7 +133,7 @@ static int make_jlevels(const us_grid_desc* a, const us_grid_desc* b, int64_t n,
 // ---------------------------------------------------------------------------------------------------------------
 // forward (both tables) and / or the counts of the binning: one workgroup = 1024 points x one level
 // ---------------------------------------------------------------------------------------------------------------
-// DYDX: also leave d(features)/d(position) of both grids, level-major planes [L][N][3][2] (= tcnn's dy_dx, which the input gradient
+// DYDX: also leave d(features)/d(position) of both grids, planes [L][3][N][2] (= tcnn's dy_dx, which the input gradient
 // contracts with dL/dy: us_hashgrid_dydx_rays) -- the 8 vertices are in registers here, and 24 contiguous bytes per thread and grid
 // stream out coalesced, where a second gather pass over the tables (us_hashgrid_bwd_input_rays) costs as much as the encoder itself.
 template <bool GATHER, bool COUNT, bool DYDX = false>
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
             float* o = (s ? outB : outA) + feat_index(lm, i, n, level, C, 2);
             o[0] = r0; o[1] = r1;
             if (DYDX) {                                          // k_fwd<F, DYDX>'s arithmetic, value for value
-                float2* dd = reinterpret_cast<float2*>((s ? dydxB : dydxA) + ((int64_t)level * n + i) * 6);
+                float* dd_base = (s ? dydxB : dydxA) + (int64_t)level * 3 * n * 2 + i * 2;      // planes [L][3][N][2]: a store instruction covers whole lines
 #pragma unroll
                 for (int gd = 0; gd < 3; ++gd) {
                     float a0 = 0.0f, a1 = 0.0f;
@@ -189,8 +193,14 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
                     }
                     const float xin = x[i * 3 + gd];
                     const bool pass = !clamp || (xin >= 0.0f && xin <= 1.0f);
-                    // (plain stores: as non-temporal 8-byte stores they left the L2 uncombined -- the encoder took 261 us instead of 188)
-                    dd[gd] = pass ? make_float2(a0, a1) : make_float2(0.0f, 0.0f);
+                    typedef float f2_t __attribute__((ext_vector_type(2)));
+                    f2_t o2; o2.x = pass ? a0 : 0.0f; o2.y = pass ? a1 : 0.0f;
+                    f2_t* dst = reinterpret_cast<f2_t*>(dd_base + (int64_t)gd * n * 2);
+#if J_DYDX_NT
+                    __builtin_nontemporal_store(o2, dst);
+#else
+                    *dst = o2;
+#endif
                 }
             }
         }
@@ -904,8 +914,8 @@ __global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_leve
                 const int64_t e = (int64_t)level * n + i;
                 typedef float f2_t __attribute__((ext_vector_type(2)));
                 const f2_t y = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(dy + e * 2));
-                const f2_t* d = reinterpret_cast<const f2_t*>(dd + e * 6);
-                const f2_t d0 = __builtin_nontemporal_load(d), d1 = __builtin_nontemporal_load(d + 1), d2 = __builtin_nontemporal_load(d + 2);
+                const f2_t* d = reinterpret_cast<const f2_t*>(dd + (int64_t)level * 3 * n * 2 + i * 2);
+                const f2_t d0 = __builtin_nontemporal_load(d), d1 = __builtin_nontemporal_load(d + n), d2 = __builtin_nontemporal_load(d + 2 * n);
                 float t[3];
                 t[0] = y.x * d0.x; t[1] = y.x * d1.x; t[2] = y.x * d2.x;      // input_grad_level: r[gd] += dy[0] * d[0][gd], then dy[1] * d[1][gd]
                 r[0] += t[0]; r[1] += t[1]; r[2] += t[2];
