@@ -2,13 +2,29 @@
 profiles/<tag>_bench.json and profiles/traffic.json from the rocprofv3 output directories tools/collect_profiles.sh left under gpurun_out/."""
 import collections, csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-T = sys.argv[1] if len(sys.argv) > 1 else "r02"
+T = sys.argv[1] if len(sys.argv) > 1 else "r03"
 newest = lambda pat: max(glob.glob(os.path.join(R, pat), recursive=True), key=os.path.getmtime)
 def load(d):
     return list(csv.DictReader(open(newest(f"gpurun_out/{T}_{d}/**/*counter_collection.csv"))))
 shutil.copy(newest(f"gpurun_out/{T}_trace/**/*kernel_stats.csv"), os.path.join(R, f"profiles/{T}_kernel_stats.csv"))
 if os.path.exists(os.path.join(R, f"gpurun_out/bench_{T}.json")):
     shutil.copy(os.path.join(R, f"gpurun_out/bench_{T}.json"), os.path.join(R, f"profiles/{T}_bench.json"))
+# round 3: the joint_opt window and the tracking iteration (kernel statistics), timelines of one replayed mapping / window / tracking iteration
+import subprocess
+for tag, delim in (("window", "k_adam_segs"), ("track", "k_pose_window_step"), ("map", "k_adam_segs")):
+    try:
+        if tag != "map":
+            shutil.copy(newest(f"gpurun_out/{T}_{tag}/**/*kernel_stats.csv"), os.path.join(R, f"profiles/{T}_{tag}_kernel_stats.csv"))
+        txt = subprocess.run([sys.executable, os.path.join(R, "tools/timeline.py"), os.path.join(R, f"gpurun_out/{T}_{tag}"), "3", delim],
+                             capture_output=True, text=True).stdout
+        name = f"profiles/{T}_timeline.txt" if tag == "map" else f"profiles/{T}_{tag}_timeline.txt"
+        what = {"map": "the replayed mapping iteration (bench.py headline: MapWindow graph, joint_opt off)", "window": "the joint_opt mapping iteration (tools/time_window.py 16 256)",
+                "track": "the tracking iteration (tools/prof_track_fused.py: TrackStep.iterate_fused, 2000 x 40)"}[tag]
+        open(os.path.join(R, name), "w").write(f"# tools/timeline.py on a rocprofv3 --kernel-trace of {what}, MI355X, {T}: start (us), +duration, idle before, queue, kernel\n" + txt)
+    except Exception as e:
+        print("no", tag, "trace:", e)
+
+
 def agg(rows):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
@@ -54,7 +70,7 @@ def traffic(names):
             if any(n in k for n in names):
                 tot += corr * med(a[k][c]) * 1024
     return tot
-out = {"hashgrid_bwd_joint": traffic(("k_jcolscan", "k_jscan", "k_jwrite", "k_jaccum")), "hashgrid_fwd_joint": traffic(("k_jfwd",))}
+out = {"hashgrid_bwd_joint": traffic(("k_jcolscan", "k_jscan", "k_jwrite", "k_jaccum")), "hashgrid_fwd_joint": traffic(("k_jfwd<true, true, false>",))}
 for k, v in out.items():
     print(k, round(v / 1e6, 1), "MB")
 json.dump({**out, "_note": f"bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per-kernel medians summed over the kernels of the entry point (hashgrid_bwd_joint: "
