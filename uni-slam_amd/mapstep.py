@@ -236,8 +236,8 @@ class MapStep:
         """`with step._branch() as st2:` -- the launches inside go to the side stream (st2 = its handle), which first waits
         for everything queued on the main stream; _join() makes the main stream wait for the side stream.  Without overlap
         the block simply runs on the main stream."""
-        def __init__(self, step):
-            self.step = step
+        def __init__(self, step, after=None):
+            self.step, self.after = step, after
 
         def __enter__(self):
             s = self.step
@@ -246,7 +246,10 @@ class MapStep:
                 return L.stream()
             if s.side is None:
                 s.side = torch.cuda.Stream(device=s.device)
-            s.side.wait_stream(torch.cuda.current_stream())
+            if self.after is not None:                   # behind a point of the main stream that lies BEFORE launches already queued there
+                s.side.wait_event(self.after)
+            else:
+                s.side.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(s.side)
             self.ctx.__enter__()
             return L.stream()
@@ -256,8 +259,8 @@ class MapStep:
                 self.ctx.__exit__(*a)
             return False
 
-    def _branch(self):
-        return MapStep._Branch(self)
+    def _branch(self, after=None):
+        return MapStep._Branch(self, after)
 
     def _join(self):
         if self.overlap and not self._probing and self.side is not None:
@@ -378,20 +381,35 @@ class MapStep:
             # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
             scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                                                              3 | L.US_GRID_BWD_OVERWRITE | self._det, P(self.ws), self.ws_bytes, q)
-            if self._probing or not self.overlap:
-                self._timed("hashgrid_scan_joint", lambda: scan_call(st))
-            else:
+            # The critical chain is queued FIRST at a fork: in a captured graph the branch that is recorded first keeps the producer's
+            # queue, and a kernel that changes queues starts ~10 us late (profiles/r03_timeline.txt).  So the decoders are launched
+            # before the scans, which wait for an event recorded right behind the encoder.
+            main_first = self._decoder_pair() and self.overlap and not self._probing
+            ev = None
+            if main_first:
+                ev = torch.cuda.Event(); ev.record()
+
+            def fork_scans():
                 if self.scan_stream is None:
                     self.scan_stream = torch.cuda.Stream(device=self.device)
-                self.scan_stream.wait_stream(torch.cuda.current_stream())
+                if ev is not None:
+                    self.scan_stream.wait_event(ev)
+                else:
+                    self.scan_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.scan_stream):
                     L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
                     if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
                         L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
                         self._step_advanced = True
+            if self._probing or not self.overlap:
+                self._timed("hashgrid_scan_joint", lambda: scan_call(st))
+            elif not main_first:
+                fork_scans()
             if self._decoder_pair():                             # both decoders in one launch
                 self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
                                                                         off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+                if main_first:
+                    fork_scans()
                 return self._finish_forward(o, d, gd, gc, R)
             # decoders of different shapes: one after the other on the main stream
             self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
@@ -509,6 +527,8 @@ class MapStep:
                 mlp_s(st)
                 self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                                     N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
+            # (at THIS fork the side work is recorded first: queueing the record pass ahead of the reductions, as forward() does with the
+            #  decoders, made the replayed graph serialise scans and reductions on one queue in front of the record pass: 0.596 ms against 0.546)
             if defer:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
                     if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
