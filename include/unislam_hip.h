@@ -262,6 +262,16 @@ int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b);
  * way: its workspaces are reduced by this function, not by us_mlp_reduce.) */
 int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b, size_t workspace_bytes,
                        int64_t n, float* grad_params_a, float* grad_params_b, void* stream);
+/* us_mlp_reduce_pair with torch.optim.Adam of the decoder param group folded in (src/Mapper.py:118,443-445; single process): the
+ * gradients are the fixed-order sums of the partial rows us_mlp_bwd_pair(US_MLP_DEFER_REDUCE) left (WRITTEN to grad_params_*, no cleared
+ * buffer needed), beta's gradient the f64 sum of the per-ray partials of us_render_loss_bwd(US_LOSS_DEFER_BETA) (beta_partials NULL: no
+ * beta), then Adam on exactly those parameters with the bias corrections us_adam_step_inc left in step_dev -- the arithmetic of
+ * us_adam_step_segments_dev.  One launch on the main stream instead of a fill, two reductions and a fork / join around the table gradient. */
+int us_mlp_reduce_pair_adam(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b,
+                            size_t workspace_bytes, int64_t n, float* params_a, float* params_b, float* grad_params_a, float* grad_params_b,
+                            float* m_a, float* m_b, float* v_a, float* v_b, const float* beta_partials, int64_t n_rays, float* beta,
+                            float* grad_beta, float* m_beta, float* v_beta, double lr, double beta1, double beta2, double eps,
+                            const float* step_dev, void* stream);
 int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
                     const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags, void* stream);
 int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,

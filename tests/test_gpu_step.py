@@ -883,3 +883,40 @@ def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():
     dev = lambda a, b: float((a - b).norm() / a.norm())
     print("bf16 vs fp32:", dev(d0, d1), dev(c0, c1), " fp32 one-grid kernels vs fp32 joint kernels:", dev(d0, d2), dev(c0, c2))
     assert dev(d0, d1) < 1e-3 and dev(c0, c1) < 1e-3
+
+
+def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
+    """iterate() (single process, joint kernels, bf16 decoder pair): the decoder-gradient and beta reductions run inside the decoders'
+    optimiser launch (us_mlp_reduce_pair_adam).  Same parameters, moments and gradients, bit for bit, as forward() + backward() +
+    adam_step() with the separate reductions; five iterations."""
+    import unislam_amd as us
+    R, S = 700, 40
+    ro, rd, gd, gc = _rays(R, seed=41, outside=True)
+    g = torch.Generator().manual_seed(2)
+    trs = [torch.rand(R, S, generator=g).to(DEV) for _ in range(5)]
+    outs = []
+    for folded in (True, False):
+        torch.manual_seed(7)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        assert step.joint and step._decoder_pair() and step.overlap
+        losses = []
+        for tr in trs:
+            if folded:
+                losses.append(float(step.iterate(ro, rd, gd, gc, t_rand=tr, has_zero_depth=False)))
+            else:
+                step.forward(ro, rd, gd, gc, tr, False)
+                losses.append(float(step.backward()))
+                step.adam_step()
+        torch.cuda.synchronize()
+        outs.append((losses, step.flat.clone(), step.m.clone(), step.v.clone(), step.grad[:step.o_tab_s].clone()))
+    a, b = outs
+    assert a[0] == b[0]
+    for k in range(1, 4):
+        assert torch.equal(a[k], b[k]), k
+    # the decoder gradients of the last iteration are in the gradient buffer either way (the unfolded optimiser pass clears them: compare
+    # against a recomputation)
+    assert float(a[4].abs().max()) > 0

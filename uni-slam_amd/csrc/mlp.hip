@@ -770,6 +770,82 @@ extern "C" int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, 
     return US_OK;
 }
 
+// The same reductions with the optimiser step of the decoder param group folded in (single process; the data-parallel step needs the
+// gradients themselves for its all-reduce): gradient = fixed-order sum of the partial rows (written to grad_params: no cleared buffer
+// needed), beta's gradient = f64 sum of the per-ray partials, then torch.optim.Adam on exactly those parameters -- one launch on the
+// MAIN stream in front of the tables' Adam pass instead of a fill, two reductions and a fork / join around the table gradient
+// (src/Mapper.py:443-445: zero_grad, backward, step for the param group of :118).
+struct DecAdam { float lr, one_minus_b1, b2, one_minus_b2, eps; const float* step_dev; };
+__device__ __forceinline__ void dec_adam_apply(float g, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const DecAdam& ad) {
+    const double* aux = reinterpret_cast<const double*>(ad.step_dev + 2);          // as k_adam_segs (render.hip) reads them
+    const float step_size = (float)((double)ad.lr / aux[0]), bc2_sqrt = (float)aux[1];
+    const float m0 = *m, v0 = *v;
+    const float mi = m0 + ad.one_minus_b1 * (g - m0);
+    const float vi = v0 * ad.b2 + (ad.one_minus_b2 * g) * g;
+    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
+    *p = *p + (-step_size) * (mi / denom);
+    *m = mi; *v = vi;
+}
+__global__ __launch_bounds__(1024) void k_mlp_reduce_pair_adam(const float* __restrict__ pa, const float* __restrict__ pb, int n_rows, int npa, int npb,
+                                                               float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ Pa,
+                                                               float* __restrict__ Pb, float* __restrict__ ma, float* __restrict__ mb,
+                                                               float* __restrict__ va, float* __restrict__ vb, const float* __restrict__ beta_part,
+                                                               int64_t n_rays, float* __restrict__ p_beta,
+                                                               float* __restrict__ g_beta, float* __restrict__ m_beta, float* __restrict__ v_beta,
+                                                               DecAdam ad) {
+    if (blockIdx.y == 2) {                                       // beta: one workgroup
+        if (blockIdx.x != 0 || !beta_part) return;
+        __shared__ double shd[1024];
+        double acc = 0.0;
+        for (int64_t r = threadIdx.x; r < n_rays; r += 1024) acc += (double)beta_part[r];
+        shd[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) { const float g = (float)shd[0]; *g_beta = g; dec_adam_apply(g, p_beta, m_beta, v_beta, ad); }
+        return;
+    }
+    __shared__ float sh[16][64];
+    const float* partials = blockIdx.y ? pb : pa;
+    const int np = blockIdx.y ? npb : npa;
+    const int kl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    float s = 0.0f;
+    if (k < np)
+        for (int r = sl; r < n_rows; r += 16) s += partials[(size_t)r * np + k];
+    sh[sl][kl] = s;
+    __syncthreads();
+    if (sl == 0 && k < np) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][kl];
+        (blockIdx.y ? gb : ga)[k] = t;
+        dec_adam_apply(t, (blockIdx.y ? Pb : Pa) + k, (blockIdx.y ? mb : ma) + k, (blockIdx.y ? vb : va) + k, ad);
+    }
+}
+
+extern "C" int us_mlp_reduce_pair_adam(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b,
+                                       size_t workspace_bytes, int64_t n, float* params_a, float* params_b, float* grad_params_a,
+                                       float* grad_params_b, float* m_a, float* m_b, float* v_a, float* v_b, const float* beta_partials,
+                                       int64_t n_rays, float* beta, float* grad_beta, float* m_beta, float* v_beta, double lr, double beta1,
+                                       double beta2, double eps, const float* step_dev, void* stream) {
+    US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_reduce_pair_adam: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(workspace_a && workspace_b && params_a && params_b && grad_params_a && grad_params_b && m_a && m_b && v_a && v_b && step_dev, US_ERR_NULL,
+               "us_mlp_reduce_pair_adam: NULL pointer");
+    US_REQUIRE(!beta_partials || (beta && grad_beta && m_beta && v_beta && n_rays >= 1), US_ERR_NULL, "us_mlp_reduce_pair_adam: beta needs p, g, m, v and n_rays");
+    US_REQUIRE(((uintptr_t)step_dev & 7u) == 0, US_ERR_SHAPE, "us_mlp_reduce_pair_adam: step_dev (float[8]) must be 8-byte aligned");
+    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
+               "us_mlp_reduce_pair_adam: workspace %zu B too small", workspace_bytes);
+    const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
+    DecAdam ad; ad.lr = (float)lr; ad.one_minus_b1 = (float)(1.0 - beta1); ad.b2 = (float)beta2; ad.one_minus_b2 = (float)(1.0 - beta2); ad.eps = (float)eps;
+    ad.step_dev = step_dev;
+    hipLaunchKernelGGL(k_mlp_reduce_pair_adam, dim3((unsigned)us_cdiv(npa > npb ? npa : npb, 64), beta_partials ? 3 : 2), dim3(1024), 0,
+                       (hipStream_t)stream, (const float*)workspace_a, (const float*)workspace_b, (int)mlp_pair_rows(da, n), npa, npb, grad_params_a,
+                       grad_params_b, params_a, params_b, m_a, m_b, v_a, v_b, beta_partials, n_rays, beta, grad_beta, m_beta, v_beta, ad);
+    US_CHECK_LAUNCH("us_mlp_reduce_pair_adam");
+    return US_OK;
+}
+
 #include <string.h>
 #ifdef US_EXPERIMENTS                    // measured-slower variants, kept buildable: tools/build_experiments.sh (include/unislam_hip_experiments.h)
 #include "encode_decode.inc"

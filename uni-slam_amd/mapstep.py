@@ -449,13 +449,16 @@ class MapStep:
         self.n_rays = R
         return self.stats
 
-    def backward(self, on_ready=None, ray_grads=False):
+    def backward(self, on_ready=None, ray_grads=False, fold=False):
         """
         Gradients of loss = sum_k w_k * sums_k / counts_k (self.stats, possibly reduced over ranks) into self.grad.
         ray_grads: also form dL/d(rays_o), dL/d(rays_d) (self.g_o, self.g_d [R,3]) -- what the joint pose optimisation of
         src/Mapper.py:358-374 differentiates through; the positions' gradient re-gathers the tables (no stored dy/dx).
         The colour branch runs first; on_ready(view) is called when the colour-table segment, and at the end the
         [decoders | beta | sdf table] segment, of self.grad are final (dist.dp_iterate overlaps their all-reduces).
+        fold: the caller runs adam_step() next and reads no decoder gradient in between (iterate(), MapWindow): the decoder-gradient
+        and beta reductions are then left to adam_step(), which sums them inside the decoders' optimiser launch
+        (us_mlp_reduce_pair_adam) -- no side-stream work around the table gradient, no queue crossing in front of the record pass.
         """
         lib, st = L.lib(), L.stream()
         o, d, gd, gc, R = self._batch
@@ -469,6 +472,7 @@ class MapStep:
         # The binned table backward writes every table entry (US_GRID_BWD_OVERWRITE); the decoder segment, which the MLP
         # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
         binned = self.ws is not None
+        self._folded = False
         # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
         # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
         defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing)
@@ -527,9 +531,14 @@ class MapStep:
                 mlp_s(st)
                 self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
                                                                     N, P(self.d_feat_c), off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws), self.mlp_ws_bytes, st))
+            self._folded = bool(fold and defer and on_ready is None and self.group is None and self._decoder_pair())
+            if self._folded:
+                defer_side = False                               # adam_step() sums the partial rows itself
+            else:
+                defer_side = defer
             # (at THIS fork the side work is recorded first: queueing the record pass ahead of the reductions, as forward() does with the
             #  decoders, made the replayed graph serialise scans and reductions on one queue in front of the record pass: 0.596 ms against 0.546)
-            if defer:
+            if defer_side:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
                     if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
                         self.grad[:self.o_tab_s].zero_()
@@ -561,7 +570,7 @@ class MapStep:
                 self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
                                                                                     P(self.ws), self.ws_bytes, st))
-            if defer:
+            if defer_side:
                 self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
         elif self.overlap and not self._probing:
             with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
@@ -647,7 +656,25 @@ class MapStep:
         f = self.lr_factor
         groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
                   (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
-        if ranges is None:
+        if ranges is None and getattr(self, "_folded", False):
+            # backward(fold=True) left the decoders' partial rows and beta's per-ray partials: their sums and the decoder group's Adam
+            # in one launch, then the tables
+            self._folded = False
+            if not self._step_advanced:                          # (a forward pass that did not queue the increment: one-stream mode)
+                L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
+                self._step_advanced = True
+            off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+            hb = self.has_beta
+            L.check(lib.us_mlp_reduce_pair_adam(
+                ctypes.byref(self.desc_s), ctypes.byref(self.desc_c), P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, self.n_rays * self.S,
+                off(self.flat, self.o_dec_s), off(self.flat, self.o_dec_c), off(self.grad, self.o_dec_s), off(self.grad, self.o_dec_c),
+                off(self.m, self.o_dec_s), off(self.m, self.o_dec_c), off(self.v, self.o_dec_s), off(self.v, self.o_dec_c),
+                P(self.beta_part) if hb else None, self.n_rays, off(self.flat, self.o_beta) if hb else None, off(self.grad, self.o_beta) if hb else None,
+                off(self.m, self.o_beta) if hb else None, off(self.v, self.o_beta) if hb else None, self.lr["decoders"] * f, 0.9, 0.999, 1e-8,
+                P(self.step_dev), st), "us_mlp_reduce_pair_adam")
+            segs, zero_mask = list(groups)[1:], 0
+            self._dec_grad_clean = False
+        elif ranges is None:
             segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
             self._dec_grad_clean = True                          # cleared on the way
         else:
@@ -672,6 +699,11 @@ class MapStep:
 
     def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, presampled=False):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
+        if self.group is None:
+            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled)
+            loss = self.backward(fold=True)
+            self.adam_step()
+            return loss
         return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled), self.group)
 
     def capture(self, n_rays, t_rand=False):

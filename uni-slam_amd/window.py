@@ -120,7 +120,7 @@ class MapWindow:
             s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws, presampled=True)
         finally:
             s.store_dydx = False
-        loss = s.backward(ray_grads=True)
+        loss = s.backward(ray_grads=True, fold=True)              # (adam_step() below sums the decoder-gradient partials itself)
         g_o, g_d = s.g_o, s.g_d
         if not s._step_advanced:                                 # the poses are one more group of the SAME optimiser: one step count
             L.check(lib.us_adam_step_inc(P(s.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
