@@ -901,7 +901,7 @@ def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
         es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
         with torch.no_grad():
             es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
-        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, deterministic=True)    # (no float atomics in hot bins)
         assert step.joint and step._decoder_pair() and step.overlap
         losses = []
         for tr in trs:
