@@ -598,6 +598,17 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
 #define MLP_BWD_MAX_WG 256
 #endif
 
+// workgroups (= partial rows of the weight gradient in the workspace) of a one-decoder backward launch: ONE definition for the launch
+// (us_mlp_bwd) and for the reduction that reads the rows later (us_mlp_reduce)
+static int64_t mlp_bwd_rows(const us_mlp_desc* d, int64_t n, int* waves_out) {
+    const bool bf = d->precision != US_PREC_F32;
+    const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
+    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves);
+    if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;               // one workgroup per CU
+    if (waves_out) *waves_out = waves;
+    return nb;
+}
+
 extern "C" size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d) {
     return d ? (size_t)MLP_BWD_MAX_WG * us_mlp_n_params(d) * sizeof(float) : 0;
 }
@@ -613,8 +624,8 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     if (!dL_din && !grad_params) return US_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool bf = d->precision != US_PREC_F32;
-    const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
-    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;   // one workgroup per CU
+    int waves;
+    const int64_t nb = mlp_bwd_rows(d, n, &waves);
     dim3 grid((unsigned)nb), block(waves * 64);
     float* partials = nullptr;
     if (grad_params && workspace) {
@@ -644,9 +655,7 @@ extern "C" int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t
     US_REQUIRE(workspace && grad_params, US_ERR_NULL, "us_mlp_reduce: NULL pointer");
     US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(d), US_ERR_WORKSPACE, "us_mlp_reduce: workspace %zu B < %zu B", workspace_bytes,
                us_mlp_bwd_workspace_bytes(d));
-    const bool bf = d->precision != US_PREC_F32;
-    const int waves = bf ? MLP_BF_BWD_WAVES(d->width) : MLP_BWD_WAVES(d->width);
-    int64_t nb = us_cdiv(n, (bf ? 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) : (d->width == 64 ? 32 : 16 * MLP_BWD_NQ)) * waves); if (nb > MLP_BWD_MAX_WG) nb = MLP_BWD_MAX_WG;
+    const int64_t nb = mlp_bwd_rows(d, n, nullptr);
     const int np = (int)us_mlp_n_params(d);
     hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)us_cdiv(np, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, (int)nb, np, grad_params);
     US_CHECK_LAUNCH("us_mlp_reduce");
@@ -667,6 +676,7 @@ extern "C" int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b)
 #ifndef MLP_BWD_PAIR_WG
 #define MLP_BWD_PAIR_WG 128
 #endif
+static_assert(MLP_BWD_PAIR_WG <= MLP_BWD_MAX_WG, "the pair launch's partial rows must fit the workspace us_mlp_bwd_workspace_bytes sizes");
 static int64_t mlp_pair_rows(const us_mlp_desc* d, int64_t n) {
     const int waves = MLP_BF_BWD_WAVES(d->width);
     int64_t nb = us_cdiv(n, 16 * MLP_BF_BWD_NQ(d->width, d->n_hidden) * waves);

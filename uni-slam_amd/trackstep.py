@@ -96,7 +96,7 @@ class TrackStep:
         # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers.  Both tables in
         # one launch where the pair of grids qualifies (positions and cells computed once, one launch less in a latency-bound chain)
         if self._joint is None:
-            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
+            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, 1))    # the count-free encoder needs the shared geometry only
         if self._joint:
             # ... and d(features)/d(position) of both, which the pose gradient contracts at the end (no second gather pass over the tables)
             if self.dydx_s is None:
@@ -233,7 +233,7 @@ class TrackStep:
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
         if self._joint is None:
-            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, max(N, 1)))
+            self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, 1))    # the count-free encoder needs the shared geometry only
         fast = (getattr(self, "fast_path", True) and self._joint and self.mode == 2 and n <= 8192 and S <= 128 and bool(lib.us_mlp_pair_supported(ms, mc)))
         b1, b2 = self.betas
         if not fast:
@@ -257,28 +257,33 @@ class TrackStep:
         self.rng_calls = getattr(self, "rng_calls", 0) + 1
         seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1)
         pix = P(indices.contiguous()) if indices is not None else None
-        self._timed("us_track_sample", lambda: lib.us_track_sample(P(self.pose), pix, n, self.intr, W0, H0, W1 - W0, H1 - H0, P(self.img_d), P(self.img_c), W, self.bhost,
-                                    P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation),
-                                    ctypes.c_float(3 * self.truncation), tr, seed, P(self.pstep), 1 if self.perturb else 0, None, None,
-                                    P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st))
+        T = self._timed
+        T("us_track_sample", lambda: lib.us_track_sample(
+            P(self.pose), pix, n, self.intr, W0, H0, W1 - W0, H1 - H0, P(self.img_d), P(self.img_c), W, self.bhost, P(self.t_uni), self.n_strat,
+            P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
+            P(self.pstep), 1 if self.perturb else 0, None, None, P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st))
         if self.dydx_s is None:
             self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
             self.dydx_c = torch.empty_like(self.dydx_s)
-        self._timed("us_hashgrid_fwd_joint_dydx", lambda: lib.us_hashgrid_fwd_joint_dydx(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c),
-                                               3, None, 0, st))
-        self._timed("us_mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
-        self._timed("us_track_loss_fwd", lambda: lib.us_track_loss_fwd(P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), self.truncation,
-                                      P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.err),
-                                      P(self.median), P(self.stats), st))
-        self._timed("us_track_loss_bwd", lambda: lib.us_track_loss_bwd(P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), P(self.depth),
-                                      P(self.rgb), P(self.unc), P(self.median), self.truncation, self.w5, P(self.stats), P(self.d_raw),
-                                      P(self.loss), st))
-        self._timed("us_mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
-                                    off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st))
-        self._timed("us_hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), n, S, P(self.z),
-                                          self.bhost, P(self.g_o), P(self.g_d), None, st))
-        self._timed("us_pose_window_step", lambda: lib.us_pose_window_step(P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose),
-                                        self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st))
+        T("us_hashgrid_fwd_joint_dydx", lambda: lib.us_hashgrid_fwd_joint_dydx(
+            ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3, None, 0, st))
+        T("us_mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(
+            ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+        T("us_track_loss_fwd", lambda: lib.us_track_loss_fwd(
+            P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), self.truncation, P(self.term), P(self.unc),
+            P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.err), P(self.median), P(self.stats), st))
+        T("us_track_loss_bwd", lambda: lib.us_track_loss_bwd(
+            P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), P(self.depth), P(self.rgb), P(self.unc),
+            P(self.median), self.truncation, self.w5, P(self.stats), P(self.d_raw), P(self.loss), st))
+        T("us_mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(
+            ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4,
+            P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st))
+        T("us_hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(
+            self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), n, S, P(self.z), self.bhost, P(self.g_o),
+            P(self.g_d), None, st))
+        T("us_pose_window_step", lambda: lib.us_pose_window_step(
+            P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose), self.lr_R, self.lr_T,
+            b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st))
         return self.loss, self.unc[:n], self.valid[:n]
 
     def _timed(self, name, rc_fn):
