@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _build(us, n_frames, seed=0, mlp_precision="fp32"):
+def _build(us, n_frames, seed=0, mlp_precision="fp32", graph_replay=False):
     from unislam_amd.synthetic import SyntheticRoom
     from unislam_amd.slam import SLAM
     torch.manual_seed(seed)
@@ -29,7 +29,7 @@ def _build(us, n_frames, seed=0, mlp_precision="fp32"):
     dec.bound = bound
     slam = SLAM(frames, (frames.H, frames.W, frames.fx, frames.fy, frames.cx, frames.cy), es, ec, dec, bound,
                 cfg={"tracking": dict(ignore_edge_W=8, ignore_edge_H=8, pixels=1000, iters=10),
-                     "mapping": dict(pixels=2000, iters=20, iters_first=300, every_frame=2, keyframe_every=2)})
+                     "mapping": dict(pixels=2000, iters=20, iters_first=300, every_frame=2, keyframe_every=2, graph_replay=graph_replay)})
     return slam, frames
 
 
@@ -63,6 +63,16 @@ def test_slam_recovers_the_trajectory():
     d_hat = out[0]
     err = (d_hat.float().reshape(-1) - depth.reshape(-1)).abs()
     assert float(err.median()) < 0.03, float(err.median())
+
+
+def test_slam_with_replayed_mapping_windows():
+    """cfg['mapping']['graph_replay']: every mapped frame captures its MapWindow (joint_opt from the fifth keyframe on, the pixel draw
+    inside the graph) and replays it `iters` times; the trajectory comes out as with eager iterations"""
+    import unislam_amd as us
+    n = 16
+    slam, frames = _build(us, n, graph_replay=True, mlp_precision="bf16")
+    slam.run()
+    assert slam.mapper.joint_opt and slam.ate_rmse() < 0.02, slam.ate_rmse()
 
 
 def test_keyframe_selection_on_device():
