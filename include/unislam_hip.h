@@ -262,6 +262,17 @@ int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b);
  * way: its workspaces are reduced by this function, not by us_mlp_reduce.) */
 int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b, size_t workspace_bytes,
                        int64_t n, float* grad_params_a, float* grad_params_b, void* stream);
+/* us_mlp_bwd_pair that also contracts dL/d(features) with the encoder's dy/dx while it is in registers: dL_dpts_a / dL_dpts_b [N][3]
+ * receive each decoder's share of dL/d(point) (dy_dx_*: the planes [L][3][N][2] of us_hashgrid_fwd_joint_dydx for decoder a's / b's
+ * grid; level-major inputs).  us_ray_points_bwd2 adds the two shares and reduces them to the rays.  The input gradient of the pose
+ * optimisations (src/Mapper.py:372-376,444; src/Tracker.py:170-174,241) without a second pass over dL/d(features); dL_din_* may be
+ * NULL when no table gradient follows (tracking). */
+int us_mlp_bwd_pair_dydx(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                         const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                         const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                         float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                         void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dL_dpts_a,
+                         float* dL_dpts_b, void* stream);
 /* us_mlp_reduce_pair with torch.optim.Adam of the decoder param group folded in (src/Mapper.py:118,443-445; single process): the
  * gradients are the fixed-order sums of the partial rows us_mlp_bwd_pair(US_MLP_DEFER_REDUCE) left (WRITTEN to grad_params_*, no cleared
  * buffer needed), beta's gradient the f64 sum of the per-ray partials of us_render_loss_bwd(US_LOSS_DEFER_BETA) (beta_partials NULL: no
@@ -297,6 +308,10 @@ int us_ray_points(const float* rays_o, const float* rays_d, const float* z_vals,
 /* adjoint of us_ray_points wrt rays_o / rays_d (tracking: pose gradient, Tracker.py:170-174) */
 int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, const float* bound_host, int64_t n_rays,
                       int n_samples, float* dL_do, float* dL_dd, void* stream);
+
+/* the same for dL_dpts = dL_dpts_a + dL_dpts_b (the two grids' shares us_mlp_bwd_pair_dydx leaves) */
+int us_ray_points_bwd2(const float* dL_dpts_a, const float* dL_dpts_b, const float* z_vals, const float* bound_host, int64_t n_rays,
+                       int n_samples, float* dL_do, float* dL_dd, void* stream);
 
 /* importance samples of the rays WITHOUT a depth measurement (src/utils/Renderer.py:121-130 + common.sample_pdf src/common.py:49-85):
  * sdf_uni[R][n_uniform] of the coarse uniform pass at z_uni[R][n_uniform] -> alpha (beta: device float[1]) -> weights -> the reference's

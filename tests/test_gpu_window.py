@@ -392,3 +392,53 @@ def test_mapwindow_graph_with_device_side_draw():
         seen.append(win.gd.clone())
     assert all(np.isfinite(losses)) and float(step.step_dev[0]) == 4.0
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
+@pytest.mark.parametrize("S,n_rays", [(64, 70), (40, 133)])
+def test_decoder_backward_contracts_dydx_in_registers(S, n_rays):
+    """us_mlp_bwd_pair_dydx + us_ray_points_bwd2 == us_mlp_bwd_pair + us_hashgrid_dydx_rays (another summation order: 1e-5), with and
+    without the dL/d(features) output and the parameter gradients; dL/d(features) and the parameter gradients themselves unchanged"""
+    import ctypes
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    lib, st, P = L.lib(), L.stream(), L.ptr
+    N = n_rays * S
+    g = torch.Generator().manual_seed(S)
+    ds_ = us.make_mlp_desc(32, 32, 2, 1, "tanh", True, "bf16"); dc_ = us.make_mlp_desc(32, 32, 2, 3, "sigmoid", True, "bf16")
+    A, B = ctypes.byref(ds_), ctypes.byref(dc_)
+    ps = (torch.randn(us.network.mlp_n_params(ds_), generator=g) * 0.3).to(DEV); pc = (torch.randn(us.network.mlp_n_params(dc_), generator=g) * 0.3).to(DEV)
+    fa, fb = torch.randn(16, N, 2, generator=g).to(DEV), torch.randn(16, N, 2, generator=g).to(DEV)
+    dda, ddb = torch.randn(16, 3, N, 2, generator=g).to(DEV), torch.randn(16, 3, N, 2, generator=g).to(DEV)
+    d_raw = torch.randn(N, 4, generator=g).to(DEV); z = (torch.rand(n_rays, S, generator=g) * 3).to(DEV)
+    raw = torch.empty(N, 4, device=DEV)
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+    L.check(lib.us_mlp_fwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), N, off(raw, 3), 4, P(raw), 4, 1, st), "fwd")
+    f = lambda *s: torch.zeros(s, device=DEV)
+    wsb = int(lib.us_mlp_bwd_workspace_bytes(A))
+    bh = us.common.bound_host(BOUND)
+
+    def run(fused, want_din, want_w):
+        da, db = (f(16, N, 2), f(16, N, 2)) if (want_din or not fused) else (None, None)
+        gs, gc = (torch.zeros_like(ps), torch.zeros_like(pc)) if want_w else (None, None)
+        wa, wb = (torch.empty(wsb, dtype=torch.uint8, device=DEV), torch.empty(wsb, dtype=torch.uint8, device=DEV)) if want_w else (None, None)
+        go, gd = f(n_rays, 3), f(n_rays, 3)
+        common = (A, B, P(ps), P(pc), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, N, P(da), P(db), P(gs), P(gc), 1,
+                  P(wa), P(wb), wsb if want_w else 0)
+        if fused:
+            pa_, pb_ = f(N, 3), f(N, 3)
+            L.check(lib.us_mlp_bwd_pair_dydx(*common, P(dda), P(ddb), P(pa_), P(pb_), st), "us_mlp_bwd_pair_dydx")
+            L.check(lib.us_ray_points_bwd2(P(pa_), P(pb_), P(z), bh, n_rays, S, P(go), P(gd), st), "us_ray_points_bwd2")
+        else:
+            L.check(lib.us_mlp_bwd_pair(*common, st), "us_mlp_bwd_pair")
+            L.check(lib.us_hashgrid_dydx_rays(16, P(da), P(db), P(dda), P(ddb), n_rays, S, P(z), bh, P(go), P(gd), None, st), "us_hashgrid_dydx_rays")
+        return go, gd, da, db, gs, gc
+
+    ref = run(False, True, True)
+    for want_din, want_w in ((True, True), (False, False), (True, False)):
+        out = run(True, want_din, want_w)
+        for a, b in zip(out[:2], ref[:2]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max())), float((a - b).abs().max() / b.abs().max())
+        if want_din:
+            assert torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
+        if want_w:
+            assert torch.equal(out[4], ref[4]) and torch.equal(out[5], ref[5])

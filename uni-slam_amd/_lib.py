@@ -83,6 +83,9 @@ SIGNATURES = {
     "us_mlp_fwd": (c_int, [_MP, c_f, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_pair_supported": (c_int, [_MP, _MP]),
     "us_mlp_reduce_pair": (c_int, [_MP, _MP, c_f, c_f, ctypes.c_size_t, c_i64, c_f, c_f, c_f]),
+    "us_mlp_bwd_pair_dydx": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_int,
+                                     c_f, c_f, ctypes.c_size_t, c_f, c_f, c_f, c_f, c_f]),
+    "us_ray_points_bwd2": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),
     "us_mlp_reduce_pair_adam": (c_int, [_MP, _MP, c_f, c_f, ctypes.c_size_t, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f,
                                         c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_mlp_fwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),

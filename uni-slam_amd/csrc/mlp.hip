@@ -725,11 +725,12 @@ extern "C" int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
     return US_OK;
 }
 
-extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
-                               const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
-                               const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
-                               float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
-                               void* workspace_b, size_t workspace_bytes, void* stream) {
+static int mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                        const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                        const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                        float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                        void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dpts_a, float* dpts_b,
+                        void* stream) {
     US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_bwd_pair: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
     US_REQUIRE(out_stride_a >= (int64_t)da->n_out && dout_stride_a >= (int64_t)da->n_out && out_stride_b >= (int64_t)db->n_out &&
                dout_stride_b >= (int64_t)db->n_out, US_ERR_SHAPE, "us_mlp_bwd_pair: stride < n_out");
@@ -742,18 +743,24 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
         US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
                    "us_mlp_bwd_pair: workspace %zu B too small", workspace_bytes);
     } else {
-        US_REQUIRE(dL_din_a && dL_din_b, US_ERR_NULL, "us_mlp_bwd_pair: nothing to compute (no parameter gradients, no input gradients)");
+        US_REQUIRE((dL_din_a && dL_din_b) || dy_dx_a, US_ERR_NULL, "us_mlp_bwd_pair: nothing to compute (no parameter gradients, no input gradients)");
         workspace_a = workspace_b = nullptr;
     }
+    US_REQUIRE((dL_din_a != nullptr) == (dL_din_b != nullptr), US_ERR_NULL, "us_mlp_bwd_pair: input gradients of both decoders or of neither");
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
+    if (dy_dx_a || dy_dx_b || dpts_a || dpts_b) {
+        US_REQUIRE(dy_dx_a && dy_dx_b && dpts_a && dpts_b && dpts_a != dpts_b, US_ERR_NULL, "us_mlp_bwd_pair_dydx: dy_dx and dL_dpts of both decoders");
+        US_REQUIRE(lm && da->n_in == 32, US_ERR_CONFIG, "us_mlp_bwd_pair_dydx: level-major inputs of 16 levels x 2 features");
+        US_REQUIRE(((((uintptr_t)dy_dx_a) | ((uintptr_t)dy_dx_b)) & 7u) == 0, US_ERR_SHAPE, "us_mlp_bwd_pair_dydx: dy_dx must be 8-byte aligned");
+    }
     hipStream_t s = (hipStream_t)stream;
     const int waves = MLP_BF_BWD_WAVES(da->width);
     const int64_t nb = mlp_pair_rows(da, n);
     dim3 grid((unsigned)nb, 2), block(waves * 64);
     MlpBwdJob a = {params_a, (int)da->has_bias, (int)da->n_out, (int)da->out_act, in_a, out_a, (long long)out_stride_a, dL_dout_a,
-                   (long long)dout_stride_a, dL_din_a, grad_params_a, (float*)workspace_a};
+                   (long long)dout_stride_a, dL_din_a, grad_params_a, (float*)workspace_a, dy_dx_a, dpts_a};
     MlpBwdJob b = {params_b, (int)db->has_bias, (int)db->n_out, (int)db->out_act, in_b, out_b, (long long)out_stride_b, dL_dout_b,
-                   (long long)dout_stride_b, dL_din_b, grad_params_b, (float*)workspace_b};
+                   (long long)dout_stride_b, dL_din_b, grad_params_b, (float*)workspace_b, dy_dx_b, dpts_b};
     MLP_PAIR_DISPATCH(k_mlp_bwd_pair, a, b, n, lm);
     US_CHECK_LAUNCH("us_mlp_bwd_pair");
     if (wgrad && !(flags & US_MLP_DEFER_REDUCE)) {
@@ -763,6 +770,28 @@ extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
         US_CHECK_LAUNCH("us_mlp_bwd_pair(reduce)");
     }
     return US_OK;
+}
+
+extern "C" int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                               const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                               const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                               float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                               void* workspace_b, size_t workspace_bytes, void* stream) {
+    return mlp_bwd_pair(da, db, params_a, params_b, in_a, in_b, out_a, out_stride_a, out_b, out_stride_b, dL_dout_a, dout_stride_a, dL_dout_b,
+                        dout_stride_b, n, dL_din_a, dL_din_b, grad_params_a, grad_params_b, flags, workspace_a, workspace_b, workspace_bytes,
+                        nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int us_mlp_bwd_pair_dydx(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
+                                    const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
+                                    const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
+                                    float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
+                                    void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dL_dpts_a,
+                                    float* dL_dpts_b, void* stream) {
+    US_REQUIRE(n <= 0 || (dy_dx_a && dy_dx_b && dL_dpts_a && dL_dpts_b), US_ERR_NULL, "us_mlp_bwd_pair_dydx: NULL pointer");
+    return mlp_bwd_pair(da, db, params_a, params_b, in_a, in_b, out_a, out_stride_a, out_b, out_stride_b, dL_dout_a, dout_stride_a, dL_dout_b,
+                        dout_stride_b, n, dL_din_a, dL_din_b, grad_params_a, grad_params_b, flags, workspace_a, workspace_b, workspace_bytes,
+                        dy_dx_a, dy_dx_b, dL_dpts_a, dL_dpts_b, stream);
 }
 
 // the reductions us_mlp_bwd_pair(..., US_MLP_DEFER_REDUCE) left out, both decoders in one launch (fixed order)

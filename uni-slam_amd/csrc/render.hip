@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_ray_points(const float* __restrict__ ra
     }
 }
 
-__global__ __launch_bounds__(256) void k_ray_points_bwd(const float* __restrict__ dpts, const float* __restrict__ z_vals,
+__global__ __launch_bounds__(256) void k_ray_points_bwd(const float* __restrict__ dpts, const float* __restrict__ dpts2, const float* __restrict__ z_vals,
                                                         Bound3 bd, int64_t n_rays, int S, float* __restrict__ d_o,
                                                         float* __restrict__ d_d) {
     const int lane = threadIdx.x & 63;
@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void k_ray_points_bwd(const float* __restrict_
         const float z = z_vals[ray * S + s];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float gk = dpts[(ray * S + s) * 3 + k] / bd.span[k];
+            float g = dpts[(ray * S + s) * 3 + k];
+            if (dpts2) g += dpts2[(ray * S + s) * 3 + k];       // the two grids' shares (us_mlp_bwd_pair_dydx)
+            const float gk = g / bd.span[k];
             so[k] += gk; sd[k] += gk * z;
         }
     }
@@ -1318,9 +1320,19 @@ extern "C" int us_ray_points_bwd(const float* dL_dpts, const float* z_vals, cons
                                  int n_samples, float* dL_do, float* dL_dd, void* stream) {
     if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(dL_dpts && z_vals && bound_host, US_ERR_NULL, "us_ray_points_bwd: NULL pointer");
-    hipLaunchKernelGGL(k_ray_points_bwd, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dpts, z_vals,
+    hipLaunchKernelGGL(k_ray_points_bwd, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dpts, (const float*)nullptr, z_vals,
                        make_bound(bound_host), n_rays, n_samples, dL_do, dL_dd);
     US_CHECK_LAUNCH("us_ray_points_bwd");
+    return US_OK;
+}
+
+extern "C" int us_ray_points_bwd2(const float* dL_dpts_a, const float* dL_dpts_b, const float* z_vals, const float* bound_host, int64_t n_rays,
+                                  int n_samples, float* dL_do, float* dL_dd, void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(dL_dpts_a && dL_dpts_b && z_vals && bound_host, US_ERR_NULL, "us_ray_points_bwd2: NULL pointer");
+    hipLaunchKernelGGL(k_ray_points_bwd, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dpts_a, dL_dpts_b, z_vals,
+                       make_bound(bound_host), n_rays, n_samples, dL_do, dL_dd);
+    US_CHECK_LAUNCH("us_ray_points_bwd2");
     return US_OK;
 }
 

@@ -182,7 +182,7 @@ class MapStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
-        self.dydx_s = self.dydx_c = None
+        self.dydx_s = self.dydx_c = self.dpts_s = self.dpts_c = None
         self._graph = None              # a captured iteration holds the old buffers' addresses: capture() again after a reallocation
         self.z, self.pts = f(R, S), f(R, S, 3)
         self.feat_s, self.feat_c = f(N, 32), f(N, 32)
@@ -521,7 +521,20 @@ class MapStep:
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
-            if self._decoder_pair():                             # both decoders' backward passes in one launch
+            self._dpts_valid = False
+            if self._decoder_pair() and ray_grads and self._dydx_valid:
+                # ... which also contract dL/d(features) with the encoder's dy/dx while it is in registers: each decoder's share of
+                # dL/d(point) (the pose gradient's input: no second pass over dL/d(features))
+                if getattr(self, "dpts_s", None) is None or self.dpts_s.numel() < self.max_rays * S * 3:
+                    self.dpts_s = torch.empty(self.max_rays * S * 3, dtype=torch.float32, device=self.device)
+                    self.dpts_c = torch.empty_like(self.dpts_s)
+                self._dpts_valid = True
+                self._timed("mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair_dydx(
+                    ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
+                    off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), off(self.grad, self.o_dec_s),
+                    off(self.grad, self.o_dec_c), mflags, P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, P(self.dydx_s), P(self.dydx_c),
+                    P(self.dpts_s), P(self.dpts_c), st))
+            elif self._decoder_pair():                           # both decoders' backward passes in one launch
                 self._timed("mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c),
                                                                         off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4, P(self.d_raw), 4, N,
                                                                         P(self.d_feat_s), P(self.d_feat_c), off(self.grad, self.o_dec_s),
@@ -590,7 +603,11 @@ class MapStep:
             if not hasattr(self, "g_o") or self.g_o.shape[0] < R:
                 f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
                 self.g_o, self.g_d, self.d_pts = f(self.max_rays, 3), f(self.max_rays, 3), None
-            if self._dydx_valid and S <= 128:
+            if getattr(self, "_dpts_valid", False):
+                # the decoders' backward launch has left the two grids' shares of dL/d(point): add, reduce to the rays
+                self._timed("ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, R, S, P(self.g_o),
+                                                                              P(self.g_d), st))
+            elif self._dydx_valid and S <= 128:
                 # the forward pass left dy/dx: one streaming launch contracts it with dL/dy and reduces to the rays
                 self._timed("hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s),
                                                                                     P(self.dydx_c), R, S, P(self.z), self.bhost, P(self.g_o), P(self.g_d),

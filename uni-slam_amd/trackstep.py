@@ -46,7 +46,7 @@ class TrackStep:
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.max_rays = R
-        self.dydx_s = self.dydx_c = None
+        self.dydx_s = self.dydx_c = self.dpts_s = self.dpts_c = None
         self.z, self.pts, self.d_pts = f(R, S), f(R, S, 3), f(R, S, 3)
         self.feat_s, self.feat_c, self.d_feat_s, self.d_feat_c = f(N, 32), f(N, 32), f(N, 32), f(N, 32)
         self.raw, self.d_raw = f(R, S, 4), f(R, S, 4)
@@ -218,8 +218,8 @@ class TrackStep:
             us_mlp_fwd_pair              both decoders
             us_track_loss_fwd            compositing + per-ray loss partials | median gate + statistics (one workgroup)
             us_track_loss_bwd            loss gradients + compositing backward
-            us_mlp_bwd_pair              both decoders' input gradients
-            us_hashgrid_dydx_rays        dL/d(points) contracted from dy/dx and reduced to dL/d(rays_o), dL/d(rays_d)
+            us_mlp_bwd_pair_dydx         both decoders' input gradients, contracted in registers with dy/dx: dL/d(points) per grid
+            us_ray_points_bwd2           the two shares added and reduced to dL/d(rays_o), dL/d(rays_d)
             us_pose_window_step          pose gradient + Adam on the 7 numbers (step count included)
         otherwise the general chain (us_pose_rays + forward_backward + the pose step).
         """
@@ -275,12 +275,15 @@ class TrackStep:
         T("us_track_loss_bwd", lambda: lib.us_track_loss_bwd(
             P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), P(self.depth), P(self.rgb), P(self.unc),
             P(self.median), self.truncation, self.w5, P(self.stats), P(self.d_raw), P(self.loss), st))
-        T("us_mlp_bwd_pair", lambda: lib.us_mlp_bwd_pair(
+        # decoder pair backward: the input gradients stay in registers and are contracted there with dy/dx (each grid's share of
+        # dL/d(point)); nothing else reads dL/d(features) in tracking, so it is not written
+        if getattr(self, "dpts_s", None) is None or self.dpts_s.numel() < self.max_rays * S * 3:
+            self.dpts_s = torch.empty(self.max_rays * S * 3, dtype=torch.float32, device=self.device)
+            self.dpts_c = torch.empty_like(self.dpts_s)
+        T("us_mlp_bwd_pair_dydx", lambda: lib.us_mlp_bwd_pair_dydx(
             ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4,
-            P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st))
-        T("us_hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(
-            self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), n, S, P(self.z), self.bhost, P(self.g_o),
-            P(self.g_d), None, st))
+            P(self.d_raw), 4, N, None, None, None, None, 1, None, None, 0, P(self.dydx_s), P(self.dydx_c), P(self.dpts_s), P(self.dpts_c), st))
+        T("us_ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, n, S, P(self.g_o), P(self.g_d), st))
         T("us_pose_window_step", lambda: lib.us_pose_window_step(
             P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose), self.lr_R, self.lr_T,
             b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st))
