@@ -676,6 +676,9 @@ extern "C" int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b)
 #ifndef MLP_BWD_PAIR_WG
 #define MLP_BWD_PAIR_WG 128
 #endif
+#ifndef MLP_BWD_IN_WG
+#define MLP_BWD_IN_WG 1024               // workgroups per decoder of the input-gradient-only launch
+#endif
 static_assert(MLP_BWD_PAIR_WG <= MLP_BWD_MAX_WG, "the pair launch's partial rows must fit the workspace us_mlp_bwd_workspace_bytes sizes");
 static int64_t mlp_pair_rows(const us_mlp_desc* d, int64_t n) {
     const int waves = MLP_BF_BWD_WAVES(d->width);
@@ -761,7 +764,14 @@ static int mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const floa
                    (long long)dout_stride_a, dL_din_a, grad_params_a, (float*)workspace_a, dy_dx_a, dpts_a};
     MlpBwdJob b = {params_b, (int)db->has_bias, (int)db->n_out, (int)db->out_act, in_b, out_b, (long long)out_stride_b, dL_dout_b,
                    (long long)dout_stride_b, dL_din_b, grad_params_b, (float*)workspace_b, dy_dx_b, dpts_b};
-    MLP_PAIR_DISPATCH(k_mlp_bwd_pair, a, b, n, lm);
+    if (wgrad) {
+        MLP_PAIR_DISPATCH(k_mlp_bwd_pair, a, b, n, lm);
+    } else {                                                     // input gradients only: the lean kernel, one workgroup per 8 chunks or so
+        int64_t rows = us_cdiv(n, 16 * MLP_BF_BWD_IN_NQ * MLP_BF_BWD_IN_WAVES);
+        if (rows > MLP_BWD_IN_WG) rows = MLP_BWD_IN_WG;
+        grid = dim3((unsigned)rows, 2); block = dim3(MLP_BF_BWD_IN_WAVES * 64);
+        MLP_PAIR_DISPATCH(k_mlp_bwd_pair_in, a, b, n, lm);
+    }
     US_CHECK_LAUNCH("us_mlp_bwd_pair");
     if (wgrad && !(flags & US_MLP_DEFER_REDUCE)) {
         const int npa = (int)us_mlp_n_params(da), npb = (int)us_mlp_n_params(db);
