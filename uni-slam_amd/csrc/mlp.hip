@@ -677,7 +677,7 @@ extern "C" int us_mlp_pair_supported(const us_mlp_desc* a, const us_mlp_desc* b)
 #define MLP_BWD_PAIR_WG 128
 #endif
 #ifndef MLP_BWD_IN_WG
-#define MLP_BWD_IN_WG 1024               // workgroups per decoder of the input-gradient-only launch
+#define MLP_BWD_IN_WG 128                // workgroups per decoder of the input-gradient-only launch (mlp_bf16.inc has the sweep)
 #endif
 static_assert(MLP_BWD_PAIR_WG <= MLP_BWD_MAX_WG, "the pair launch's partial rows must fit the workspace us_mlp_bwd_workspace_bytes sizes");
 static int64_t mlp_pair_rows(const us_mlp_desc* d, int64_t n) {
