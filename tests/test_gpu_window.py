@@ -442,3 +442,45 @@ def test_decoder_backward_contracts_dydx_in_registers(S, n_rays):
             assert torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
         if want_w:
             assert torch.equal(out[4], ref[4]) and torch.equal(out[5], ref[5])
+
+
+def test_mapwindow_with_pixels_without_depth():
+    """a window whose pools hold pixels without a depth measurement (src/utils/Renderer.py:104-130: the importance-sampling branch):
+    MapWindow runs eagerly (capture is refused: the branch reads a row count on the host) and gives the loss statistics and the pose
+    gradient input of MapStep on the same rays, jitter and draws"""
+    import unislam_amd as us
+    b, P, n_per = 5, 400, 60
+    c2ws, depths, colors, dirs = _window(b, P, 21)
+    depths[:, ::7] = 0.0
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(P, (b, n_per), generator=g).to(DEV)
+    R = b * n_per
+    t_rand = torch.rand(R, 40, generator=g).to(DEV)
+    n0 = int((depths.to(DEV).gather(1, idx) <= 0).sum())
+    assert n0 > 10
+    zd = (torch.rand(n0, 32, generator=g).to(DEV), torch.rand(n0, 8, generator=g).to(DEV))
+    outs = []
+    for mode in ("window", "step"):
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True)
+        assert win.has_zero
+        with pytest.raises(us.UniSlamHipError):
+            win.capture()
+        if mode == "window":
+            step.lr = {k: 0.0 for k in step.lr}; win.cam_lr = 0.0
+            loss = win.iterate(idx, t_rand=t_rand, zero_depth_draws=zd)
+            g_o, g_d = step.g_o[:R].clone(), step.g_d[:R].clone()
+        else:
+            win.draw(idx)
+            loss = step.forward_backward(*win.rays(), t_rand=t_rand, has_zero_depth=True, ray_grads=True, zero_depth_draws=zd)
+            g_o, g_d = [t.clone() for t in step.ray_gradients()]
+        outs.append((float(loss), step.stats.clone(), step.z[:R].clone(), g_o, g_d))
+    a, c = outs
+    assert np.isfinite(a[0]) and a[0] == c[0] and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
+    for k in (3, 4):
+        assert torch.allclose(a[k], c[k], rtol=1e-4, atol=1e-5 * float(c[k].abs().max()))
