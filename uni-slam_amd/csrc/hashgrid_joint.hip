@@ -513,12 +513,12 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         };
         // stage entry: {local entry, d0, d1, bin of the level}; its position k in the stage is its cursor value (minus `sb`), and the
         // record's address follows at copy-out: gd[bin] + (k + sb) * 3
-        auto copy_out = [&](uint32_t cnt, const uint32_t* gd, uint32_t sb) {
+        auto copy_out = [&](uint32_t cnt, const uint32_t* gd, uint32_t sb, uint32_t emask) {
             auto put = [&](const uint4 a, uint32_t k) {
                 const uint32_t addr = gd[a.w & (J_LVL_BINS - 1u)] + (k + sb) * 3u;
                 if (addr + 3u <= rec_cap_dw) {
                     typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-                    u32x3 w; w.x = a.x; w.y = a.y; w.z = a.z;
+                    u32x3 w; w.x = a.x & emask; w.y = a.y; w.z = a.z;
                     *reinterpret_cast<u32x3*>(rec + addr) = w;
                 }
             };
@@ -529,14 +529,15 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             }
             if (k < cnt) put(st4[k], k);
         };
-        uint32_t kk[4];                                          // stage positions of this lane's 8 records, 16 bits each
         lds_barrier();                                           // the previous level's copy-out has left the stage; cursors are in place
         if (!split) {
+            // joint level: the stage entry carries table B's local entry; table A's is that masked (at copy-out), so the second half
+            // only replaces the two values at the SAME positions -- no entries, bins or cursors again
             const uint32_t nbm = (1u << q.lgB) - 1u, lg = q.lgB;
+            uint32_t k8[8];                                      // stage positions of this lane's records (0xFFFF: none)
             {
-                uint32_t e[8];                                   // table B's entries; they give table A's bin and (masked) local entry
+                uint32_t e[8];
                 slot_entries((q.flags & J_HASHED_B) != 0u, q.hsB, q.res, q.res2, cell, e);
-                uint32_t k8[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     k8[c] = 0xFFFFu;
@@ -544,32 +545,27 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if (((tail >> c) & 1u) && k8[c] < J_STAGE)
-                        st4[k8[c]] = make_uint4(local_of(e[c], lg) & q.maskA, __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), (e[c] >> BIN_LINE_LOG2) & nbm);
+                    if (k8[c] < J_STAGE)
+                        st4[k8[c]] = make_uint4(local_of(e[c], lg), __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), (e[c] >> BIN_LINE_LOG2) & nbm);
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) kk[c] = (k8[2 * c] & 0xFFFFu) | (k8[2 * c + 1] << 16);
             }
             consume_next();
             lds_barrier();
             const uint32_t cnt = min(ttot[par], (uint32_t)J_STAGE);
-            copy_out(cnt, gdl[par], 0u);
+            copy_out(cnt, gdl[par], 0u, q.maskA);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
             lds_barrier();
-            {                                                    // table B: same bins, same stage positions, the B half of the bin's region
-                uint32_t e[8];
-                slot_entries((q.flags & J_HASHED_B) != 0u, q.hsB, q.res, q.res2, cell, e);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t k = (kk[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
-                    if (((tail >> c) & 1u) && k < J_STAGE)
-                        st4[k] = make_uint4(local_of(e[c], lg), __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), (e[c] >> BIN_LINE_LOG2) & nbm);
+            for (int c = 0; c < 8; ++c) {
+                if (k8[c] < J_STAGE) {
+                    uint32_t* w = reinterpret_cast<uint32_t*>(&st4[k8[c]]);
+                    w[1] = __float_as_uint(val[c][0]); w[2] = __float_as_uint(val[c][1]);
                 }
             }
             lds_barrier();
-            copy_out(cnt, gdb[par], 0u);
+            copy_out(cnt, gdb[par], 0u, 0xFFFFFFFFu);
         } else {
             const uint32_t nbA = 1u << q.lgA, mA = nbA - 1u, mB = (1u << q.lgB) - 1u;
             {                                                    // table A: bins [0, nbA) of the level, stage index = cursor
@@ -590,7 +586,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t na = min(atot[par], (uint32_t)J_STAGE);
-            copy_out(na, gdl[par], 0u);
+            copy_out(na, gdl[par], 0u, 0xFFFFFFFFu);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -612,7 +608,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 }
             }
             lds_barrier();
-            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gdl[par], sb);
+            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gdl[par], sb, 0xFFFFFFFFu);
         }
     }
 }
