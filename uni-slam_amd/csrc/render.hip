@@ -774,8 +774,10 @@ __device__ __forceinline__ float median_select(const float* __restrict__ a, cons
     __syncthreads();
     uint32_t local = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
+        const float av = b ? fabsf(a[i] - b[i]) : a[i];          // unconditional: value and flag in ONE round trip
+        const bool ok = !valid || valid[i];
         uint32_t k = 0xFFFFFFFFu;                                // flagged-out elements never enter a histogram
-        if (!valid || valid[i]) { k = __float_as_uint(b ? fabsf(a[i] - b[i]) : a[i]); ++local; }
+        if (ok) { k = __float_as_uint(av); ++local; }
         key[i] = k;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
@@ -789,9 +791,29 @@ __device__ __forceinline__ float median_select(const float* __restrict__ a, cons
         __syncthreads();
         const uint32_t prefix = sel[1];
         const int sh = 8 * pass;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const uint32_t k = key[i];
-            if (k != 0xFFFFFFFFu && (pass == 3 || (k >> (sh + 8)) == prefix)) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+        if (pass == 3) {
+            // sign + high exponent bits: a handful of distinct digits, nearly all elements in one or two of them -- plain atomics would
+            // queue up on those addresses.  One atomic per distinct digit and wave: the first lane left names its digit, the lanes
+            // that share it are counted by a ballot.  (All lanes of a wave run the same number of outer iterations: n is uniform.)
+            for (int i0 = threadIdx.x & ~63; i0 < n; i0 += 1024) {
+                const int i = i0 + (threadIdx.x & 63);
+                const uint32_t k = i < n ? key[i] : 0xFFFFFFFFu;
+                const bool act = k != 0xFFFFFFFFu;
+                const uint32_t d = k >> 24;
+                uint64_t rem = __ballot(act);
+                while (rem) {
+                    const int leader = __ffsll((unsigned long long)rem) - 1;
+                    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                    const uint64_t same = __ballot(act && d == dl);
+                    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+                    rem &= ~same;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const uint32_t k = key[i];
+                if (k != 0xFFFFFFFFu && (k >> (sh + 8)) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x < 64) {                                  // one wave: 4 bins per lane, wave scan, pick the bin of the rank
@@ -833,31 +855,36 @@ __global__ __launch_bounds__(1024) void k_track_gate_reduce(const float* __restr
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sel[3];
     __shared__ double sh[LOSS_NSTAT][16];
+    // the ten partials of a ray are five unconditional 8-byte loads, two rays in flight per thread; those of the first 2048 rays (every
+    // ray of a Replica / ScanNet tracking batch) are requested BEFORE the median's barriers and arrive under them
+    static_assert(LOSS_NSTAT == 10, "five float2 per ray");
+    float2 p[2][5];
+    auto request = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 1024 * u;
+            const float2* src = reinterpret_cast<const float2*>(partials + (int64_t)(i < n ? i : 0) * LOSS_NSTAT);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) p[u][q] = src[q];
+        }
+    };
+    request(threadIdx.x);
     const float med = median_select(err, nullptr, valid, n, key, hist, sel);
     if (threadIdx.x == 0) median_out[0] = med;
     const float thr = 10.0f * med;
     double acc[LOSS_NSTAT];
 #pragma unroll
     for (int k = 0; k < LOSS_NSTAT; ++k) acc[k] = 0.0;
-    // the gate comes from the keys in LDS (0xFFFFFFFF = not pre-filtered in); the ten partials of a ray are five unconditional 8-byte
-    // loads, two rays in flight per thread: one round trip to memory instead of a dependent chain
-    static_assert(LOSS_NSTAT == 10, "five float2 per ray");
+    // the gate comes from the keys in LDS (0xFFFFFFFF = not pre-filtered in)
     for (int i0 = threadIdx.x; i0 < n; i0 += 2048) {
-        float2 p[2][5]; bool gate[2];
+        if (i0 != (int)threadIdx.x) request(i0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + 1024 * u;
-            const bool in = i < n;
-            const uint32_t k = in ? key[i] : 0xFFFFFFFFu;
-            gate[u] = k != 0xFFFFFFFFu && __uint_as_float(k) < thr;
-            const float2* src = reinterpret_cast<const float2*>(partials + (int64_t)(in ? i : 0) * LOSS_NSTAT);
+            const uint32_t k = i < n ? key[i] : 0xFFFFFFFFu;
+            const bool gate = k != 0xFFFFFFFFu && __uint_as_float(k) < thr;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) p[u][q] = src[q];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { acc[2 * q] += gate[u] ? (double)p[u][q].x : 0.0; acc[2 * q + 1] += gate[u] ? (double)p[u][q].y : 0.0; }
+            for (int q = 0; q < 5; ++q) { acc[2 * q] += gate ? (double)p[u][q].x : 0.0; acc[2 * q + 1] += gate ? (double)p[u][q].y : 0.0; }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
