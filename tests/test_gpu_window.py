@@ -484,3 +484,34 @@ def test_mapwindow_with_pixels_without_depth():
     assert np.isfinite(a[0]) and a[0] == c[0] and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
     for k in (3, 4):
         assert torch.allclose(a[k], c[k], rtol=1e-4, atol=1e-5 * float(c[k].abs().max()))
+
+
+def test_a_captured_iteration_does_not_keep_its_owner_in_a_cycle():
+    """hipGraphDestroy is not permitted while a stream captures: a graph that is only reachable from a garbage cycle would be destroyed by
+    the cyclic collector at an arbitrary later time -- e.g. inside the NEXT capture (a 40-frame SLAM run with one captured MapWindow
+    per mapped frame aborted there).  The owner of a CapturedIteration must therefore die by reference counting alone."""
+    import gc, weakref
+    from unislam_amd.graph import CapturedIteration
+
+    class Owner:
+        def __init__(self):
+            self.x = torch.zeros(8, device=DEV)
+            self.it = CapturedIteration(lambda: self.work(), warmup=1)
+
+        def work(self):
+            self.x.add_(1.0)
+            return self.x
+
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        o = Owner()
+        before = float(o.x[0])
+        o.it.replay(); torch.cuda.synchronize()
+        assert float(o.x[0]) == before + 1.0 and o.it.fn is None
+        r = weakref.ref(o)
+        del o
+        assert r() is None                                                 # no collector involved
+    finally:
+        if was:
+            gc.enable()

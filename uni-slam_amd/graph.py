@@ -11,6 +11,8 @@ Requirements on `fn`: static tensor addresses (update inputs in place), no host 
 indexing), optimisers constructed with capturable=True and already stepped at least once (warmup >= 1 does that): a
 capture that contains an optimiser's lazy state initialisation would re-zero the moments on every replay.
 """
+import gc
+
 import torch
 
 
@@ -24,8 +26,19 @@ class CapturedIteration:
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        # No cyclic garbage collection while the stream captures: an older graph that is only reachable from a garbage cycle would be
+        # destroyed by the collector in the middle of the capture, and hipGraphDestroy is "not permitted when stream is capturing"
+        # (seen in a 40-frame SLAM run with one captured MapWindow per mapped frame).  The callable is dropped afterwards: it usually
+        # closes over the object that owns this one, and that cycle is what kept old graphs alive until a collection.
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+        finally:
+            if was:
+                gc.enable()
+        self.fn = None
 
     def replay(self):
         self.graph.replay()
