@@ -423,6 +423,9 @@ int us_pose_adam_step(float* pose7, const float* g7, float* m7, float* v7, doubl
 /* out[0] = lower median (torch.median) of |a[i] - b[i]| over the elements with valid[i] != 0 (valid NULL: all); +inf if none.
  * n <= 8192.  The 10 x median gate of the tracking loss: src/Tracker.py:212-214. */
 int us_masked_median(const float* a, const float* b, const uint8_t* valid, int64_t n, float* out, void* stream);
+/* out[0] = sum of a[i] over the elements with valid[i] != 0 (valid NULL: all) / max(their count, 1); fixed-order f64 sums, one launch.
+ * The tracker's mean rendered uncertainty of the pre-filtered rays, `rendered_weights.detach().mean()` src/Tracker.py:353. */
+int us_masked_mean(const float* a, const uint8_t* valid, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser  (replaces torch.optim.Adam at src/Mapper.py:364,445 / src/Tracker.py:328,242)
@@ -526,6 +529,22 @@ int us_window_sample(const float* c2w_first, const float* poses7, int b, int64_t
 int us_pose_window_step(float* poses7, int n_poses, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t row_a,
                         int64_t n_a, int first_pose_b, int64_t row_b, int64_t n_b, float* m7, float* v7, float* g7_out, double lr_q,
                         double lr_t, double beta1, double beta2, double eps, float* step_dev, int flags, void* stream);
+/* The tracker's pose step with the loop's minimum-loss bookkeeping in the same launch (src/Tracker.py:240-242 and :346-348):
+ * us_pose_window_step(pose7, 1, ..., rows [0, n_rays), US_POSE_OWN_STEP), and before the step: where loss[0] -- the loss of THIS iteration,
+ * rendered at pose7 as it is on entry -- is below min_loss[0], min_loss[0] takes it and best7[7] that pose (`candidate_cam_pose`).  A NaN
+ * loss never counts as better (torch's `<`).  g7_out nullable.  draw_counter (float[1], nullable) is advanced by one: the rng_counter of
+ * us_track_sample's in-kernel pixel draw when it has to outlive the per-frame optimiser state (step_dev restarts with every frame). */
+int us_pose_track_step(float* pose7, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n_rays, float* m7, float* v7,
+                       float* g7_out, double lr_q, double lr_t, double beta1, double beta2, double eps, float* step_dev, const float* loss,
+                       float* min_loss, float* best7, float* draw_counter, void* stream);
+
+/* Pose conversions of the drivers' per-frame glue, one launch each (src/common.py:182-208; on torch ops: chains of ~30 / ~20 small launches).
+ *   us_matrix_to_cam_pose  c2w[n][4][4] row-major -> pose7[n][7] = (pytorch3d matrix_to_quaternion of the rotation, real part first; the
+ *                          translation column), matrix_to_cam_pose(RT=True).  extrapolate != 0 (n must be 1, c2w holds TWO matrices):
+ *                          pose7[0] = 2 * pose(c2w[1]) - pose(c2w[0]), the constant-speed prediction of src/Tracker.py:317-320.
+ *   us_cam_pose_to_matrix  pose7[n][7] -> c2w[n][4][4] through pytorch3d quaternion_to_matrix, last row (0, 0, 0, 1). */
+int us_matrix_to_cam_pose(const float* c2w, int n, int extrapolate, float* pose7, void* stream);
+int us_cam_pose_to_matrix(const float* pose7, int n, float* c2w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -515,3 +515,93 @@ def test_a_captured_iteration_does_not_keep_its_owner_in_a_cycle():
     finally:
         if was:
             gc.enable()
+
+
+def test_track_step_keeps_the_minimum_loss_pose_and_mean_uncertainty():
+    """us_pose_track_step: the pose step with the tracker's minimum-loss bookkeeping in its launch (src/Tracker.py:346-348) against
+    us_pose_window_step + the same bookkeeping on torch ops, both chains, bit for bit; us_masked_mean against torch (:353)"""
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    torch.manual_seed(3)
+    dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+    H, Wd, fx, fy, cx, cy, eh, ew, n = 60, 80, 40.0, 40.0, 39.5, 29.5, 4, 5, 300
+    g = torch.Generator().manual_seed(4)
+    gt_depth = (torch.rand(H, Wd, generator=g) * 1.5 + 0.5).to(DEV); gt_depth[20, 20:30] = 0.0
+    gt_color = torch.rand(H, Wd, 3, generator=g).to(DEV)
+    w = dict(fs=10, center=200, tail=50, color=5, depth=1)
+    pose0 = torch.tensor([0.9, 0.1, -0.2, 0.3, 3.0, 1.2, 0.0], device=DEV)
+    draws = [(torch.randint((H - 2 * eh) * (Wd - 2 * ew), (n,), generator=g).to(DEV), torch.rand(n, 40, generator=g).to(DEV)) for _ in range(8)]
+    for fast in (True, False):
+        res = []
+        for keep in (True, False):                                                       # (both runs keep the candidate; the second ignores it)
+            ts = us.TrackStep(es, ec, dec, BOUND, 32, 8, 0.06, w, max_rays=n)
+            ts.fast_path = fast
+            ts.begin_frame(pose0, gt_color, gt_depth, 2e-2, 1e-2, H, Wd, fx, fy, cx, cy, eh, ew)      # large steps: the loss goes up and down
+            min_loss, cand, losses = torch.full((1,), float("inf"), device=DEV), ts.pose.clone(), []
+            for idx, tr in draws:
+                before = ts.pose.clone()
+                loss, unc, valid = ts.iterate_fused(n, t_rand=tr, indices=idx)
+                better = loss < min_loss
+                min_loss, cand = torch.where(better, loss, min_loss), torch.where(better, before, cand)
+                losses.append(float(loss))
+            res.append((losses, ts.pose.clone(), min_loss, cand, ts.min_loss.clone(), ts.best_pose.clone()))
+            if keep:
+                m = ts.mean_uncertainty(unc, valid)
+                ref = (unc * valid.float()).sum() / valid.float().sum().clamp(min=1)
+                np.testing.assert_allclose(float(m), float(ref), rtol=1e-6)
+        (la, pa, ma, ca, dev_min, dev_best), (lb, pb, mb, cb, _, _) = res
+        assert la == lb and torch.equal(pa, pb)                                          # the step itself is unchanged
+        assert min(la) < la[0] and la.index(min(la)) not in (0, len(la) - 1)             # the minimum sits inside the loop
+        assert torch.equal(dev_min, ma) and torch.equal(dev_best, ca) and torch.equal(ca, cb)
+        assert float(ts.draw_ctr) == len(draws) and float(ts.pstep) == len(draws)         # the draw's counter advances with the step ...
+        ts.begin_frame(pose0, gt_color, gt_depth, 2e-2, 1e-2, H, Wd, fx, fy, cx, cy, eh, ew)
+        assert float(ts.draw_ctr) == len(draws) and float(ts.pstep) == 0                  # ... and is not reset with the frame
+    # a NaN loss never replaces the candidate; an empty selection has mean 0
+    lib, P_ = L.lib(), L.ptr
+    z3 = torch.zeros(4, 3, device=DEV)
+    pose, m7, v7, stp = pose0.clone(), torch.zeros(7, device=DEV), torch.zeros(7, device=DEV), torch.zeros(1, device=DEV)
+    mn, best = torch.tensor([0.5], device=DEV), torch.full((7,), 9.0, device=DEV)
+    for val, taken in ((float("nan"), False), (0.75, False), (0.25, True)):
+        lv = torch.tensor([val], device=DEV)
+        L.check(lib.us_pose_track_step(P_(pose), P_(z3), P_(z3), P_(z3), 4, P_(m7), P_(v7), None, 1e-3, 1e-3, 0.5, 0.999, 1e-8, P_(stp),
+                                       P_(lv), P_(mn), P_(best), None, L.stream()), "us_pose_track_step")
+        assert (float(mn) == val) == taken and (float(best[4]) == 3.0) == taken
+    out, vals, none = torch.ones(1, device=DEV), torch.rand(10, device=DEV), torch.zeros(10, dtype=torch.uint8, device=DEV)
+    L.check(lib.us_masked_mean(P_(vals), P_(none), 10, P_(out), L.stream()), "us_masked_mean")
+    assert float(out) == 0.0
+    L.check(lib.us_masked_mean(P_(vals), None, 10, P_(out), L.stream()), "us_masked_mean")
+    np.testing.assert_allclose(float(out), float(vals.double().mean()), rtol=1e-6)
+
+
+def test_pose_conversion_kernels_equal_the_torch_chains():
+    """us_matrix_to_cam_pose / us_cam_pose_to_matrix (one launch each) against the torch restatement of pytorch3d's matrix_to_quaternion /
+    quaternion_to_matrix (src/common.py:182-208) -- every branch of the candidate selection (rotations by up to 180 degrees about the
+    three axes and about random ones), the constant-speed extrapolation (src/Tracker.py:317-320), and the round trip"""
+    import unislam_amd as us
+    from unislam_amd import common as C
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(400, 4, generator=g)
+    q[:40, 0] *= 1e-3                                                           # nearly half turns: the real part is NOT the largest
+    q[40:50] = torch.eye(4)[[1, 2, 3, 0, 1, 2, 3, 1, 2, 3]] + 1e-4 * torch.randn(10, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    R = O.quaternion_to_matrix(q)
+    c2w = torch.eye(4).repeat(400, 1, 1); c2w[:, :3, :3] = R; c2w[:, :3, 3] = torch.randn(400, 3, generator=g) * 3
+    ref = O.matrix_to_cam_pose(c2w)                                              # CPU torch chain (oracle restatement, pinned by g14)
+    got = C.matrix_to_cam_pose(c2w.to(DEV))
+    assert got.shape == (400, 7) and len(set(ref[:, :4].abs().argmax(-1).tolist())) == 4       # all four branches were taken
+    assert torch.allclose(got.cpu(), ref, rtol=0, atol=2e-7) and torch.equal(got[:, 4:].cpu(), c2w[:, :3, 3])
+    back = C.cam_pose_to_matrix(got)
+    ref_back = torch.eye(4).repeat(400, 1, 1); ref_back[:, :3, :3] = O.quaternion_to_matrix(ref[:, :4]); ref_back[:, :3, 3] = ref[:, 4:]
+    assert torch.allclose(back.cpu(), ref_back, rtol=0, atol=5e-7) and torch.allclose(back.cpu(), c2w, rtol=0, atol=2e-6)
+    assert torch.equal(back[:, 3].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]).repeat(400, 1))
+    pred = C.predict_cam_pose(c2w[3].to(DEV), c2w[4].to(DEV))
+    assert pred.shape == (1, 7) and torch.allclose(pred.cpu(), 2 * ref[4:5] - ref[3:4], rtol=0, atol=5e-7)
+    # tensors inside autograd keep the differentiable torch chain
+    p = got[:2].clone().requires_grad_(True)
+    C.cam_pose_to_matrix(p).sum().backward()
+    assert p.grad is not None and float(p.grad.abs().sum()) > 0

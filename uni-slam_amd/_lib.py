@@ -112,6 +112,7 @@ SIGNATURES = {
                                    c_f]),
     "us_pose_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_masked_median": (c_int, [c_f, c_f, c_f, c_i64, c_f, c_f]),
+    "us_masked_mean": (c_int, [c_f, c_f, c_i64, c_f, c_f]),
     "us_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_f]),
     "us_adam_step_segments": (c_int, [c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                       ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_int, ctypes.c_uint, c_f]),
@@ -139,6 +140,9 @@ SIGNATURES = {
     "us_window_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_pose_window_step": (c_int, [c_f, c_int, c_f, c_f, c_f, c_i64, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl,
                                     c_dbl, c_f, c_int, c_f]),
+    "us_matrix_to_cam_pose": (c_int, [c_f, c_int, c_int, c_f, c_f]),
+    "us_cam_pose_to_matrix": (c_int, [c_f, c_int, c_f, c_f]),
+    "us_pose_track_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f, c_f, c_f, c_f, c_f]),
 }
 
 # the experiments build (tools/build_experiments.sh, include/unislam_hip_experiments.h): bound when the loaded library exports them

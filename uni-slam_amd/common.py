@@ -174,15 +174,41 @@ def matrix_to_quaternion(matrix):
     return quat_candidates[best, :].reshape(batch_dim + (4,))
 
 
+def _on_device_plain(t):
+    return t.is_cuda and t.dtype == torch.float32 and not t.requires_grad and t.dim() == 3
+
+
 def matrix_to_cam_pose(batch_matrices, RT=True):
-    """common.py:182-194"""
+    """common.py:182-194.  Device tensors outside autograd take one launch (us_matrix_to_cam_pose) instead of ~30 torch ops."""
+    if RT and _on_device_plain(batch_matrices) and tuple(batch_matrices.shape[1:]) == (4, 4):
+        m = batch_matrices.contiguous()
+        out = torch.empty((m.shape[0], 7), dtype=torch.float32, device=m.device)
+        L.check(L.lib().us_matrix_to_cam_pose(L.ptr(m), m.shape[0], 0, L.ptr(out), L.stream()), "us_matrix_to_cam_pose")
+        return out
     if RT:
         return torch.cat([matrix_to_quaternion(batch_matrices[:, :3, :3]), batch_matrices[:, :3, 3]], dim=-1)
     return torch.cat([batch_matrices[:, :3, 3], matrix_to_quaternion(batch_matrices[:, :3, :3])], dim=-1)
 
 
+def predict_cam_pose(c2w_before, c2w_last):
+    """the tracker's constant-speed initial guess (Tracker.py:317-320): 2 * pose(c2w_last) - pose(c2w_before) on the 7 numbers -> [1, 7]"""
+    m = torch.stack([c2w_before, c2w_last], dim=0)
+    if _on_device_plain(m):
+        out = torch.empty((1, 7), dtype=torch.float32, device=m.device)
+        L.check(L.lib().us_matrix_to_cam_pose(L.ptr(m), 1, 1, L.ptr(out), L.stream()), "us_matrix_to_cam_pose")
+        return out
+    pre = matrix_to_cam_pose(m)
+    return 2 * pre[1:] - pre[0:1]
+
+
 def cam_pose_to_matrix(batch_poses):
-    """common.py:196-208"""
+    """common.py:196-208.  Device tensors outside autograd take one launch (us_cam_pose_to_matrix)."""
+    if batch_poses.is_cuda and batch_poses.dtype == torch.float32 and not batch_poses.requires_grad and batch_poses.dim() == 2 \
+            and batch_poses.shape[1] == 7:
+        p = batch_poses.contiguous()
+        out = torch.empty((p.shape[0], 4, 4), dtype=torch.float32, device=p.device)
+        L.check(L.lib().us_cam_pose_to_matrix(L.ptr(p), p.shape[0], L.ptr(out), L.stream()), "us_cam_pose_to_matrix")
+        return out
     c2w = torch.eye(4, device=batch_poses.device).unsqueeze(0).repeat(batch_poses.shape[0], 1, 1)
     c2w[:, :3, :3] = quaternion_to_matrix(batch_poses[:, :4])
     c2w[:, :3, 3] = batch_poses[:, 4:]

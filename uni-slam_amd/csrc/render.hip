@@ -845,6 +845,26 @@ __global__ __launch_bounds__(1024) void k_masked_median(const float* __restrict_
     if (threadIdx.x == 0) out[0] = m;
 }
 
+// mean of the flagged values (sum / max(count, 1)), one workgroup, fixed-order f64 sums: the tracker's mean rendered uncertainty of the
+// rays that passed the pre-filter (src/Tracker.py:353, `rendered_weights.detach().mean()` on the compacted rays)
+__global__ __launch_bounds__(1024) void k_masked_mean(const float* __restrict__ a, const uint8_t* __restrict__ valid, int64_t n, float* __restrict__ out) {
+    __shared__ double shs[16], shc[16];
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float v = a[i];
+        const bool ok = !valid || valid[i];
+        s += ok ? (double)v : 0.0; c += ok ? 1.0 : 0.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { shs[threadIdx.x >> 6] = s; shc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, C = 0.0;
+        for (int w = 0; w < 16; ++w) { S += shs[w]; C += shc[w]; }
+        out[0] = (float)(S / (C < 1.0 ? 1.0 : C));
+    }
+}
+
 // The tracking loss's median gate and its statistics in ONE workgroup (src/Tracker.py:212-238): the compositing kernel left |gt - depth|
 // per ray and the ten loss partials of every ray that passes the OTHER half of the gate (pre-filter, alpha mask); here the lower median
 // over the pre-filtered rays, then the fixed-order sums of the partials of the rays with err < 10 x median.
@@ -1581,6 +1601,14 @@ extern "C" int us_masked_median(const float* a, const float* b, const uint8_t* v
     US_REQUIRE(n >= 0 && n <= MEDIAN_MAX, US_ERR_SHAPE, "us_masked_median: n = %lld not in 0..%d", (long long)n, MEDIAN_MAX);
     hipLaunchKernelGGL(k_masked_median, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, valid, (int)n, out);
     US_CHECK_LAUNCH("us_masked_median");
+    return US_OK;
+}
+
+extern "C" int us_masked_mean(const float* a, const uint8_t* valid, int64_t n, float* out, void* stream) {
+    US_REQUIRE(a && out, US_ERR_NULL, "us_masked_mean: NULL pointer");
+    US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_masked_mean: n = %lld", (long long)n);
+    hipLaunchKernelGGL(k_masked_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, valid, n, out);
+    US_CHECK_LAUNCH("us_masked_mean");
     return US_OK;
 }
 

@@ -66,7 +66,9 @@ struct PoseStep {
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_pose_window_step(float* __restrict__ poses7, const float* __restrict__ g_o, const float* __restrict__ g_d,
                                                           const float* __restrict__ dirs, float* __restrict__ m7, float* __restrict__ v7,
-                                                          float* __restrict__ g7_out, float* __restrict__ step_dev, PoseStep ps) {
+                                                          float* __restrict__ g7_out, float* __restrict__ step_dev, PoseStep ps,
+                                                          const float* __restrict__ loss = nullptr, float* __restrict__ min_loss = nullptr,
+                                                          float* __restrict__ best7 = nullptr, float* __restrict__ draw_counter = nullptr) {
     __shared__ double sh[12][THREADS / 64];
     __shared__ float g7[7];
     const int j = blockIdx.x;
@@ -126,6 +128,13 @@ __global__ __launch_bounds__(THREADS) void k_pose_window_step(float* __restrict_
     if (e < 7) {
         const float gi = g7[e];
         if (g7_out) g7_out[(int64_t)j * 7 + e] = gi;
+        if (loss) {                                                // the tracker's candidate (src/Tracker.py:346-348): the pose the loss was
+            const bool better = loss[0] < min_loss[0];             // rendered at is kept while it is the best so far; the seven lanes read
+            if (better) {                                          // the old minimum before lane 0 replaces it (one wave, program order)
+                best7[e] = pose[e];
+                if (e == 0) min_loss[0] = loss[0];
+            }
+        }
         if (ps.apply) {
             float step_size, bc2s;
             const float lr = e < 4 ? ps.lr_q : ps.lr_t;
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(THREADS) void k_pose_window_step(float* __restrict_
         }
     }
     if (ps.apply && ps.own_step && threadIdx.x == 0) step_dev[0] = step;
+    if (draw_counter && threadIdx.x == 0) draw_counter[0] += 1.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -189,5 +199,103 @@ extern "C" int us_pose_window_step(float* poses7, int n_poses, const float* g_ra
     hipLaunchKernelGGL(k_pose_window_step<256>, dim3((unsigned)n_poses), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
                        g7_out, step_dev, ps);
     US_CHECK_LAUNCH("us_pose_window_step");
+    return US_OK;
+}
+
+// the tracker's pose step (src/Tracker.py:240-242 inside the loop of :333-348): us_pose_window_step for ONE pose with its own step count,
+// plus the minimum-loss bookkeeping of the loop in the same launch -- loss[0] is the loss of THIS iteration (rendered at the pose as it is
+// on entry); where it is below min_loss[0], min_loss and best7 take it and that pose.  NaN never counts as better (torch's `<`).
+// draw_counter (nullable) is advanced by one: the counter of us_track_sample's in-kernel pixel draw, which must outlive the per-frame
+// optimiser state (step_dev restarts at 0 with every frame; a draw keyed to it would pick the same pixels in every frame).
+extern "C" int us_pose_track_step(float* pose7, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t n_rays, float* m7,
+                                  float* v7, float* g7_out, double lr_q, double lr_t, double beta1, double beta2, double eps, float* step_dev,
+                                  const float* loss, float* min_loss, float* best7, float* draw_counter, void* stream) {
+    US_REQUIRE(pose7 && g_rays_o && g_rays_d && dirs && m7 && v7 && step_dev, US_ERR_NULL, "us_pose_track_step: NULL pointer");
+    US_REQUIRE(loss && min_loss && best7, US_ERR_NULL, "us_pose_track_step: loss, min_loss and best7 are required (us_pose_window_step has none)");
+    US_REQUIRE(n_rays >= 0, US_ERR_SHAPE, "us_pose_track_step: bad shape");
+    PoseStep ps;
+    ps.nA = n_rays; ps.rowA = 0; ps.nB = 0; ps.rowB = 0; ps.jB = 0;
+    ps.lr_q = (float)lr_q; ps.lr_t = (float)lr_t; ps.b1 = (float)beta1; ps.b2 = (float)beta2; ps.eps = (float)eps;
+    ps.own_step = 1; ps.apply = 1;
+    hipLaunchKernelGGL(k_pose_window_step<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, pose7, g_rays_o, g_rays_d, dirs, m7, v7, g7_out,
+                       step_dev, ps, loss, min_loss, best7, draw_counter);
+    US_CHECK_LAUNCH("us_pose_track_step");
+    return US_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pose <-> matrix (src/common.py:182-208): the per-frame glue of both drivers.  On torch ops one conversion is a chain of ~30 / ~20
+// small launches (0.43 / 0.25 ms of host time each, MI355X box) -- a third of a tracked frame; here one launch each.
+// ---------------------------------------------------------------------------------------------------------------
+// pytorch3d.transforms.matrix_to_quaternion (real part first): four candidates, the one with the largest |q_m| is returned; then
+// the translation column.  extrapolate: n == 1 and c2w holds TWO matrices -- the constant-speed prediction 2 * pose(c2w[1]) - pose(c2w[0])
+// of src/Tracker.py:317-320 comes out (element-wise on the 7 numbers, as there).
+__device__ __forceinline__ void w_matrix_pose(const float* __restrict__ M, float q[7]) {
+    const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[4], m11 = M[5], m12 = M[6], m20 = M[8], m21 = M[9], m22 = M[10];
+    const float a[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+    float qa[4];
+    int best = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qa[c] = a[c] > 0.0f ? sqrtf(a[c]) : 0.0f;                 // _sqrt_positive_part
+        if (qa[c] > qa[best]) best = c;                            // argmax: the first of equal maxima
+    }
+    const float cand[4][4] = {{qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01},
+                              {m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20},
+                              {m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21},
+                              {m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]}};
+    const float den = 2.0f * fmaxf(qa[best], 0.1f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = cand[0][c];
+        if (best == 1) v = cand[1][c]; else if (best == 2) v = cand[2][c]; else if (best == 3) v = cand[3][c];
+        q[c] = v / den;
+    }
+    q[4] = M[3]; q[5] = M[7]; q[6] = M[11];
+}
+
+__global__ __launch_bounds__(64) void k_matrix_to_pose(const float* __restrict__ c2w, int n, int extrapolate, float* __restrict__ pose7) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    float q[7];
+    w_matrix_pose(c2w + (int64_t)i * 16, q);
+    if (extrapolate) {
+        float q1[7];
+        w_matrix_pose(c2w + 16, q1);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) q[c] = 2.0f * q1[c] - q[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) pose7[(int64_t)i * 7 + c] = q[c];
+}
+
+__global__ __launch_bounds__(64) void k_pose_to_matrix(const float* __restrict__ pose7, int n, float* __restrict__ c2w) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* q = pose7 + (int64_t)i * 7;
+    float R[9];
+    w_quat_rot(q, R);
+    float* M = c2w + (int64_t)i * 16;
+    M[0] = R[0]; M[1] = R[1]; M[2] = R[2]; M[3] = q[4];
+    M[4] = R[3]; M[5] = R[4]; M[6] = R[5]; M[7] = q[5];
+    M[8] = R[6]; M[9] = R[7]; M[10] = R[8]; M[11] = q[6];
+    M[12] = 0.0f; M[13] = 0.0f; M[14] = 0.0f; M[15] = 1.0f;
+}
+
+extern "C" int us_matrix_to_cam_pose(const float* c2w, int n, int extrapolate, float* pose7, void* stream) {
+    US_REQUIRE(c2w && pose7, US_ERR_NULL, "us_matrix_to_cam_pose: NULL pointer");
+    US_REQUIRE(n >= 0 && (!extrapolate || n == 1), US_ERR_SHAPE, "us_matrix_to_cam_pose: n = %d (the extrapolation takes two matrices and returns one pose)", n);
+    if (n == 0) return US_OK;
+    hipLaunchKernelGGL(k_matrix_to_pose, dim3((unsigned)us_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, c2w, n, extrapolate, pose7);
+    US_CHECK_LAUNCH("us_matrix_to_cam_pose");
+    return US_OK;
+}
+
+extern "C" int us_cam_pose_to_matrix(const float* pose7, int n, float* c2w, void* stream) {
+    US_REQUIRE(pose7 && c2w, US_ERR_NULL, "us_cam_pose_to_matrix: NULL pointer");
+    US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_cam_pose_to_matrix: n = %d", n);
+    if (n == 0) return US_OK;
+    hipLaunchKernelGGL(k_pose_to_matrix, dim3((unsigned)us_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, pose7, n, c2w);
+    US_CHECK_LAUNCH("us_cam_pose_to_matrix");
     return US_OK;
 }

@@ -12,7 +12,7 @@ Left out: visualiser, logger/checkpoints, mesher (SURVEY.md 8 "out of scope").
 """
 import torch
 
-from .common import cam_pose_to_matrix, get_samples, matrix_to_cam_pose
+from .common import cam_pose_to_matrix, get_samples, matrix_to_cam_pose, predict_cam_pose
 from .step import MapStep, TrackStep
 from .window import MapWindow
 
@@ -177,30 +177,34 @@ class Tracker:
                               c["w"], mask_mode=slam.cfg["t_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"])
         self.num_cam_iters = c["iters"]
         self.rendered_weight = {}
+        self._graph = None
 
     def track_frame(self, idx, color, depth):
         s, c, dev = self.s, self.c, self.s.device
         H, W, fx, fy, cx, cy = s.cam
         pre_c2w = s.estimate_c2w_list[idx - 1]
         if c["const_speed_assumption"] and idx - 2 >= 0:                                # linear prediction (:317-320)
-            pre = matrix_to_cam_pose(torch.stack([s.estimate_c2w_list[idx - 2], pre_c2w], dim=0))
-            cam_pose = 2 * pre[1:] - pre[0:1]
+            cam_pose = predict_cam_pose(s.estimate_c2w_list[idx - 2], pre_c2w)
         else:
             cam_pose = matrix_to_cam_pose(pre_c2w.unsqueeze(0))
-        self.step.begin_frame(cam_pose[0], color, depth, c["lr_T"], c["lr_R"], H, W, fx, fy, cx, cy, c["ignore_edge_H"], c["ignore_edge_W"],
-                              betas=(0.5, 0.999))
-        min_loss = torch.full((1,), float("inf"), device=dev)
-        cand = self.step.pose.clone()
+        begin = lambda: self.step.begin_frame(cam_pose[0], color, depth, c["lr_T"], c["lr_R"], H, W, fx, fy, cx, cy, c["ignore_edge_H"],
+                                              c["ignore_edge_W"], betas=(0.5, 0.999))
+        begin()
+        # The iteration is nine short launches: issued one by one from Python the loop is host-bound (2.2 ms per frame at Replica's
+        # settings for 1.1 ms of kernels).  Every buffer of TrackStep is static, the pixel draw and the jitter happen in the kernels,
+        # and the optimiser's state lives on the device, so ONE captured graph serves every iteration of every frame.
+        if c.get("graph_replay", True) and self._graph is None:
+            from .graph import CapturedIteration
+            self.step.iterate_fused(c["pixels"])                                        # eager once: lazy buffers, then the frame's state again
+            begin()
+            self._graph = CapturedIteration(lambda: self.step.iterate_fused(c["pixels"]), warmup=0)
         it = 0
         while it < self.num_cam_iters:                                                  # re-read: the count may double mid-frame
-            pose_before = self.step.pose.clone()                                        # the loss belongs to the pose it was rendered at
-            loss, unc, valid = self.step.iterate_fused(c["pixels"])
-            better = loss < min_loss                                                    # (:346-348), kept on the device
-            min_loss = torch.where(better, loss, min_loss)
-            cand = torch.where(better, pose_before, cand)
+            # the minimum-loss candidate (:346-348) is kept by the pose step's launch: step.min_loss / step.best_pose, on the device
+            loss, unc, valid = self._graph.replay() if self._graph is not None else self.step.iterate_fused(c["pixels"])
             it += 1
             if it == self.num_cam_iters - 1:                                            # (:352-364)
-                w = (unc * valid.float()).sum() / valid.float().sum().clamp(min=1)
+                w = self.step.mean_uncertainty(unc, valid).clone()
                 self.rendered_weight[idx] = w
                 if c["activated_mapping_mode"] and float(w) > c["uncertainty_ts"]:
                     self.num_cam_iters = c["iters"] * 2
@@ -208,7 +212,7 @@ class Tracker:
                 else:
                     self.num_cam_iters = c["iters"]
                     s.m_iters, s.tracking_back = s.cfg["mapping"]["iters"], False
-        return cam_pose_to_matrix(cand.reshape(1, 7))[0]
+        return cam_pose_to_matrix(self.step.best_pose.reshape(1, 7))[0]
 
 
 class SLAM:

@@ -66,9 +66,18 @@ class TrackStep:
 
     def refresh_parameters(self):
         """call after the mapper changed the decoders (Tracker.update_params_from_mapping, Tracker.py:246-269)"""
-        self._ps, self._pc = self._decoder_params()
+        # into buffers that keep their addresses (a captured iteration holds them): packed copies are refreshed in place, views of
+        # live parameters (tcnn-layout decoders, a learnable beta) are already the parameters themselves
+        def keep(name, new):
+            old = getattr(self, name, None)
+            if old is not None and old.shape == new.shape and old.data_ptr() != new.data_ptr():
+                old.copy_(new)
+            else:
+                setattr(self, name, new)
+        ps, pc = self._decoder_params()
+        keep("_ps", ps); keep("_pc", pc)
         b = self.dec.beta
-        self._beta = L.f32(b.detach()).reshape(1) if torch.is_tensor(b) else torch.tensor([float(b)], device=self.device)
+        keep("_beta", L.f32(b.detach()).reshape(1) if torch.is_tensor(b) else torch.tensor([float(b)], device=self.device))
 
     def forward_backward(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None):
         """render the rays, evaluate the tracking loss, return (loss[1], g_rays_o[R,3], g_rays_d[R,3], pixel_unc[R], valid[R])"""
@@ -91,7 +100,7 @@ class TrackStep:
         seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self.rng_calls) & (2 ** 64 - 1)
         L.check(lib.us_sample_points(P(o), P(d), P(gd), self.bhost, R, P(self.t_uni), self.n_strat, P(self.t_surf), self.n_imp,
                                      ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
-                                     P(self.pstep) if hasattr(self, "pstep") else None, 1 if self.perturb else 0, 1, P(self.valid),
+                                     P(self.draw_ctr) if hasattr(self, "draw_ctr") else None, 1 if self.perturb else 0, 1, P(self.valid),
                                      P(self.z), P(self.pts), st), "us_sample_points")
         # level-major feature planes (flags 3 = clamp + level-major); no dy_dx is stored: the pose gradient re-gathers.  Both tables in
         # one launch where the pair of grids qualifies (positions and cells computed once, one launch less in a latency-bound chain)
@@ -200,7 +209,10 @@ class TrackStep:
             f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
             self.pose, self.g_pose, self.pm, self.pv, self.pstep = f(7), f(7), f(7), f(7), f(1)
             self.img_d, self.img_c = torch.empty((H, W), device=dev), torch.empty((H, W, 3), device=dev)
+        if not hasattr(self, "min_loss"):
+            self.min_loss, self.best_pose, self.mean_unc, self.draw_ctr = (torch.zeros(k, dtype=torch.float32, device=dev) for k in (1, 7, 1, 1))
         self.pose.copy_(pose7.detach().reshape(7))
+        self.min_loss.fill_(float("inf")); self.best_pose.copy_(self.pose)     # the loop's candidate (Tracker.py:331,346-348)
         self.img_d.copy_(gt_depth.reshape(H, W)); self.img_c.copy_(gt_color.reshape(H, W, 3))
         self.pm.zero_(); self.pv.zero_(); self.pstep.zero_()
         self.lr_T, self.lr_R, self.betas = float(lr_T), float(lr_R), betas
@@ -211,7 +223,10 @@ class TrackStep:
     def iterate_fused(self, batch_size, t_rand=None, indices=None):
         """
         One Tracker.optimize_tracking call (Tracker.py:149-244) with everything on the device.  Returns (loss[1], pixel_unc[R],
-        valid[R]); the updated pose is self.pose.  Where the model qualifies (two F = 2 grids of one geometry, a decoder pair, the
+        valid[R]); the updated pose is self.pose.  The loop's minimum-loss bookkeeping (Tracker.py:346-348) rides on the pose step's
+        launch (us_pose_track_step): self.min_loss[1] / self.best_pose[7] (reset by begin_frame) take this iteration's loss and the pose
+        it was rendered at where the loss is the lowest so far.  The in-kernel pixel draw is keyed to self.draw_ctr, a device counter
+        that the same launch advances and that is NOT reset per frame (the optimiser's own count is).  Where the model qualifies (two F = 2 grids of one geometry, a decoder pair, the
         'original' mask, <= 8192 rays of <= 128 samples) the iteration is NINE launches:
             us_track_sample              pixel draw (indices None) + pose -> rays + pre-filter + z + points
             us_hashgrid_fwd_joint_dydx   both encoders + d(features)/d(position)
@@ -220,7 +235,7 @@ class TrackStep:
             us_track_loss_bwd            loss gradients + compositing backward
             us_mlp_bwd_pair_dydx         both decoders' input gradients, contracted in registers with dy/dx: dL/d(points) per grid
             us_ray_points_bwd2           the two shares added and reduced to dL/d(rays_o), dL/d(rays_d)
-            us_pose_window_step          pose gradient + Adam on the 7 numbers (step count included)
+            us_pose_track_step           pose gradient + Adam on the 7 numbers (step count included) + minimum-loss candidate
         otherwise the general chain (us_pose_rays + forward_backward + the pose step).
         """
         lib, st, P = L.lib(), L.stream(), L.ptr
@@ -246,9 +261,9 @@ class TrackStep:
             L.check(lib.us_pose_rays(P(self.pose), P(indices.contiguous()), n, self.intr, W0, H0, W1 - W0, P(self.img_d), P(self.img_c), W,
                                      P(self.t_ro), P(self.t_rd), P(self.t_dirs), P(self.t_gd), P(self.t_gc), st), "us_pose_rays")
             loss, g_o, g_d, unc, valid = self.forward_backward(self.t_ro, self.t_rd, self.t_gd, self.t_gc, t_rand)
-            L.check(lib.us_pose_window_step(P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv),
-                                            P(self.g_pose), self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st),
-                    "us_pose_window_step")
+            L.check(lib.us_pose_track_step(P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.pm), P(self.pv), P(self.g_pose),
+                                           self.lr_R, self.lr_T, b1, b2, 1e-8, P(self.pstep), P(loss), P(self.min_loss), P(self.best_pose),
+                                           P(self.draw_ctr), st), "us_pose_track_step")
             return loss, unc, valid
         self._track_inputs(n)
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
@@ -261,7 +276,7 @@ class TrackStep:
         T("us_track_sample", lambda: lib.us_track_sample(
             P(self.pose), pix, n, self.intr, W0, H0, W1 - W0, H1 - H0, P(self.img_d), P(self.img_c), W, self.bhost, P(self.t_uni), self.n_strat,
             P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
-            P(self.pstep), 1 if self.perturb else 0, None, None, P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st))
+            P(self.draw_ctr), 1 if self.perturb else 0, None, None, P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st))
         if self.dydx_s is None:
             self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
             self.dydx_c = torch.empty_like(self.dydx_s)
@@ -284,10 +299,16 @@ class TrackStep:
             ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4,
             P(self.d_raw), 4, N, None, None, None, None, 1, None, None, 0, P(self.dydx_s), P(self.dydx_c), P(self.dpts_s), P(self.dpts_c), st))
         T("us_ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, n, S, P(self.g_o), P(self.g_d), st))
-        T("us_pose_window_step", lambda: lib.us_pose_window_step(
-            P(self.pose), 1, P(self.g_o), P(self.g_d), P(self.t_dirs), 0, n, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose), self.lr_R, self.lr_T,
-            b1, b2, 1e-8, P(self.pstep), L.US_POSE_OWN_STEP, st))
+        T("us_pose_track_step", lambda: lib.us_pose_track_step(
+            P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.pm), P(self.pv), P(self.g_pose), self.lr_R, self.lr_T,
+            b1, b2, 1e-8, P(self.pstep), P(self.loss), P(self.min_loss), P(self.best_pose), P(self.draw_ctr), st))
         return self.loss, self.unc[:n], self.valid[:n]
+
+    def mean_uncertainty(self, unc, valid):
+        """mean pixel uncertainty of the rays that passed the pre-filter (Tracker.py:353, `rendered_weights.detach().mean()`): one launch,
+        the result stays on the device (self.mean_unc[1])"""
+        L.check(L.lib().us_masked_mean(L.ptr(L.f32(unc)), L.ptr(valid), unc.shape[0], L.ptr(self.mean_unc), L.stream()), "us_masked_mean")
+        return self.mean_unc
 
     def _timed(self, name, rc_fn):
         """run one C-ABI launch; with self.probe (a dict) set, bracket it with HIP events on the launch stream (bench.py)"""
