@@ -275,7 +275,8 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
         torch.cuda.synchronize()
         kern = {k: _median([a.elapsed_time(b) for a, b in v]) for k, v in ts.probe.items()}
         ts.probe = None
-        out["launches_per_iteration"] = len(kern)
+        out["c_abi_calls_per_iteration"] = len(kern)
+        out["launches_per_iteration"] = len(kern) + (1 if "us_track_loss_fwd" in kern else 0)     # us_track_loss_fwd is two kernels
         out["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
         N = 2000 * 40
         enc = "us_hashgrid_fwd_joint_dydx"
@@ -287,6 +288,57 @@ def tracking_bench(us, es, ec, dec, bound, dev, iters=200):
                                "note": "gather bytes only; the launch also writes 2 x 24 B per point and level of dy/dx for the pose gradient"}
     except Exception as e:                                # report, do not hide
         out["fused_error"] = repr(e)[:300]
+    return out
+
+
+def slam_bench(us, dev, hidden, prec, n_frames=30):
+    """
+    secondary number: what a FRAME costs through the drivers (unislam_amd.slam: Tracker.track_frame / Mapper.map_frame, after
+    src/Tracker.py:271-370 and src/Mapper.py:461-545) at Replica's settings -- 680 x 1200 frames, 2000 rays x 8 tracking iterations per
+    frame, 4000 rays x 15 mapping iterations every fourth frame over the keyframe window (joint_opt from the fifth keyframe), tables
+    2^16 / 2^19 at 1 cm -- on the synthetic room (unislam_amd.synthetic; frames rendered ahead).  Wall time with a device
+    synchronisation around every call; medians over the frames after the window has filled.
+    """
+    from unislam_amd.synthetic import SyntheticRoom
+    from unislam_amd.slam import SLAM
+    out = {"workload": f"{n_frames} frames 680x1200 of the synthetic room, Replica settings (tracking 2000 x 8, mapping 4000 x 15 every 4th frame, "
+                       "joint_opt, tables 2^16 / 2^19 at 1 cm), drivers of unislam_amd.slam"}
+    try:
+        torch.manual_seed(0)
+        frames = SyntheticRoom(n_frames=n_frames, H=CAM["H"], W=CAM["W"], device=dev)
+        for i in range(n_frames):
+            frames[i]
+        bound = load_bound([[-0.5, 6.5], [-1.1, 3.5], [-1.7, 1.5]]).to(dev)
+        pls = per_level_scale(int((bound[:, 1] - bound[:, 0]).max() / 0.01))
+        mk = lambda l2: us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2,
+                                                "base_resolution": 16, "per_level_scale": pls}).to(dev)
+        cfg = {"rendering": {"perturb": True, "n_stratified": 32, "n_importance": 8}, "scale": 1, "grid_mode": "hash_grid",
+               "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
+        dec = us.Decoders(cfg, c_dim=32, hidden_size=hidden, truncation=0.06, n_blocks=2).to(dev)
+        dec.bound = bound
+        slam = SLAM(frames, (frames.H, frames.W, frames.fx, frames.fy, frames.cx, frames.cy), mk(16), mk(19), dec, bound,
+                    cfg={"mapping": dict(iters_first=100)})
+        t_track, t_map = [], []
+
+        def timed(fn, sink):
+            def f(*a, **k):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r = fn(*a, **k)
+                torch.cuda.synchronize(); sink.append(1e3 * (time.perf_counter() - t0))
+                return r
+            return f
+
+        slam.tracker.track_frame = timed(slam.tracker.track_frame, t_track)
+        slam.mapper.map_frame = timed(slam.mapper.map_frame, t_map)
+        slam.run()
+        every = slam.cfg["mapping"]["every_frame"]
+        tr, mp = _median(t_track[len(t_track) // 2:]), _median(t_map[len(t_map) // 2:])
+        out.update({"tracking_ms_per_frame": tr, "mapping_ms_per_mapped_frame": mp, "mapped_every": every,
+                    "steady_state_ms_per_frame": tr + mp / every, "steady_state_frames_per_s": 1e3 / (tr + mp / every),
+                    "ate_rmse_cm": 100 * slam.ate_rmse(), "keyframes": len(slam.mapper.keyframe_list), "joint_opt": bool(slam.mapper.joint_opt),
+                    "tracking_ms_all": [round(x, 2) for x in t_track], "mapping_ms_all": [round(x, 1) for x in t_map]})
+    except Exception as e:                                # report, do not hide
+        out["error"] = repr(e)[:300]
     return out
 
 
@@ -535,6 +587,8 @@ def run_rank(args):
             rec["joint_opt"] = joint_opt_bench(us, lambda: build_step(args.mlp_precision), bound, dev, args.steps, args.warmup)
         if world == 1 and not args.no_tracking:
             rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
+        if world == 1 and not args.no_tracking and not args.no_extras:
+            rec["slam_frame"] = slam_bench(us, dev, args.hidden, args.mlp_precision)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(bound, n_strat, n_imp, args.hidden, R)
         print(json.dumps(rec), flush=True)
