@@ -177,7 +177,7 @@ class Tracker:
                               c["w"], mask_mode=slam.cfg["t_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"])
         self.num_cam_iters = c["iters"]
         self.rendered_weight = {}
-        self._graph = None
+        self._graphs = {}
 
     def track_frame(self, idx, color, depth):
         s, c, dev = self.s, self.c, self.s.device
@@ -192,17 +192,35 @@ class Tracker:
         begin()
         # The iteration is nine short launches: issued one by one from Python the loop is host-bound (2.2 ms per frame at Replica's
         # settings for 1.1 ms of kernels).  Every buffer of TrackStep is static, the pixel draw and the jitter happen in the kernels,
-        # and the optimiser's state lives on the device, so ONE captured graph serves every iteration of every frame.
-        if c.get("graph_replay", True) and self._graph is None:
-            from .graph import CapturedIteration
-            self.step.iterate_fused(c["pixels"])                                        # eager once: lazy buffers, then the frame's state again
-            begin()
-            self._graph = CapturedIteration(lambda: self.step.iterate_fused(c["pixels"]), warmup=0)
+        # and the optimiser's state lives on the device, so captured graphs serve every frame: one graph per RUN LENGTH -- the k
+        # iterations up to the loop's one host decision (7, or 8 / 15 while tracking back) in one launch, single iterations behind it.
+        replay = bool(c.get("graph_replay", True))
+        n_pix = c["pixels"]
+
+        def run(k):
+            if not replay:
+                for _ in range(k):
+                    out = self.step.iterate_fused(n_pix)
+                return out
+            if k not in self._graphs:
+                from .graph import CapturedIteration
+                if not self._graphs:
+                    self.step.iterate_fused(n_pix)                                      # eager once: lazy buffers, then the frame's state again
+                    begin()
+
+                def body():
+                    for _ in range(k):
+                        out = self.step.iterate_fused(n_pix)
+                    return out
+                self._graphs[k] = CapturedIteration(body, warmup=0)                     # (a capture records, it does not execute)
+            return self._graphs[k].replay()
+
         it = 0
         while it < self.num_cam_iters:                                                  # re-read: the count may double mid-frame
             # the minimum-loss candidate (:346-348) is kept by the pose step's launch: step.min_loss / step.best_pose, on the device
-            loss, unc, valid = self._graph.replay() if self._graph is not None else self.step.iterate_fused(c["pixels"])
-            it += 1
+            k = max(self.num_cam_iters - 1 - it, 1)                                     # iterations up to the check of :352, or one behind it
+            loss, unc, valid = run(k)
+            it += k
             if it == self.num_cam_iters - 1:                                            # (:352-364)
                 w = self.step.mean_uncertainty(unc, valid).clone()
                 self.rendered_weight[idx] = w
