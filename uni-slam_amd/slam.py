@@ -178,6 +178,7 @@ class Tracker:
         self.num_cam_iters = c["iters"]
         self.rendered_weight = {}
         self._graphs = {}
+        self.params_stale = True                                                        # set by SLAM.run after every mapping pass
 
     def track_frame(self, idx, color, depth):
         s, c, dev = self.s, self.c, self.s.device
@@ -188,8 +189,9 @@ class Tracker:
         else:
             cam_pose = matrix_to_cam_pose(pre_c2w.unsqueeze(0))
         begin = lambda: self.step.begin_frame(cam_pose[0], color, depth, c["lr_T"], c["lr_R"], H, W, fx, fy, cx, cy, c["ignore_edge_H"],
-                                              c["ignore_edge_W"], betas=(0.5, 0.999))
-        begin()
+                                              c["ignore_edge_W"], betas=(0.5, 0.999), refresh=self.params_stale)
+        begin()                                                                         # (update_params_from_mapping, :302: after a mapping pass)
+        self.params_stale = False
         # The iteration is nine short launches: issued one by one from Python the loop is host-bound (2.2 ms per frame at Replica's
         # settings for 1.1 ms of kernels).  Every buffer of TrackStep is static, the pixel draw and the jitter happen in the kernels,
         # and the optimiser's state lives on the device, so captured graphs serve every frame: one graph per RUN LENGTH -- the k
@@ -269,6 +271,7 @@ class SLAM:
                 self.estimate_c2w_list[idx] = self.tracker.track_frame(idx, color, depth)
             if idx % every == 0 or self.tracking_back or idx == n - 1:                  # Mapper.py:487-493
                 self.mapper.map_frame(idx, color, depth, gt_c2w, rays_d)
+                self.tracker.params_stale = True
             if log is not None:
                 log(idx, self)
         return self.estimate_c2w_list[:n]

@@ -198,11 +198,12 @@ class TrackStep:
 
     # ------------------------------------------------------------------------------------------ fully fused tracking
     def begin_frame(self, pose7, gt_color, gt_depth, lr_T, lr_R, H, W, fx, fy, cx, cy, ignore_edge_H, ignore_edge_W,
-                    betas=(0.5, 0.999)):
+                    betas=(0.5, 0.999), refresh=True):
         """
         Per-frame set-up of the fused tracking loop (Tracker.py:315-329): pose7 = (quaternion[4], translation[3]) initial
         guess, gt_color [H,W,3], gt_depth [H,W]; a fresh Adam state for the two parameter groups (lr_R for the quaternion,
-        lr_T for the translation).  The buffers are static, so iterate_fused() can be captured into a hipGraph.
+        lr_T for the translation).  The buffers are static, so iterate_fused() can be captured into a hipGraph.  refresh: re-read the
+        decoders' parameters (Tracker.update_params_from_mapping, Tracker.py:246-269).
         """
         dev = self.device
         if not hasattr(self, "pose"):
@@ -218,7 +219,8 @@ class TrackStep:
         self.lr_T, self.lr_R, self.betas = float(lr_T), float(lr_R), betas
         self.frame = (H, W, ignore_edge_H, ignore_edge_W)
         self.intr = L.host_floats([fx, fy, cx, cy])
-        self.refresh_parameters()
+        if refresh or not hasattr(self, "_ps"):                  # refresh=False: the caller knows the decoders have not changed since
+            self.refresh_parameters()
 
     def iterate_fused(self, batch_size, t_rand=None, indices=None):
         """
