@@ -10,7 +10,7 @@
 //                 and one stage position per record pair; the bin's record region holds its A records, then its B records.
 //   SPLIT levels  one grid dense, the other hashed (room0: levels 4-6): unrelated entries, each grid has its own bins.
 // Everything per (point, level) that does not depend on the table -- cell, keys, run masks, weights, the run scan's bookkeeping -- is
-// computed once for both grids; records stay the 12-byte {local entry, d0, d1} of hashgrid_binned.hip, one stream per grid.
+// computed once for both grids; records are 10 bytes (16-bit local entry, d0, d1) in two planes per (bin, grid) region (below).
 //   k_jfwd<gather,count>  encoder for both tables (one thread per point and level, blockIdx.y = level) that also leaves the binning
 //                         counts, one row of records-per-bin per 512 points;
 //   k_jcolscan, k_jscan   column scan over the rows, exclusive scan of the bin totals;
@@ -51,6 +51,19 @@
 #define J_WANT_MAX 8
 
 enum { J_HASHED_A = 1, J_HASHED_B = 2, J_PACKABLE = 4, J_SPLIT = 8 };
+
+// RECORDS: 10 bytes each, as two planes per (bin, grid) region -- the local entries as 16-bit numbers (< 2^11: J_ACC_DOUBLES / 2 entries per
+// bin), then the value pairs; both parts start at multiples of 16 bytes, so the accumulate pass reads a PAIR of records as one aligned
+// 4-byte load (two entries) + one aligned 16-byte load (four values), consecutive lanes consecutive pairs.  The pass is bound by its
+// record stream (timing builds, MI355X, one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us):
+// 12-byte {entry, d0, d1} records 102.5 us, this layout 88.7 (same box); the same 10 bytes as 5-dword units of two records -- one
+// unaligned 16-byte load + a 4-byte load over the same lines -- took 104: the shape of the loads counts, not only their bytes.  The
+// record pass writes a 2-byte and an 8-byte store per record instead of one 12-byte store, at no cost (125.7 against 125.2 us).
+// A joint bin holds its A region, then its B region.
+// SoA region of c records of one grid: [entries: c x u16, padded to 4 dwords][values: c x 2 dwords], size padded to 4 dwords
+__host__ __device__ __forceinline__ uint32_t j_region_ce(uint32_t c) { return (((c + 1u) >> 1) + 3u) & ~3u; }
+__host__ __device__ __forceinline__ uint32_t j_region_dw(uint32_t c) { return (j_region_ce(c) + 2u * c + 3u) & ~3u; }
+static_assert(J_ACC_DOUBLES / 2 <= 65536 && J_LVL_BINS <= 65536, "local entry and bin of the level in 16 bits each");
 
 struct JLevel {
     float    scale;
@@ -349,8 +362,8 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
     }
 }
 
-// exclusive scans of totals[0..TB): rec_off (records per grid) and dw_off (dwords: a joint bin holds its A records, then its B
-// records: 6 dwords per count; a single-grid bin 3), and the list of extra chunks of hot bins (as k_bin_scan).  8 elements per
+// exclusive scans of totals[0..TB): rec_off (records per grid) and dw_off (dwords: a joint bin holds its A region, then its B
+// region, j_region_dw(count) each; a single-grid bin one), and the list of extra chunks of hot bins (as k_bin_scan).  8 elements per
 // thread; wave scans + one fix-up over the 16 wave totals (two barriers).
 struct JSingle { uint32_t lo[J_MAX_LEVELS], len[J_MAX_LEVELS]; };     // bin ranges of the split levels (bins that serve one grid only)
 __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __restrict__ totals, uint32_t TB,
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
     __shared__ uint32_t ws[3][16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     constexpr int E = J_MAX_BINS / 1024;
-    uint32_t c[E], dwn[E], s = 0, d = 0, xs = 0;
+    uint32_t c[E], dwn[E], s = 0, d = 0, xs = 0;                 // dwn: dwords of the bin's region(s)
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const uint32_t b = E * t + k;
@@ -368,8 +381,8 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
         bool single = false;
 #pragma unroll
         for (int l = 0; l < J_MAX_LEVELS; ++l) single |= (b - sg.lo[l]) < sg.len[l];
-        dwn[k] = b < TB ? (single ? 3u : 6u) : 0u;
-        s += c[k]; d += c[k] * dwn[k]; xs += c[k] > chunk0 ? (c[k] - 1u) / chunk0 : 0u;
+        dwn[k] = b < TB ? (single ? 1u : 2u) * j_region_dw(c[k]) : 0u;
+        s += c[k]; d += dwn[k]; xs += c[k] > chunk0 ? (c[k] - 1u) / chunk0 : 0u;
     }
     auto block_scan = [&](uint32_t v, int slot, uint32_t& total) {    // inclusive scan over the 1024 threads
         uint32_t incl = v;
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
     for (int k = 0; k < E; ++k) {
         const uint32_t b = E * t + k;
         if (b < TB) { rec_off[b] = run; dw_off[b] = drun; }
-        run += c[k]; drun += c[k] * dwn[k];
+        run += c[k]; drun += dwn[k];
         const uint32_t nx = c[k] > chunk ? (c[k] - 1u) / chunk : 0u;
         for (uint32_t j = 0; j < nx; ++j) extra[xrun + j] = b | ((j + 1u) << 16);
         xrun += nx;
@@ -417,10 +430,13 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
                                                             uint32_t row_stride, uint32_t* __restrict__ rec, uint32_t rec_cap_dw,
                                                             int64_t plane_stride) {
-    __shared__ uint4 st4[J_STAGE];                               // {local entry, d0, d1, address of the record in dwords}: 64 KiB
+    __shared__ uint2 stxy[J_STAGE];                              // stage: {local entry | bin of the level << 16, d0}
+    __shared__ uint32_t stz[J_STAGE];                            //        d1                                       (48 KiB together)
     __shared__ uint32_t cur[2][J_LVL_BINS];                      // [level parity][bin of the level]: stage cursor
-    __shared__ uint32_t gdl[2][J_LVL_BINS];                      // address of a record (dwords) = cursor * 3 + gdl
-    __shared__ uint32_t gdb[2][J_LVL_BINS];                      // joint bins: the same for the B record
+    __shared__ uint32_t gro[2][J_LVL_BINS];                      // record index inside the bin's region = cursor + gro
+    __shared__ uint32_t goa[2][J_LVL_BINS];                      // first dword of the bin's (A) region
+    __shared__ uint32_t gob[2][J_LVL_BINS];                      // joint bins: first dword of the B region
+    __shared__ uint32_t gce[2][J_LVL_BINS];                      // dwords of the region's entry part
     __shared__ uint32_t wtot[2][J_ROW_POINTS / 64];
     __shared__ uint32_t atot[2], ttot[2];                        // [parity]: records of the A bins (split level) / of all bins
     const uint32_t tid = threadIdx.x;
@@ -461,8 +477,10 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         const uint32_t excl = before + incl - c;
         if (tid < nlb) {
             cur[par][tid] = excl;
-            gdl[par][tid] = o + (p - excl) * 3u;                 // record address = o + (p + (cursor - excl)) * 3
-            gdb[par][tid] = o + (tt + p - excl) * 3u;            // joint bin: the B records follow the bin's tt A records
+            gro[par][tid] = p - excl;                            // record index = p + (cursor - excl)
+            goa[par][tid] = o;
+            gob[par][tid] = o + j_region_dw(tt);                 // joint bin: the B region follows the region of the bin's tt A records
+            gce[par][tid] = j_region_ce(tt);
         }
         if (split && tid == (1u << q.lgA)) atot[par] = excl;
         if (tid == nlb - 1u) ttot[par] = excl + c;
@@ -511,23 +529,30 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 setup_scan(par ^ 1, c1, incl1);
             }
         };
-        // stage entry: {local entry, d0, d1, bin of the level}; its position k in the stage is its cursor value (minus `sb`), and the
-        // record's address follows at copy-out: gd[bin] + (k + sb) * 3
-        auto copy_out = [&](uint32_t cnt, const uint32_t* gd, uint32_t sb, uint32_t emask) {
-            auto put = [&](const uint4 a, uint32_t k) {
-                const uint32_t addr = gd[a.w & (J_LVL_BINS - 1u)] + (k + sb) * 3u;
-                if (addr + 3u <= rec_cap_dw) {
-                    typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-                    u32x3 w; w.x = a.x & emask; w.y = a.y; w.z = a.z;
-                    *reinterpret_cast<u32x3*>(rec + addr) = w;
+        // stage entry: {local entry | bin of the level << 16, d0, d1}; its position k in the stage is its cursor value (minus `sb`); at
+        // copy-out it becomes record r = gro[bin] + k + sb of the bin's region: a 2-byte store into the entry plane and an 8-byte store
+        // into the value plane
+        auto stage_put = [&](uint32_t k, uint32_t loc, float d0, float d1, uint32_t bin) {
+            stxy[k] = make_uint2(loc | (bin << 16), __float_as_uint(d0)); stz[k] = __float_as_uint(d1);
+        };
+        auto copy_out = [&](uint32_t cnt, const uint32_t* go, uint32_t sb, uint32_t emask) {
+            auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
+                const uint32_t bin = a.x >> 16, r = gro[par][bin] + k + sb;
+                const uint32_t base = go[bin], va = base + gce[par][bin] + 2u * r;
+                if (va + 2u <= rec_cap_dw) {
+                    reinterpret_cast<uint16_t*>(rec + base)[r] = (uint16_t)(a.x & emask);
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(8)));
+                    u32x2 w; w.x = a.y; w.y = z;
+                    *reinterpret_cast<u32x2*>(rec + va) = w;
                 }
             };
             uint32_t k = tid;
             for (; k + J_ROW_POINTS < cnt; k += 2 * J_ROW_POINTS) {
-                const uint4 a0 = st4[k], a1 = st4[k + J_ROW_POINTS];
-                put(a0, k); put(a1, k + J_ROW_POINTS);
+                const uint2 a0 = stxy[k], a1 = stxy[k + J_ROW_POINTS];
+                const uint32_t z0 = stz[k], z1 = stz[k + J_ROW_POINTS];
+                put(a0, z0, k); put(a1, z1, k + J_ROW_POINTS);
             }
-            if (k < cnt) put(st4[k], k);
+            if (k < cnt) put(stxy[k], stz[k], k);
         };
         lds_barrier();                                           // the previous level's copy-out has left the stage; cursors are in place
         if (!split) {
@@ -546,26 +571,23 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (k8[c] < J_STAGE)
-                        st4[k8[c]] = make_uint4(local_of(e[c], lg), __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), (e[c] >> BIN_LINE_LOG2) & nbm);
+                        stage_put(k8[c], local_of(e[c], lg), val[c][0], val[c][1], (e[c] >> BIN_LINE_LOG2) & nbm);
                 }
             }
             consume_next();
             lds_barrier();
             const uint32_t cnt = min(ttot[par], (uint32_t)J_STAGE);
-            copy_out(cnt, gdl[par], 0u, q.maskA);
+            copy_out(cnt, goa[par], 0u, q.maskA & 0xFFFFu);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
             lds_barrier();
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if (k8[c] < J_STAGE) {
-                    uint32_t* w = reinterpret_cast<uint32_t*>(&st4[k8[c]]);
-                    w[1] = __float_as_uint(val[c][0]); w[2] = __float_as_uint(val[c][1]);
-                }
+                if (k8[c] < J_STAGE) { stxy[k8[c]].y = __float_as_uint(val[c][0]); stz[k8[c]] = __float_as_uint(val[c][1]); }
             }
             lds_barrier();
-            copy_out(cnt, gdb[par], 0u, 0xFFFFFFFFu);
+            copy_out(cnt, gob[par], 0u, 0xFFFFu);
         } else {
             const uint32_t nbA = 1u << q.lgA, mA = nbA - 1u, mB = (1u << q.lgB) - 1u;
             {                                                    // table A: bins [0, nbA) of the level, stage index = cursor
@@ -580,13 +602,13 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (((tail >> c) & 1u) && k8[c] < J_STAGE)
-                        st4[k8[c]] = make_uint4(local_of(e[c], q.lgA), __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), (e[c] >> BIN_LINE_LOG2) & mA);
+                        stage_put(k8[c], local_of(e[c], q.lgA), val[c][0], val[c][1], (e[c] >> BIN_LINE_LOG2) & mA);
                 }
             }
             consume_next();
             lds_barrier();
             const uint32_t na = min(atot[par], (uint32_t)J_STAGE);
-            copy_out(na, gdl[par], 0u, 0xFFFFFFFFu);
+            copy_out(na, goa[par], 0u, 0xFFFFu);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -604,11 +626,11 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (((tail >> c) & 1u) && k8[c] - sb < J_STAGE)
-                        st4[k8[c] - sb] = make_uint4(local_of(e[c], q.lgB), __float_as_uint(val[c][0]), __float_as_uint(val[c][1]), nbA + ((e[c] >> BIN_LINE_LOG2) & mB));
+                        stage_put(k8[c] - sb, local_of(e[c], q.lgB), val[c][0], val[c][1], nbA + ((e[c] >> BIN_LINE_LOG2) & mB));
                 }
             }
             lds_barrier();
-            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gdl[par], sb, 0xFFFFFFFFu);
+            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), goa[par], sb, 0xFFFFu);
         }
     }
 }
@@ -627,11 +649,11 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
-enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_VOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
 
 template <int BUF> struct JBufTag { static constexpr int value = BUF; };
 
-__global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
+__global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
                                                             const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
                                                             const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
                                                             const uint32_t* __restrict__ rec, float* __restrict__ gradA,
@@ -668,8 +690,8 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
         if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
         const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
         const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
-        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? cnt * 3u : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
-                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff};
+        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region_dw(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
+                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff, j_region_ce(cnt)};
         const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
         if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
 #pragma unroll
@@ -682,21 +704,23 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
     __syncthreads();
     const uint32_t n = n_items, nz = n_zitems;
     auto field = [&](int f, uint32_t k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)items[f][k]); };
-    constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL;
+    constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL * 2;  // records per batch: every thread takes J_ACC_UNROLL pairs
     constexpr int EPT = J_ACC_DOUBLES / 2 / J_ACC_THREADS;       // entries per thread in the sweep
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-    u32x3 w3[2][J_ACC_UNROLL];
-    // ---- the request side of the pipeline: item fk, records from fa on
-    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
-    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(16)));
+    uint32_t we[2][J_ACC_UNROLL];                                // a pair's two local entries
+    u32x4 wv[2][J_ACC_UNROLL];                                   // ... and its four values
+    // ---- the request side of the pipeline: item fk, records from fa on (fa is even: chunks of hot bins start at multiples of hdr[1])
+    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0, f_voff = 0;
+    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); f_voff = field(JI_VOFF, fk); } };
     auto fetch = [&](auto tag) {                                 // every load unconditional (the compiler closes a conditional block with
         constexpr int buf = decltype(tag)::value;                // s_waitcnt vmcnt(0): ONE record in flight per thread): past the end of an
-                                                                 // item, and past the last item of the workgroup, it re-reads the last record
+                                                                 // item, and past the last item of the workgroup, it re-reads the last pair
         const uint32_t* base = rec + (size_t)f_base;
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
-            const uint32_t r = min(fa + u * J_ACC_THREADS + tid, f_c1 - 1u);
-            w3[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(base + (size_t)r * 3u));
+            const uint32_t q = min((fa >> 1) + u * J_ACC_THREADS + tid, (f_c1 - 1u) >> 1);
+            we[buf][u] = __builtin_nontemporal_load(base + q);                                                   // two 16-bit entries
+            wv[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + f_voff + (size_t)q * 4u));     // their four values
         }
         fa += STEP;
         if (fa >= f_c1) { ++fk; f_load(); }
@@ -746,12 +770,15 @@ __global__ __launch_bounds__(J_ACC_THREADS) void k_jaccum_p(JLevels lv, uint32_t
         fetch(other);
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
-            if (a + u * J_ACC_THREADS + tid < c1) {
-                const uint32_t lc = w3[buf][u].x;
-                if (lc < nl) {
-                    atomicAdd(&my[lc], (double)__uint_as_float(w3[buf][u].y));                    // ds_add_f64
-                    atomicAdd(&my[nl + lc], (double)__uint_as_float(w3[buf][u].z));
-                }
+            const uint32_t r0 = a + 2u * (u * J_ACC_THREADS + tid);
+            const uint32_t l0 = we[buf][u] & 0xFFFFu, l1 = we[buf][u] >> 16;
+            if (r0 < c1 && l0 < nl) {
+                atomicAdd(&my[l0], (double)__uint_as_float(wv[buf][u].x));                        // ds_add_f64
+                atomicAdd(&my[nl + l0], (double)__uint_as_float(wv[buf][u].y));
+            }
+            if (r0 + 1u < c1 && l1 < nl) {
+                atomicAdd(&my[l1], (double)__uint_as_float(wv[buf][u].z));
+                atomicAdd(&my[nl + l1], (double)__uint_as_float(wv[buf][u].w));
             }
         }
         a += STEP;
@@ -792,7 +819,8 @@ static size_t j_header_bytes(int TB, int64_t n) {
     const size_t rows = (size_t)us_cdiv(n, J_ROW_POINTS);
     return (size_t)(3 * (J_MAX_BINS + 64) + 16 + ACC_EXTRA_MAX) * sizeof(uint32_t) + 2 * rows * j_row_stride(TB) * sizeof(uint32_t);
 }
-static uint64_t j_record_dwords(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 6ull; }   // both grids, 3 dwords each
+// both grids: 2.5 dwords per record, and both planes of every (bin, grid) region are padded to 4 dwords
+static uint64_t j_record_dwords(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 5ull + 24ull * J_MAX_BINS; }
 
 extern "C" int us_hashgrid_joint_supported(const us_grid_desc* a, const us_grid_desc* b, int64_t n) {
     JLevels lv;
