@@ -52,17 +52,15 @@
 
 enum { J_HASHED_A = 1, J_HASHED_B = 2, J_PACKABLE = 4, J_SPLIT = 8 };
 
-// RECORDS: 10 bytes each, as two planes per (bin, grid) region -- the local entries as 16-bit numbers (< 2^11: J_ACC_DOUBLES / 2 entries per
-// bin), then the value pairs; both parts start at multiples of 16 bytes, so the accumulate pass reads a PAIR of records as one aligned
-// 4-byte load (two entries) + one aligned 16-byte load (four values), consecutive lanes consecutive pairs.  The pass is bound by its
-// record stream (timing builds, MI355X, one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us):
-// 12-byte {entry, d0, d1} records 102.5 us, this layout 88.7 (same box); the same 10 bytes as 5-dword units of two records -- one
-// unaligned 16-byte load + a 4-byte load over the same lines -- took 104: the shape of the loads counts, not only their bytes.  The
-// record pass writes a 2-byte and an 8-byte store per record instead of one 12-byte store, at no cost (125.7 against 125.2 us).
-// A joint bin holds its A region, then its B region.
-// SoA region of c records of one grid: [entries: c x u16, padded to 4 dwords][values: c x 2 dwords], size padded to 4 dwords
-__host__ __device__ __forceinline__ uint32_t j_region_ce(uint32_t c) { return (((c + 1u) >> 1) + 3u) & ~3u; }
-__host__ __device__ __forceinline__ uint32_t j_region_dw(uint32_t c) { return (j_region_ce(c) + 2u * c + 3u) & ~3u; }
+// RECORDS: 10 bytes each, in TWO PLANES over one record index R -- the local entries as 16-bit numbers (< 2^11: J_ACC_DOUBLES / 2 entries
+// per bin) in E[R], the value pairs in V[R].  Every (bin, grid) region starts at a multiple of 8 records, so the accumulate pass reads a
+// PAIR of records as one aligned 4-byte load (two entries) + one aligned 16-byte load (four values), consecutive lanes consecutive pairs,
+// and the record pass derives both addresses of a record from ONE per-bin number.  The accumulate pass is bound by its record stream
+// (timing builds, MI355X, one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us): 12-byte
+// {entry, d0, d1} records 102.5 us, two planes 88.7 (same box); the same 10 bytes as 5-dword units of two records -- one unaligned 16-byte
+// load + a 4-byte load over the same lines -- took 104: the shape of the loads counts, not only their bytes.
+// A region of c records takes j_region(c) record indices; a joint bin holds its A region, then its B region.
+__host__ __device__ __forceinline__ uint32_t j_region(uint32_t c) { return (c + 7u) & ~7u; }
 static_assert(J_ACC_DOUBLES / 2 <= 65536 && J_LVL_BINS <= 65536, "local entry and bin of the level in 16 bits each");
 
 struct JLevel {
@@ -362,8 +360,8 @@ __global__ __launch_bounds__(JCS_THREADS) void k_jcolscan(JLevels lv, uint32_t n
     }
 }
 
-// exclusive scans of totals[0..TB): rec_off (records per grid) and dw_off (dwords: a joint bin holds its A region, then its B
-// region, j_region_dw(count) each; a single-grid bin one), and the list of extra chunks of hot bins (as k_bin_scan).  8 elements per
+// exclusive scans of totals[0..TB): rec_off (records per grid) and dw_off (first record index of the bin in the two planes: a joint bin
+// holds its A region, then its B region, j_region(count) indices each; a single-grid bin one), and the list of extra chunks of hot bins.  8 elements per
 // thread; wave scans + one fix-up over the 16 wave totals (two barriers).
 struct JSingle { uint32_t lo[J_MAX_LEVELS], len[J_MAX_LEVELS]; };     // bin ranges of the split levels (bins that serve one grid only)
 __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __restrict__ totals, uint32_t TB,
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
     __shared__ uint32_t ws[3][16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     constexpr int E = J_MAX_BINS / 1024;
-    uint32_t c[E], dwn[E], s = 0, d = 0, xs = 0;                 // dwn: dwords of the bin's region(s)
+    uint32_t c[E], dwn[E], s = 0, d = 0, xs = 0;                 // dwn: record indices of the bin's region(s)
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const uint32_t b = E * t + k;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
         bool single = false;
 #pragma unroll
         for (int l = 0; l < J_MAX_LEVELS; ++l) single |= (b - sg.lo[l]) < sg.len[l];
-        dwn[k] = b < TB ? (single ? 1u : 2u) * j_region_dw(c[k]) : 0u;
+        dwn[k] = b < TB ? (single ? 1u : 2u) * j_region(c[k]) : 0u;
         s += c[k]; d += dwn[k]; xs += c[k] > chunk0 ? (c[k] - 1u) / chunk0 : 0u;
     }
     auto block_scan = [&](uint32_t v, int slot, uint32_t& total) {    // inclusive scan over the 1024 threads
@@ -428,15 +426,13 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const float* __restrict__ dyA, const float* __restrict__ dyB, int64_t n, int clamp,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
-                                                            uint32_t row_stride, uint32_t* __restrict__ rec, uint32_t rec_cap_dw,
-                                                            int64_t plane_stride) {
+                                                            uint32_t row_stride, uint16_t* __restrict__ rec_e, uint2* __restrict__ rec_v,
+                                                            uint32_t rec_cap, int64_t plane_stride) {
     __shared__ uint2 stxy[J_STAGE];                              // stage: {local entry | bin of the level << 16, d0}
     __shared__ uint32_t stz[J_STAGE];                            //        d1                                       (48 KiB together)
     __shared__ uint32_t cur[2][J_LVL_BINS];                      // [level parity][bin of the level]: stage cursor
-    __shared__ uint32_t gro[2][J_LVL_BINS];                      // record index inside the bin's region = cursor + gro
-    __shared__ uint32_t goa[2][J_LVL_BINS];                      // first dword of the bin's (A) region
-    __shared__ uint32_t gob[2][J_LVL_BINS];                      // joint bins: first dword of the B region
-    __shared__ uint32_t gce[2][J_LVL_BINS];                      // dwords of the region's entry part
+    __shared__ uint32_t gra[2][J_LVL_BINS];                      // record index in the planes = cursor + gra
+    __shared__ uint32_t grb[2][J_LVL_BINS];                      // joint bins: the same for the B record
     __shared__ uint32_t wtot[2][J_ROW_POINTS / 64];
     __shared__ uint32_t atot[2], ttot[2];                        // [parity]: records of the A bins (split level) / of all bins
     const uint32_t tid = threadIdx.x;
@@ -477,10 +473,8 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         const uint32_t excl = before + incl - c;
         if (tid < nlb) {
             cur[par][tid] = excl;
-            gro[par][tid] = p - excl;                            // record index = p + (cursor - excl)
-            goa[par][tid] = o;
-            gob[par][tid] = o + j_region_dw(tt);                 // joint bin: the B region follows the region of the bin's tt A records
-            gce[par][tid] = j_region_ce(tt);
+            gra[par][tid] = o + p - excl;                        // record index = o + p + (cursor - excl)
+            grb[par][tid] = o + j_region(tt) + p - excl;         // joint bin: the B region follows the region of the bin's tt A records
         }
         if (split && tid == (1u << q.lgA)) atot[par] = excl;
         if (tid == nlb - 1u) ttot[par] = excl + c;
@@ -530,20 +524,16 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             }
         };
         // stage entry: {local entry | bin of the level << 16, d0, d1}; its position k in the stage is its cursor value (minus `sb`); at
-        // copy-out it becomes record r = gro[bin] + k + sb of the bin's region: a 2-byte store into the entry plane and an 8-byte store
-        // into the value plane
+        // copy-out it becomes record R = gr[bin] + k + sb: a 2-byte store into the entry plane and an 8-byte store into the value plane
         auto stage_put = [&](uint32_t k, uint32_t loc, float d0, float d1, uint32_t bin) {
             stxy[k] = make_uint2(loc | (bin << 16), __float_as_uint(d0)); stz[k] = __float_as_uint(d1);
         };
-        auto copy_out = [&](uint32_t cnt, const uint32_t* go, uint32_t sb, uint32_t emask) {
+        auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, uint32_t emask) {
             auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
-                const uint32_t bin = a.x >> 16, r = gro[par][bin] + k + sb;
-                const uint32_t base = go[bin], va = base + gce[par][bin] + 2u * r;
-                if (va + 2u <= rec_cap_dw) {
-                    reinterpret_cast<uint16_t*>(rec + base)[r] = (uint16_t)(a.x & emask);
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(8)));
-                    u32x2 w; w.x = a.y; w.y = z;
-                    *reinterpret_cast<u32x2*>(rec + va) = w;
+                const uint32_t R = gr[a.x >> 16] + k + sb;
+                if (R < rec_cap) {
+                    rec_e[R] = (uint16_t)(a.x & emask);
+                    rec_v[R] = make_uint2(a.y, z);
                 }
             };
             uint32_t k = tid;
@@ -577,7 +567,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t cnt = min(ttot[par], (uint32_t)J_STAGE);
-            copy_out(cnt, goa[par], 0u, q.maskA & 0xFFFFu);
+            copy_out(cnt, gra[par], 0u, q.maskA & 0xFFFFu);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -587,7 +577,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 if (k8[c] < J_STAGE) { stxy[k8[c]].y = __float_as_uint(val[c][0]); stz[k8[c]] = __float_as_uint(val[c][1]); }
             }
             lds_barrier();
-            copy_out(cnt, gob[par], 0u, 0xFFFFu);
+            copy_out(cnt, grb[par], 0u, 0xFFFFu);
         } else {
             const uint32_t nbA = 1u << q.lgA, mA = nbA - 1u, mB = (1u << q.lgB) - 1u;
             {                                                    // table A: bins [0, nbA) of the level, stage index = cursor
@@ -608,7 +598,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t na = min(atot[par], (uint32_t)J_STAGE);
-            copy_out(na, goa[par], 0u, 0xFFFFu);
+            copy_out(na, gra[par], 0u, 0xFFFFu);
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -630,7 +620,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 }
             }
             lds_barrier();
-            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), goa[par], sb, 0xFFFFu);
+            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, 0xFFFFu);
         }
     }
 }
@@ -649,14 +639,15 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
-enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_VOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
 
 template <int BUF> struct JBufTag { static constexpr int value = BUF; };
 
 __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
                                                             const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
                                                             const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
-                                                            const uint32_t* __restrict__ rec, float* __restrict__ gradA,
+                                                            const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
+                                                            float* __restrict__ gradA,
                                                             float* __restrict__ gradB, int overwrite, int side_sel) {
     // side_sel: -1 both grids' items; 0 / 1: the items of grid A / B only (the data-parallel step finishes the colour table first, so
     // that its all-reduce travels while the sdf table is summed)
@@ -690,8 +681,8 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
         if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
         const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
         const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
-        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region_dw(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
-                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff, j_region_ce(cnt)};
+        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
+                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff};
         const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
         if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
 #pragma unroll
@@ -707,20 +698,22 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
     constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL * 2;  // records per batch: every thread takes J_ACC_UNROLL pairs
     constexpr int EPT = J_ACC_DOUBLES / 2 / J_ACC_THREADS;       // entries per thread in the sweep
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(16)));
+    const uint32_t* rec_e2 = reinterpret_cast<const uint32_t*>(rec_e);
+    const u32x4* rec_v2 = reinterpret_cast<const u32x4*>(rec_v);
     uint32_t we[2][J_ACC_UNROLL];                                // a pair's two local entries
     u32x4 wv[2][J_ACC_UNROLL];                                   // ... and its four values
     // ---- the request side of the pipeline: item fk, records from fa on (fa is even: chunks of hot bins start at multiples of hdr[1])
-    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0, f_voff = 0;
-    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); f_voff = field(JI_VOFF, fk); } };
+    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
+    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
     auto fetch = [&](auto tag) {                                 // every load unconditional (the compiler closes a conditional block with
         constexpr int buf = decltype(tag)::value;                // s_waitcnt vmcnt(0): ONE record in flight per thread): past the end of an
                                                                  // item, and past the last item of the workgroup, it re-reads the last pair
-        const uint32_t* base = rec + (size_t)f_base;
+        const size_t pair0 = (size_t)(f_base >> 1);              // (regions start at multiples of 8 records)
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
             const uint32_t q = min((fa >> 1) + u * J_ACC_THREADS + tid, (f_c1 - 1u) >> 1);
-            we[buf][u] = __builtin_nontemporal_load(base + q);                                                   // two 16-bit entries
-            wv[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + f_voff + (size_t)q * 4u));     // their four values
+            we[buf][u] = __builtin_nontemporal_load(rec_e2 + pair0 + q);                                         // two 16-bit entries
+            wv[buf][u] = __builtin_nontemporal_load(rec_v2 + pair0 + q);                                         // their four values
         }
         fa += STEP;
         if (fa >= f_c1) { ++fk; f_load(); }
@@ -819,14 +812,15 @@ static size_t j_header_bytes(int TB, int64_t n) {
     const size_t rows = (size_t)us_cdiv(n, J_ROW_POINTS);
     return (size_t)(3 * (J_MAX_BINS + 64) + 16 + ACC_EXTRA_MAX) * sizeof(uint32_t) + 2 * rows * j_row_stride(TB) * sizeof(uint32_t);
 }
-// both grids: 2.5 dwords per record, and both planes of every (bin, grid) region are padded to 4 dwords
-static uint64_t j_record_dwords(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 5ull + 24ull * J_MAX_BINS; }
+// record indices of both grids (every (bin, grid) region padded to 8) and the bytes of the two planes over them
+static uint64_t j_record_cap(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 2ull + 16ull * J_MAX_BINS; }
+static size_t j_record_bytes(uint32_t n_levels, int64_t n) { return (size_t)j_record_cap(n_levels, n) * 10u; }    // (cap is a multiple of 8: both planes 16-byte aligned)
 
 extern "C" int us_hashgrid_joint_supported(const us_grid_desc* a, const us_grid_desc* b, int64_t n) {
     JLevels lv;
     const int TB = make_jlevels(a, b, n, &lv);
     if (TB <= 0) return 0;
-    if (j_record_dwords(a->n_levels, n) > 0xFFFFFFF0ull) return 0;           // 32-bit record addresses (in dwords)
+    if (j_record_cap(a->n_levels, n) > 0xFFFFFFF0ull) return 0;              // 32-bit record indices
     return 1;
 }
 
@@ -834,10 +828,10 @@ extern "C" size_t us_hashgrid_joint_workspace_bytes(const us_grid_desc* a, const
     if (!us_hashgrid_joint_supported(a, b, n)) return 0;
     JLevels lv;
     const int TB = make_jlevels(a, b, n, &lv);
-    return j_header_bytes(TB, n) + (size_t)j_record_dwords(a->n_levels, n) * sizeof(uint32_t);
+    return j_header_bytes(TB, n) + j_record_bytes(a->n_levels, n);
 }
 
-struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *counts, *prefix, *rec; uint32_t n_rows, stride, rec_cap_dw; };
+struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *counts, *prefix; uint16_t* rec_e; uint2* rec_v; uint32_t n_rows, stride, rec_cap; };
 static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n) {
     JWorkspace w;
     w.totals = (uint32_t*)workspace;
@@ -848,8 +842,9 @@ static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n)
     w.counts = w.extra + ACC_EXTRA_MAX;
     w.n_rows = (uint32_t)us_cdiv(n, J_ROW_POINTS); w.stride = j_row_stride(TB);
     w.prefix = w.counts + (size_t)w.n_rows * w.stride;
-    w.rec = (uint32_t*)((char*)workspace + j_header_bytes(TB, n));
-    w.rec_cap_dw = (uint32_t)j_record_dwords(n_levels, n);
+    w.rec_cap = (uint32_t)j_record_cap(n_levels, n);
+    w.rec_e = (uint16_t*)((char*)workspace + j_header_bytes(TB, n));
+    w.rec_v = (uint2*)((char*)w.rec_e + (size_t)w.rec_cap * 2u);
     return w;
 }
 
@@ -1036,10 +1031,10 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
                "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
     if (!(flags & US_GRID_BWD_RECORDS_READY))
         hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                           w.stride, w.rec, w.rec_cap_dw, plane_stride > 0 ? plane_stride : n);
+                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n);
     const uint32_t n_acc_items = (side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB);
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec, gradA, gradB, overwrite, side_sel);
+                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
 }
