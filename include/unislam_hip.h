@@ -140,8 +140,9 @@ int us_hashgrid_fwd_counted(const us_grid_desc* desc_host, const float* params, 
  * points with the sdf and the colour table, which src/UNISLAM.py:241-253 builds from one base resolution and one per-level scale:
  * cells, fractional positions, the runs of a ray's samples and the vertex hashes coincide, only log2_hashmap_size differs.
  * `a` / `b`: the two descriptors (F = 2, <= 16 levels, equal scale[] / resolution[]); levels where both tables are dense with equal
- * size, or both hashed with a's size <= b's, share one 20-byte record and one bin per vertex contribution; other levels (one dense,
- * one hashed) keep one 12-byte record per grid.  Results are those of us_hashgrid_fwd / us_hashgrid_bwd_binned on each grid. */
+ * size, or both hashed with a's size <= b's, share one bin, one cursor and one stage position per vertex contribution; other levels
+ * (one dense, one hashed) keep bins of their own per grid.  The intermediate records are exact: 10 bytes each (16-bit bin-local entry,
+ * two f32 values) in two aligned planes.  Results are those of us_hashgrid_fwd / us_hashgrid_bwd_binned on each grid. */
 int us_hashgrid_joint_supported(const us_grid_desc* a, const us_grid_desc* b, int64_t n);
 size_t us_hashgrid_joint_workspace_bytes(const us_grid_desc* a, const us_grid_desc* b, int64_t n);
 /* outA / outB = encode(x) with table a / b.  flags: US_GRID_CLAMP01, US_GRID_LEVEL_MAJOR.  workspace (nullable): when given

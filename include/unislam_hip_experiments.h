@@ -15,7 +15,9 @@ extern "C" {
  * { local entry, the two contributions rounded to 26 / 27 significant fp32 bits } instead of 12; the sums are still formed in f64.
  * Relative rounding per contribution <= 2^-18: far inside the 1e-3 parity bound, but not bit-equal to the unpacked pass.
  * Measured on MI355X (4096 x 64 points, room0 tables): 186 -> 179 us per colour-table gradient -- the two passes are bound by LDS
- * atomics and per-workgroup latency, not by their bytes, so the default keeps the exact 12-byte records. */
+ * atomics and per-workgroup latency, not by their bytes, so the default keeps the exact 12-byte records.  (Round 1's reading of the
+ * one-grid kernels.  Round 3's timing builds of the two-grid accumulate pass show the opposite -- that pass IS its record stream -- and
+ * the two-grid kernels now write exact 10-byte records in two aligned planes: DESIGN.md 5f.) */
 #define US_GRID_BWD_PACKED 32
 
 /* Render-only encode + decode in one launch: outA = decoder A(grid A(x)), outB = decoder B(grid B(x)) -- what Decoders.forward
