@@ -24,6 +24,8 @@ bwd = lambda: L.check(lib.us_mlp_bwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), off(
                                           P(gs), P(gc), 1 | L.US_MLP_DEFER_REDUCE, P(wa), P(wb), wsb, st), "bwd")
 bwd_in = lambda: L.check(lib.us_mlp_bwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, n, P(da), P(db),
                                              None, None, 1, None, None, 0, st), "bwd_in")
+bwd_w = lambda: L.check(lib.us_mlp_bwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, n, None, None,
+                                            P(gs), P(gc), 1 | L.US_MLP_DEFER_REDUCE, P(wa), P(wb), wsb, st), "bwd_w")
 def t(fn, reps=50):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -32,4 +34,5 @@ def t(fn, reps=50):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-print(f"n {n}: fwd_pair {t(fwd):.1f} us  bwd_pair {t(bwd):.1f} us  bwd_pair (input gradients only) {t(bwd_in):.1f} us")
+print(f"n {n}: fwd_pair {t(fwd):.1f} us  bwd_pair {t(bwd):.1f} us  bwd_pair (input gradients only) {t(bwd_in):.1f} us  "
+      f"bwd_pair (parameter gradients only) {t(bwd_w):.1f} us")
