@@ -59,7 +59,10 @@ enum { J_HASHED_A = 1, J_HASHED_B = 2, J_PACKABLE = 4, J_SPLIT = 8 };
 // (timing builds, MI355X, one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us): 12-byte
 // {entry, d0, d1} records 102.5 us, two planes 88.7 (same box); the same 10 bytes as 5-dword units of two records -- one unaligned 16-byte
 // load + a 4-byte load over the same lines -- took 104: the shape of the loads counts, not only their bytes.
-// A region of c records takes j_region(c) record indices; a joint bin holds its A region, then its B region.
+// A region of c records takes j_region(c) record indices; a joint bin holds its A region, then its B region -- and only the B region's
+// entries are written: table A's local entry is table B's masked, so the A items of the accumulate pass read E of the B region (the
+// 2-byte stores are the expensive part of the record pass's copy-out: without the A pass's, 126 -> 114 us and 132 -> 118 on two boxes;
+// pairing the remaining ones into 4-byte stores costs more than it saves, with row shifts as well as with two positions per lane).
 __host__ __device__ __forceinline__ uint32_t j_region(uint32_t c) { return (c + 7u) & ~7u; }
 static_assert(J_ACC_DOUBLES / 2 <= 65536 && J_LVL_BINS <= 65536, "local entry and bin of the level in 16 bits each");
 
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(1024) void k_jscan(JSingle sg, const uint32_t* __re
     if (t == 1023) { rec_off[TB] = s_all; dw_off[TB] = d_all; hdr[0] = x_all; hdr[1] = chunk; }
 }
 
+template <int BUF> struct JBufTag { static constexpr int value = BUF; };
+
 // ---------------------------------------------------------------------------------------------------------------
 // record pass: one workgroup = 512 points through all levels, two workgroups per CU
 // ---------------------------------------------------------------------------------------------------------------
@@ -528,11 +533,11 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         auto stage_put = [&](uint32_t k, uint32_t loc, float d0, float d1, uint32_t bin) {
             stxy[k] = make_uint2(loc | (bin << 16), __float_as_uint(d0)); stz[k] = __float_as_uint(d1);
         };
-        auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, uint32_t emask) {
+        auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, auto with_entries) {
             auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
                 const uint32_t R = gr[a.x >> 16] + k + sb;
                 if (R < rec_cap) {
-                    rec_e[R] = (uint16_t)(a.x & emask);
+                    if (decltype(with_entries)::value) rec_e[R] = (uint16_t)a.x;
                     rec_v[R] = make_uint2(a.y, z);
                 }
             };
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t cnt = min(ttot[par], (uint32_t)J_STAGE);
-            copy_out(cnt, gra[par], 0u, q.maskA & 0xFFFFu);
+            copy_out(cnt, gra[par], 0u, JBufTag<0>{});           // values only: table A reads the B region's entries, masked
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 if (k8[c] < J_STAGE) { stxy[k8[c]].y = __float_as_uint(val[c][0]); stz[k8[c]] = __float_as_uint(val[c][1]); }
             }
             lds_barrier();
-            copy_out(cnt, grb[par], 0u, 0xFFFFu);
+            copy_out(cnt, grb[par], 0u, JBufTag<1>{});
         } else {
             const uint32_t nbA = 1u << q.lgA, mA = nbA - 1u, mB = (1u << q.lgB) - 1u;
             {                                                    // table A: bins [0, nbA) of the level, stage index = cursor
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t na = min(atot[par], (uint32_t)J_STAGE);
-            copy_out(na, gra[par], 0u, 0xFFFFu);
+            copy_out(na, gra[par], 0u, JBufTag<1>{});
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 }
             }
             lds_barrier();
-            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, 0xFFFFu);
+            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, JBufTag<1>{});
         }
     }
 }
@@ -639,9 +644,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
-enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
-
-template <int BUF> struct JBufTag { static constexpr int value = BUF; };
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_EBASE, JI_EMASK, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
 
 __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
                                                             const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
@@ -671,18 +674,22 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
         }
         const JBin jb = j_bin_of(lv, n_levels, b);
         if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) ok = false;        // a single-grid bin has no records of the other grid
-        uint32_t hs = 1u, lg = 0u, goff = 0u;
+        uint32_t hs = 1u, lg = 0u, goff = 0u, emask = 0xFFFFu;
 #pragma unroll
         for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
             const JLevel& q = lv.l[l];
-            if (l < n_levels && jb.level == l) { hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA; }
+            if (l < n_levels && jb.level == l) {
+                hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA;
+                if (jb.kind == 0u && side == 0u) emask = q.maskA & 0xFFFFu;      // joint bin, table A: the B region's entries, masked
+            }
         }
         uint32_t cnt = 0, dwo = 0;
         if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
         const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
         const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
         const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
-                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff};
+                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff,
+                                            dwo + (jb.kind == 0u ? j_region(cnt) : 0u), emask};
         const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
         if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
 #pragma unroll
@@ -703,26 +710,27 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
     uint32_t we[2][J_ACC_UNROLL];                                // a pair's two local entries
     u32x4 wv[2][J_ACC_UNROLL];                                   // ... and its four values
     // ---- the request side of the pipeline: item fk, records from fa on (fa is even: chunks of hot bins start at multiples of hdr[1])
-    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
-    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
+    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0, f_ebase = 0;
+    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); f_ebase = field(JI_EBASE, fk); } };
     auto fetch = [&](auto tag) {                                 // every load unconditional (the compiler closes a conditional block with
         constexpr int buf = decltype(tag)::value;                // s_waitcnt vmcnt(0): ONE record in flight per thread): past the end of an
                                                                  // item, and past the last item of the workgroup, it re-reads the last pair
-        const size_t pair0 = (size_t)(f_base >> 1);              // (regions start at multiples of 8 records)
+        const size_t pair0 = (size_t)(f_base >> 1), epair0 = (size_t)(f_ebase >> 1);     // (regions start at multiples of 8 records)
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
             const uint32_t q = min((fa >> 1) + u * J_ACC_THREADS + tid, (f_c1 - 1u) >> 1);
-            we[buf][u] = __builtin_nontemporal_load(rec_e2 + pair0 + q);                                         // two 16-bit entries
+            we[buf][u] = __builtin_nontemporal_load(rec_e2 + epair0 + q);                                        // two 16-bit entries
             wv[buf][u] = __builtin_nontemporal_load(rec_v2 + pair0 + q);                                         // their four values
         }
         fa += STEP;
         if (fa >= f_c1) { ++fk; f_load(); }
     };
     // ---- the adding side: item k, records from a on
-    uint32_t k = 0, a = 0, c1 = 0, nl = 0, misc = 0, hs = 0, goff = 0, REP = 1, rstride = 0;
+    uint32_t k = 0, a = 0, c1 = 0, nl = 0, misc = 0, hs = 0, goff = 0, REP = 1, rstride = 0, emask = 0xFFFFu;
     double* my = acc;
     auto a_load = [&]() {
         a = field(JI_C0, k); c1 = field(JI_C1, k); nl = field(JI_NL, k); misc = field(JI_MISC, k); hs = field(JI_HS, k); goff = field(JI_GOFF, k);
+        emask = field(JI_EMASK, k);
         // slices of few entries (the sdf table: 256 per bin, 25 records per entry) are kept in 4 copies, which thins out same-address
         // collisions of the LDS atomics; the copies sit 2 nl + 8 doubles apart (bank spread)
         REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
             const uint32_t r0 = a + 2u * (u * J_ACC_THREADS + tid);
-            const uint32_t l0 = we[buf][u] & 0xFFFFu, l1 = we[buf][u] >> 16;
+            const uint32_t l0 = we[buf][u] & emask, l1 = (we[buf][u] >> 16) & emask;
             if (r0 < c1 && l0 < nl) {
                 atomicAdd(&my[l0], (double)__uint_as_float(wv[buf][u].x));                        // ds_add_f64
                 atomicAdd(&my[nl + l0], (double)__uint_as_float(wv[buf][u].y));
