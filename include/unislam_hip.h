@@ -336,6 +336,20 @@ int us_uniform_points(const float* rays_o, const float* rays_d, const int32_t* r
 int us_importance_z_rows(const float* sdf_uni, const float* z_uni, const float* beta, const float* u, uint64_t rng_seed,
                          int64_t n_rows, int n_uniform, int n_importance, const int32_t* rows, float* z_out,
                          const float* rays_o, const float* rays_d, const float* bound_host, float* pts_out, void* stream);
+/* The whole branch of src/utils/Renderer.py:104-130 with NO row count on the host (it can be captured into a hipGraph): us_zero_depth_rows,
+ * then us_uniform_points -> us_hashgrid_fwd (grid / table: the sdf grid) -> us_mlp_fwd (mlp / mlp_params: the sdf decoder, n_out 1) ->
+ * us_importance_z_rows, each launched for all n_rays rows and reading count[0] on the device; workgroups beyond it leave at once.  The
+ * rows of z_out[R][S] / pts_out[R][S][3] that belong to rays with !(gt_depth > 0) are rewritten, the others are left alone.  Scratch
+ * (caller-owned, contents undefined afterwards): rows[n_rays] int32, count[1] int32, z_uni / sdf_uni [n_rays * n_uniform],
+ * pts_uni [n_rays * n_uniform * 3], feat [n_rays * n_uniform * n_levels * n_features].  t_rand[k][n_uniform] / u[k][n_importance]
+ * (nullable: in-kernel generator with seed_uniform / seed_importance, rng_counter mixed in on the device as in us_sample_points) are
+ * indexed by the COMPACTED row k. */
+int us_zero_depth_resample(const us_grid_desc* grid, const float* table, const us_mlp_desc* mlp, const float* mlp_params,
+                           const float* beta, const float* rays_o, const float* rays_d, const float* gt_depth, int64_t n_rays,
+                           const float* bound_host, const float* t_uni, int n_uniform, int n_importance, const float* t_rand,
+                           const float* u, uint64_t seed_uniform, uint64_t seed_importance, const float* rng_counter, int perturb,
+                           int32_t* rows, int32_t* count, float* z_uni, float* pts_uni, float* feat, float* sdf_uni, float* z_out, float* pts_out,
+                           void* stream);
 
 /* us_bbox_filter + us_sample_z + us_ray_points in ONE launch, value for value (the iteration of src/Mapper.py:396-406 +
  * src/utils/Renderer.py:81-101,132-137 when no ray takes the zero-depth branch).  perturb != 0: jitter with t_rand[R][S], or,
@@ -499,7 +513,9 @@ int us_pose_grad(const float* pose, const float* g_rays_o, const float* g_rays_d
  * pools (pool_*[b][P]..., indexed by the WINDOW frame number).  Frame 0 keeps the matrix c2w_first[4][4] (the oldest pose is fixed,
  * src/Mapper.py:374); frame f >= 1 uses poses7[f-1] = (qr,qi,qj,qk, tx,ty,tz) through pytorch3d's quaternion_to_matrix.  Outputs as
  * us_gather_rays plus dirs[n][3] (nullable), the camera-frame directions us_pose_window_step needs.  The output pointers address
- * the first row of this call's block (a second call appends the extra rays of the newest frames, src/Mapper.py:385-393). */
+ * the first row of this call's block (a second call appends the extra rays of the newest frames, src/Mapper.py:385-393).
+ * c2w_first NULL (us_window_rays and us_window_sample): none of these frames is the window's fixed one -- frame f uses poses7[f]
+ * (a data-parallel rank whose share of the window's frames does not hold the oldest). */
 int us_window_rays(const float* c2w_first, const float* poses7, const float* pool_depth, const float* pool_color, const float* pool_dirs,
                    const int64_t* idx, int64_t pool_size, int f_begin, int f_count, int64_t n_per_frame, float* rays_o, float* rays_d,
                    float* depth, float* color, float* dirs, void* stream);

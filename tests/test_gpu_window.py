@@ -170,7 +170,6 @@ def test_mapwindow_reproduces_reference_joint_opt(golden, tag):
         step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per + (2000 if extra else 0))
         step.reset_optimizer(float(g["lr_factor"]))
         win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=float(g["cam_lr"]), extra=extra)
-        assert not win.has_zero
         for it in range(iters):
             idx = torch.randint(P, (n_per * b,)).reshape(b, -1)
             idx2 = torch.randint(P, (extra[1] * extra[0],)).reshape(extra[0], -1) if extra else None
@@ -181,6 +180,7 @@ def test_mapwindow_reproduces_reference_joint_opt(golden, tag):
             t_rand[inside] = torch.rand(int(inside.sum()), 40)
             win.iterate(idx.to(DEV), idx2.to(DEV) if extra else None, t_rand=t_rand.to(DEV))
             assert torch.equal(step.valid[:win.R].bool().cpu(), inside)
+            assert int(step.zd_count) == 0                       # has_zero_depth left open: the branch ran, found no row and changed nothing
         pre = f"{tag}_i{iters}_"
         if iters == 1:
             gp = T(g[pre + "g_poses"])
@@ -220,16 +220,22 @@ def test_mapwindow_first_iteration_gradients_against_reference(golden):
     np.testing.assert_allclose(float(dec.beta.grad.reshape(-1)[0]), float(np.asarray(g["w6_i1_g_beta"]).reshape(-1)[0]), rtol=1e-3)
 
 
-def test_mapwindow_graph_replay_equals_eager():
+@pytest.mark.parametrize("holes", [False, True])
+def test_mapwindow_graph_replay_equals_eager(holes):
     """capture() / replay(): five replayed joint_opt iterations == five eager ones on the same draws and jitter (loss 1e-6, parameters
-    and poses allclose); capturing leaves model, optimiser and poses alone; the extra-ray block rides along"""
+    and poses allclose); capturing leaves model, optimiser and poses alone; the extra-ray block rides along.  holes: every seventh pool
+    pixel has no depth -- the importance-sampling branch of src/utils/Renderer.py:104-130 is part of the captured graph (its row count
+    is read on the device), with its own static draws"""
     import unislam_amd as us
     b, P, n_per, extra = 8, 500, 64, (10, 25)
     c2ws, depths, colors, dirs = _window(b, P, 7)
+    if holes:
+        depths[:, ::7] = 0.0
     g = torch.Generator().manual_seed(5)
     R = b * n_per + min(extra[0], b) * extra[1]
     draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.randint(P, (min(extra[0], b), extra[1]), generator=g).to(DEV),
               torch.rand(R, 40, generator=g).to(DEV)) for _ in range(6)]
+    zds = [(torch.rand(R, 32, generator=g).to(DEV), torch.rand(R, 8, generator=g).to(DEV)) if holes else None for _ in range(6)]
     outs = []
     for mode in ("eager", "graph"):
         torch.manual_seed(0)
@@ -238,19 +244,23 @@ def test_mapwindow_graph_replay_equals_eager():
         with torch.no_grad():
             es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
         step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
-        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=False)
-        losses = [float(win.iterate(draws[0][0], draws[0][1], t_rand=draws[0][2]))]          # one eager step first: moments are non-zero
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=None if holes else False)
+        losses = [float(win.iterate(draws[0][0], draws[0][1], t_rand=draws[0][2], zero_depth_draws=zds[0]))]   # one eager step first: moments are non-zero
+        if holes:
+            assert 20 < int(step.zd_count) < R // 4
         if mode == "graph":
             before = (step.flat.clone(), step.m.clone(), win.poses.clone(), win.pm.clone(), float(step.step_dev[0]))
             win.capture(t_rand=True, device_draw=False)
             assert torch.equal(step.flat, before[0]) and torch.equal(step.m, before[1]) and torch.equal(win.poses, before[2])
             assert torch.equal(win.pm, before[3]) and float(step.step_dev[0]) == before[4] == 1.0
-        for ia, ib, tr in draws[1:]:
+        for (ia, ib, tr), zd in zip(draws[1:], zds[1:]):
             if mode == "graph":
                 win.t_rand.copy_(tr)
+                if holes:
+                    win.zd_draws[0].copy_(zd[0]); win.zd_draws[1].copy_(zd[1])
                 losses.append(float(win.replay(ia, ib)))
             else:
-                losses.append(float(win.iterate(ia, ib, t_rand=tr)))
+                losses.append(float(win.iterate(ia, ib, t_rand=tr, zero_depth_draws=zd)))
         assert float(step.step_dev[0]) == 6.0
         outs.append((losses, step.flat.clone(), win.poses.clone()))
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6)
@@ -446,8 +456,8 @@ def test_decoder_backward_contracts_dydx_in_registers(S, n_rays):
 
 def test_mapwindow_with_pixels_without_depth():
     """a window whose pools hold pixels without a depth measurement (src/utils/Renderer.py:104-130: the importance-sampling branch):
-    MapWindow runs eagerly (capture is refused: the branch reads a row count on the host) and gives the loss statistics and the pose
-    gradient input of MapStep on the same rays, jitter and draws"""
+    MapWindow gives the loss statistics and the pose gradient input of MapStep on the same rays, jitter and draws (the branch's row
+    count stays on the device: us_zero_depth_resample)"""
     import unislam_amd as us
     b, P, n_per = 5, 400, 60
     c2ws, depths, colors, dirs = _window(b, P, 21)
@@ -469,8 +479,6 @@ def test_mapwindow_with_pixels_without_depth():
         step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R)
         win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True)
         assert win.has_zero
-        with pytest.raises(us.UniSlamHipError):
-            win.capture()
         if mode == "window":
             step.lr = {k: 0.0 for k in step.lr}; win.cam_lr = 0.0
             loss = win.iterate(idx, t_rand=t_rand, zero_depth_draws=zd)

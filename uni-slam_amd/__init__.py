@@ -12,7 +12,8 @@ from .network import FusedMLP, fused_mlp, make_mlp_desc
 from .decoders import Decoders, get_model
 from .renderer import Renderer, sample_z
 from .losses import sdf_losses, mapping_loss, tracking_loss, fused_loss
-from .step import MapStep, TrackStep
+from .mapstep import MapStep
+from .trackstep import TrackStep
 from .window import MapWindow
 from .graph import CapturedIteration
 from .mesher import eval_points

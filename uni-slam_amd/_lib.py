@@ -122,6 +122,8 @@ SIGNATURES = {
     "us_zero_depth_rows": (c_int, [c_f, c_i64, c_f, c_f, c_f]),
     "us_uniform_points": (c_int, [c_f, c_f, c_f, c_i64, _HF, c_f, c_int, c_f, ctypes.c_uint64, c_int, c_f, c_f, c_f]),
     "us_importance_z_rows": (c_int, [c_f, c_f, c_f, c_f, ctypes.c_uint64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, _HF, c_f, c_f]),
+    "us_zero_depth_resample": (c_int, [_GP, c_f, _MP, c_f, c_f, c_f, c_f, c_f, c_i64, _HF, c_f, c_int, c_int, c_f, c_f, ctypes.c_uint64,
+                                       ctypes.c_uint64, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_sample_points": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt, c_f, ctypes.c_uint64,
                                  c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "us_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),

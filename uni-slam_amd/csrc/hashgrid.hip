@@ -65,12 +65,17 @@ extern "C" int us_grid_desc_init(us_grid_desc* d, uint32_t n_levels, uint32_t n_
 template <int F, bool DYDX>
 __global__ __launch_bounds__(256) void k_fwd(LevelTable tab, uint32_t n_levels, const float* __restrict__ params,
                                              const float* __restrict__ x, int64_t n, float* __restrict__ out,
-                                             float* __restrict__ dy_dx, int clamp, int lm) {
+                                             float* __restrict__ dy_dx, int clamp, int lm,
+                                             const int32_t* __restrict__ n_dev, int n_mul) {
     const uint32_t level = blockIdx.y;
     const LevelGeom g = level_geom(tab, level);
     const typename Feat<F>::T* grid = reinterpret_cast<const typename Feat<F>::T*>(params) + tab.off[level];
     const uint32_t C = n_levels * F;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // n_dev: the number of points actually present is n_dev[0] * n_mul (device memory, <= n): the launch is sized for n, which stays the
+    // plane stride of the level-major layout; threads beyond the count leave at once (us_zero_depth_resample: no row count on the host)
+    int64_t n_act = n;
+    if (n_dev) { const int64_t m = (int64_t)n_dev[0] * n_mul; n_act = m < n ? m : n; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += (int64_t)gridDim.x * blockDim.x) {
         float pos[3]; uint32_t cell[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) pos_fract(load_x(x, i, k, clamp), g.scale, pos[k], cell[k]);
@@ -469,8 +474,9 @@ static unsigned point_blocks(int64_t n, int threads, int cap) {
     return (unsigned)b;
 }
 
-extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out,
-                               float* dy_dx, int flags, void* stream) {
+// us_hashgrid_fwd with the point count optionally read on the device (n_dev[0] * n_mul <= n; NULL: n): shared with render.hip
+int us_hashgrid_fwd_counted_rows(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out,
+                                 float* dy_dx, int flags, const int32_t* n_dev, int n_mul, void* stream) {
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0; (void)lm;
     int rc = check_desc("us_hashgrid_fwd", d); if (rc) return rc;
     US_REQUIRE(n >= 0, US_ERR_SHAPE, "us_hashgrid_fwd: n < 0");
@@ -481,12 +487,17 @@ extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const
     dim3 grid(point_blocks(n, 256, 1 << 20), d->n_levels), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_FWD(F)                                                                                         \
-    if (dy_dx) hipLaunchKernelGGL((k_fwd<F, true>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm); \
-    else hipLaunchKernelGGL((k_fwd<F, false>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm);
+    if (dy_dx) hipLaunchKernelGGL((k_fwd<F, true>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm, n_dev, n_mul); \
+    else hipLaunchKernelGGL((k_fwd<F, false>), grid, block, 0, s, t, d->n_levels, params, x, n, out, dy_dx, clamp, lm, n_dev, n_mul);
     switch (d->n_features) { case 1: LAUNCH_FWD(1) break; case 2: LAUNCH_FWD(2) break; default: LAUNCH_FWD(4) break; }
 #undef LAUNCH_FWD
     US_CHECK_LAUNCH("us_hashgrid_fwd");
     return US_OK;
+}
+
+extern "C" int us_hashgrid_fwd(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out,
+                               float* dy_dx, int flags, void* stream) {
+    return us_hashgrid_fwd_counted_rows(d, params, x, n, out, dy_dx, flags, nullptr, 0, stream);
 }
 
 extern "C" int us_hashgrid_indices(const us_grid_desc* d, const float* x, int64_t n, uint32_t* idx, int flags, void* stream) {

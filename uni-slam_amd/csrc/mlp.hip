@@ -193,13 +193,18 @@ __device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_
 template <int NIN, int WIDTH, int NHID>
 __global__ __launch_bounds__(MLP_THREADS) void k_mlp_fwd(const float* __restrict__ params, int has_bias, int n_out,
                                                          int act, const float* __restrict__ in, int64_t n,
-                                                         float* __restrict__ out, int64_t out_stride, int lm) {
+                                                         float* __restrict__ out, int64_t out_stride, int lm,
+                                                         const int32_t* __restrict__ n_dev, int n_mul) {
     typedef MlpCfg<NIN, WIDTH, NHID> C;
     constexpr int NQ = C::NQ, PTS = C::PTS;
     __shared__ __attribute__((aligned(16))) float lds[C::L_FWD_END];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
     const float* bias = lds + C::L_B;
-    const int64_t n_chunks = (n + PTS - 1) / PTS;
+    // n_dev: n_dev[0] * n_mul (<= n) points are present; n stays the plane stride and the bound of every access, the chunk count follows
+    // the device-side number (the rows of a last, partial chunk beyond it are computed and never read)
+    int64_t n_act = n;
+    if (n_dev) { const int64_t m = (int64_t)n_dev[0] * n_mul; n_act = m < n ? m : n; }
+    const int64_t n_chunks = (n_act + PTS - 1) / PTS;
     const int64_t stride = (int64_t)gridDim.x * MLP_WAVES;
     int64_t chunk = (int64_t)blockIdx.x * MLP_WAVES + wave;
     // the first chunk's features are requested before the weights: the two latencies overlap; inside the loop the next chunk's
@@ -573,8 +578,9 @@ extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
         }                                                                                                          \
     } while (0)
 
-extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
-                          int64_t out_stride, int flags, void* stream) {
+// us_mlp_fwd with the point count optionally read on the device (n_dev[0] * n_mul <= n; NULL: n): shared with render.hip
+int us_mlp_fwd_counted_rows(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
+                            int64_t out_stride, int flags, const int32_t* n_dev, int n_mul, void* stream) {
     const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_fwd", d); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_fwd: out_stride %lld < n_out", (long long)out_stride);
@@ -587,11 +593,16 @@ extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float
     const int64_t cap = bf ? MLP_BF_FWD_CAP1 : MLP_FWD_MAX_WG;
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
-    if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
-    else if (bf) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
-    else MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm);
+    if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
+    else if (bf) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
+    else MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
     US_CHECK_LAUNCH("us_mlp_fwd");
     return US_OK;
+}
+
+extern "C" int us_mlp_fwd(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
+                          int64_t out_stride, int flags, void* stream) {
+    return us_mlp_fwd_counted_rows(d, params, in, n, out, out_stride, flags, nullptr, 0, stream);
 }
 
 #ifndef MLP_BWD_MAX_WG

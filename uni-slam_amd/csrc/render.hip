@@ -644,7 +644,10 @@ __global__ __launch_bounds__(256) void k_uniform_points(const float* __restrict_
                                                         const int32_t* __restrict__ rows, int64_t n_rows, Bound3x bd,
                                                         const float* __restrict__ t_uni, int Su, const float* __restrict__ t_rand,
                                                         unsigned long long seed, int perturb, float* __restrict__ z_uni,
-                                                        float* __restrict__ pts) {
+                                                        float* __restrict__ pts, const int32_t* __restrict__ n_dev,
+                                                        const float* __restrict__ rng_counter) {
+    if (n_dev) { const int64_t m = n_dev[0]; n_rows = m < n_rows ? m : n_rows; }     // the row count on the device (us_zero_depth_resample)
+    if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * Su; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / Su; const int j = (int)(i - r * Su);
         const int64_t ray = rows ? rows[r] : r;
@@ -678,9 +681,12 @@ __global__ __launch_bounds__(256) void k_importance_z(const float* __restrict__ 
                                                       unsigned long long seed, int64_t n_rays,
                                                       int Su, int n_imp, const int32_t* __restrict__ rows, float* __restrict__ z_out,
                                                       const float* __restrict__ rays_o, const float* __restrict__ rays_d, Bound3x bd,
-                                                      float* __restrict__ pts_out) {
+                                                      float* __restrict__ pts_out, const int32_t* __restrict__ n_dev,
+                                                      const float* __restrict__ rng_counter) {
     __shared__ float sh_cdf[4][IMP_MAX_U], sh_bin[4][IMP_MAX_U], sh_all[4][IMP_MAX_U + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (n_dev) { const int64_t m = n_dev[0]; n_rays = m < n_rays ? m : n_rays; }     // the row count on the device (us_zero_depth_resample)
+    if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
     if (ray >= n_rays) return;                                   // wave-uniform
     float* cdf = sh_cdf[wv]; float* bin = sh_bin[wv]; float* all = sh_all[wv];
@@ -1148,11 +1154,11 @@ __global__ __launch_bounds__(256) void k_window_sample(const float* __restrict__
         }
         src = f * ws.P + p;
         float R[9];
-        if (f == 0) {
+        if (f == 0 && c2w_first) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) { R[a * 3] = c2w_first[a * 4]; R[a * 3 + 1] = c2w_first[a * 4 + 1]; R[a * 3 + 2] = c2w_first[a * 4 + 2]; o3[a] = c2w_first[a * 4 + 3]; }
-        } else {
-            const float* q = poses7 + (f - 1) * 7;
+        } else {                                                   // c2w_first NULL: no frame here is the window's fixed one, frame f reads poses7[f]
+            const float* q = poses7 + (f - (c2w_first ? 1 : 0)) * 7;
             quat_rot(q, R);
             o3[0] = q[4]; o3[1] = q[5]; o3[2] = q[6];
         }
@@ -1555,7 +1561,8 @@ extern "C" int us_importance_z_rows(const float* sdf_uni, const float* z_uni, co
     Bound3x bd = {};
     if (pts_out) bd = make_bound3x(bound_host);
     hipLaunchKernelGGL(k_importance_z, dim3((unsigned)us_cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, sdf_uni, z_uni, beta, u,
-                       (unsigned long long)rng_seed, n_rows, n_uniform, n_importance, rows, z_out, rays_o, rays_d, bd, pts_out);
+                       (unsigned long long)rng_seed, n_rows, n_uniform, n_importance, rows, z_out, rays_o, rays_d, bd, pts_out,
+                       (const int32_t*)nullptr, (const float*)nullptr);
     US_CHECK_LAUNCH("us_importance_z");
     return US_OK;
 }
@@ -1582,8 +1589,50 @@ extern "C" int us_uniform_points(const float* rays_o, const float* rays_d, const
     US_REQUIRE(rays_o && rays_d && bound_host && t_uni && z_uni && pts, US_ERR_NULL, "us_uniform_points: NULL pointer");
     US_REQUIRE(n_uniform >= 1, US_ERR_SHAPE, "us_uniform_points: n_uniform %d", n_uniform);
     hipLaunchKernelGGL(k_uniform_points, dim3(grid_1d(n_rows * n_uniform, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
-                       rows, n_rows, make_bound3x(bound_host), t_uni, n_uniform, t_rand, (unsigned long long)rng_seed, perturb, z_uni, pts);
+                       rows, n_rows, make_bound3x(bound_host), t_uni, n_uniform, t_rand, (unsigned long long)rng_seed, perturb, z_uni, pts,
+                       (const int32_t*)nullptr, (const float*)nullptr);
     US_CHECK_LAUNCH("us_uniform_points");
+    return US_OK;
+}
+
+// Renderer.py:104-130 for the rays WITHOUT a depth measurement with no row count on the host: compaction (rows, count[0] on the device),
+// then the coarse uniform pass, the sdf grid, its decoder and the importance resampling, each launched for all n_rays rows and reading
+// count[0] on the device -- workgroups beyond it leave at once.  The whole branch can be captured into a hipGraph.
+int us_hashgrid_fwd_counted_rows(const us_grid_desc* d, const float* params, const float* x, int64_t n, float* out, float* dy_dx, int flags,
+                                 const int32_t* n_dev, int n_mul, void* stream);                        // hashgrid.hip
+int us_mlp_fwd_counted_rows(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out, int64_t out_stride, int flags,
+                            const int32_t* n_dev, int n_mul, void* stream);                             // mlp.hip
+
+extern "C" int us_zero_depth_resample(const us_grid_desc* grid, const float* table, const us_mlp_desc* mlp, const float* mlp_params,
+                                      const float* beta, const float* rays_o, const float* rays_d, const float* gt_depth, int64_t n_rays,
+                                      const float* bound_host, const float* t_uni, int n_uniform, int n_importance, const float* t_rand,
+                                      const float* u, uint64_t seed_uniform, uint64_t seed_importance, const float* rng_counter,
+                                      int perturb, int32_t* rows, int32_t* count, float* z_uni, float* pts_uni, float* feat, float* sdf_uni, float* z_out, float* pts_out,
+                                      void* stream) {
+    if (n_rays <= 0) return n_rays == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(grid && table && mlp && mlp_params && beta && rays_o && rays_d && gt_depth && bound_host && t_uni && rows && count && z_uni &&
+               pts_uni && feat && sdf_uni && z_out && pts_out, US_ERR_NULL, "us_zero_depth_resample: NULL pointer");
+    US_REQUIRE(n_rays * (int64_t)n_uniform <= 0x7fffffff, US_ERR_SHAPE, "us_zero_depth_resample: n_rays %lld x n_uniform %d", (long long)n_rays, n_uniform);
+    US_REQUIRE(n_uniform >= 3 && n_uniform <= IMP_MAX_U && n_importance >= 1 && n_importance <= 64, US_ERR_SHAPE,
+               "us_zero_depth_resample: n_uniform %d not in 3..%d or n_importance %d not in 1..64", n_uniform, IMP_MAX_U, n_importance);
+    US_REQUIRE(mlp->n_in == grid->n_levels * grid->n_features && mlp->n_out == 1, US_ERR_CONFIG,
+               "us_zero_depth_resample: the decoder maps %u -> %u, the grid leaves %u features", mlp->n_in, mlp->n_out, grid->n_levels * grid->n_features);
+    int rc = us_zero_depth_rows(gt_depth, n_rays, rows, count, stream); if (rc) return rc;
+    const Bound3x bd = make_bound3x(bound_host);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_uniform_points, dim3(grid_1d(n_rays * n_uniform, 256, 1 << 20)), dim3(256), 0, s, rays_o, rays_d, (const int32_t*)rows,
+                       n_rays, bd, t_uni, n_uniform, perturb ? t_rand : nullptr, (unsigned long long)seed_uniform, perturb, z_uni, pts_uni,
+                       (const int32_t*)count, rng_counter);
+    US_CHECK_LAUNCH("us_zero_depth_resample (uniform points)");
+    const int64_t n = n_rays * n_uniform;
+    rc = us_hashgrid_fwd_counted_rows(grid, table, pts_uni, n, feat, nullptr, US_GRID_CLAMP01 | US_GRID_LEVEL_MAJOR, count, n_uniform, stream);
+    if (rc) return rc;
+    rc = us_mlp_fwd_counted_rows(mlp, mlp_params, feat, n, sdf_uni, 1, US_MLP_LEVEL_MAJOR, count, n_uniform, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_importance_z, dim3((unsigned)us_cdiv(n_rays, 4)), dim3(256), 0, s, (const float*)sdf_uni, (const float*)z_uni, beta, u,
+                       (unsigned long long)seed_importance, n_rays, n_uniform, n_importance, (const int32_t*)rows, z_out, rays_o, rays_d, bd, pts_out,
+                       (const int32_t*)count, rng_counter);
+    US_CHECK_LAUNCH("us_zero_depth_resample (importance samples)");
     return US_OK;
 }
 
@@ -1791,7 +1840,7 @@ extern "C" int us_window_sample(const float* c2w_first, const float* poses7, int
     if (n_extra_frames == 0 || n_extra == 0) { n_extra_frames = 0; n_extra = 1; }
     const int64_t n_rays = (int64_t)b * n_per_frame + (int64_t)n_extra_frames * (n_extra_frames ? n_extra : 0);
     if (n_rays == 0) return US_OK;
-    US_REQUIRE(c2w_first && (b == 1 || poses7) && pool_depth && pool_color && pool_dirs && bound_host && t_uni && t_surf && rays_o && rays_d &&
+    US_REQUIRE((c2w_first || poses7) && ((c2w_first && b == 1) || poses7) && pool_depth && pool_color && pool_dirs && bound_host && t_uni && t_surf && rays_o && rays_d &&
                gt_depth && gt_color && valid && z_vals && pts, US_ERR_NULL, "us_window_sample: NULL pointer");
     US_REQUIRE(!n_extra_frames || ((idx_a == nullptr) == (idx_b == nullptr)), US_ERR_NULL, "us_window_sample: idx_a and idx_b together, or neither (in-kernel draw)");
     const int S = n_strat + n_imp;

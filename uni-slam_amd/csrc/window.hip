@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void k_window_rays(const float* __restrict__ c
         const int64_t f = f_begin + i / n_per;
         const int64_t src = f * P + idx[i];
         float R[9], t[3];
-        if (f == 0) {
+        if (f == 0 && c2w_first) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) { R[k * 3] = c2w_first[k * 4]; R[k * 3 + 1] = c2w_first[k * 4 + 1]; R[k * 3 + 2] = c2w_first[k * 4 + 2]; t[k] = c2w_first[k * 4 + 3]; }
-        } else {
-            const float* q = poses7 + (f - 1) * 7;
+        } else {                                                   // c2w_first NULL: no frame of this block is fixed, frame f reads poses7[f]
+            const float* q = poses7 + (f - (c2w_first ? 1 : 0)) * 7;
             w_quat_rot(q, R);
             t[0] = q[4]; t[1] = q[5]; t[2] = q[6];
         }
@@ -168,8 +168,8 @@ extern "C" int us_window_rays(const float* c2w_first, const float* poses7, const
                               float* rays_o, float* rays_d, float* depth, float* color, float* dirs, void* stream) {
     US_REQUIRE(pool_depth && pool_color && pool_dirs && idx && rays_o && rays_d && depth && color, US_ERR_NULL, "us_window_rays: NULL pointer");
     US_REQUIRE(f_begin >= 0 && f_count >= 1 && pool_size >= 1 && n_per_frame >= 0, US_ERR_SHAPE, "us_window_rays: bad shape");
-    US_REQUIRE(f_begin > 0 || c2w_first, US_ERR_NULL, "us_window_rays: frame 0 needs its matrix");
-    US_REQUIRE(f_begin + f_count <= 1 || poses7, US_ERR_NULL, "us_window_rays: frames 1.. need poses7");
+    US_REQUIRE(c2w_first || poses7, US_ERR_NULL, "us_window_rays: frame 0 needs its matrix (or, c2w_first NULL, every frame its pose)");
+    US_REQUIRE((c2w_first && f_begin + f_count <= 1) || poses7, US_ERR_NULL, "us_window_rays: frames 1.. need poses7");
     const int64_t total = (int64_t)f_count * n_per_frame;
     if (total == 0) return US_OK;
     int64_t blocks = us_cdiv(total, 256); if (blocks > 65536) blocks = 65536;

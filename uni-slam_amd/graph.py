@@ -43,3 +43,59 @@ class CapturedIteration:
     def replay(self):
         self.graph.replay()
         return self.out
+
+
+class SegmentedGraph:
+    """
+    One iteration as SEVERAL hipGraphs with eager operations between them -- the data-parallel mapping step: its rank-local launches are
+    captured, the collectives (torch.distributed work objects on RCCL's own stream) stay eager.
+
+        sg = SegmentedGraph(lambda cut: step(cut), join=step._join_side_streams)
+        sg.replay()
+
+    `fn(cut)` is run once under capture; wherever it calls cut(op), the current graph ends (after join(): side streams the caller forked
+    must have re-joined the capturing stream, a capture cannot end with forked work outstanding), `op` is noted, and a new graph begins.
+    replay() launches graph, op(), graph, op(), ... on the current stream and returns what fn returned (static tensors).
+    The capture is thread-local: a process group's watchdog thread may query its events meanwhile.
+    """
+
+    def __init__(self, fn, join=None):
+        self.segments = []
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        was = gc.isenabled()
+        gc.disable()                                    # (see CapturedIteration: no graph may be destroyed while a stream captures)
+        cur = [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(capture_error_mode="thread_local")
+
+        def end(op):
+            if join is not None:
+                join()
+            cur[0].capture_end()
+            self.segments.append((cur[0], op))
+
+        def cut(op):
+            end(op)
+            begin()
+
+        try:
+            with torch.cuda.stream(s):
+                begin()
+                try:
+                    self.out = fn(cut)
+                finally:
+                    end(None)
+        finally:
+            if was:
+                gc.enable()
+        torch.cuda.current_stream().wait_stream(s)
+
+    def replay(self):
+        for g, op in self.segments:
+            g.replay()
+            if op is not None:
+                op()
+        return self.out

@@ -86,7 +86,17 @@ class MapStep:
         if self.sharded_adam and grad_comm in ("bf16", torch.bfloat16):
             raise L.UniSlamHipError("MapStep: grad_comm='bf16' and sharded_adam=True are exclusive (the reduce-scatter runs in place on "
                                     "the fp32 gradient buffer); choose one")
-        self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter generator
+        self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter / pixel-draw generator
+        if group is not None:
+            # Data-parallel ranks usually share the torch seed (identical initial replicas): without a rank in the generator's seed they
+            # would draw the same pool pixels and the same jitter, and the all-reduce would average W copies of ONE batch.
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                r = dist.get_rank(None if group is True else group)
+                x = (r + 1) * 0x9E3779B97F4A7C15 & (2 ** 64 - 1)                    # splitmix64 finaliser of the rank
+                x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+                x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+                self.rng_seed = (self.rng_seed ^ x ^ (x >> 31)) & (2 ** 63 - 1)
         self.zd_rows = None                                                                # scratch of the zero-depth branch, on first use
         dev = hash_grid_sdf.params.device
         if dev.type != "cuda":
@@ -286,9 +296,9 @@ class MapStep:
                 presampled=False):
         """
         Sample, encode, decode, composite and reduce the LOCAL loss sums and counts into self.stats[10].
-        has_zero_depth: None -> look (one host sync, what Renderer.py:104 does every call); False -> the caller
-        knows every ray carries a depth (e.g. checked once per mapped frame on the pixel pools); True -> run the
-        importance-sampling branch of Renderer.py:104-130 for the rays with gt_depth == 0.
+        has_zero_depth: False -> the caller knows every ray carries a depth (e.g. noted per keyframe when its pool was cut) and the
+        branch's launches are skipped; None / True -> run the importance-sampling branch of Renderer.py:104-130 for the rays with
+        gt_depth == 0 (their number stays on the device: no host synchronisation either way).
         zero_depth_draws: (t_rand_uni [n0, n_strat], u [n0, n_imp]) for that branch's rays in row order, to replay a given random stream
         (tests); default: the in-kernel generator.
         backward_follows: False for a render-only call (the encoders then skip the bookkeeping they do for the table gradient).
@@ -323,30 +333,24 @@ class MapStep:
         fl = self.flat
         if has_zero_depth is not False:
             # Renderer.py:104-130 for the rays without a depth measurement, on their compacted rows: coarse uniform pass through the
-            # sdf grid + decoder, importance samples, and the rows of z / pts rewritten in place.  One host sync (the row count).
+            # sdf grid + decoder, importance samples, and the rows of z / pts rewritten in place.  The row count stays on the device
+            # (us_zero_depth_resample: every launch is sized for R rows and reads the count there), so the branch costs no host
+            # synchronisation and a window with depth holes can be captured like any other.
             Su = self.n_strat
             if self.zd_rows is None or self.zd_rows.numel() < R:
-                self.zd_rows = torch.empty(R, dtype=torch.int32, device=self.device)
-                self.zd_count = torch.empty(1, dtype=torch.int32, device=self.device)
-                self.zd_z = torch.empty(R * Su, dtype=torch.float32, device=self.device)
-                self.zd_sdf, self.zd_pts = torch.empty_like(self.zd_z), torch.empty(R * Su * 3, dtype=torch.float32, device=self.device)
-            L.check(lib.us_zero_depth_rows(P(gd), R, P(self.zd_rows), P(self.zd_count), st), "us_zero_depth_rows")
-            n0 = int(self.zd_count.item())
-            if n0:
-                tr0, u0 = zero_depth_draws if zero_depth_draws is not None else (None, None)
-                tr0 = L.f32(tr0) if (tr0 is not None and self.perturb) else None
-                u0 = L.f32(u0) if u0 is not None else None
-                assert tr0 is None or tr0.numel() == n0 * Su
-                assert u0 is None or u0.numel() == n0 * self.n_imp
-                feat = self.d_feat_s                        # free until the backward pass; n0*Su <= R*S rows
-                L.check(lib.us_uniform_points(P(o), P(d), P(self.zd_rows), n0, self.bhost, P(self.t_uni), Su, P(tr0) if tr0 is not None else None,
-                                              seed(1), 1 if self.perturb else 0, P(self.zd_z), P(self.zd_pts), st), "us_uniform_points")
-                L.check(lib.us_hashgrid_fwd(ctypes.byref(self.es.desc), off(fl, self.o_tab_s), P(self.zd_pts), n0 * Su, P(feat), None, 3, st),
-                        "us_hashgrid_fwd")
-                L.check(lib.us_mlp_fwd(ctypes.byref(self.desc_s), off(fl, self.o_dec_s), P(feat), n0 * Su, P(self.zd_sdf), 1, 1, st), "us_mlp_fwd")
-                L.check(lib.us_importance_z_rows(P(self.zd_sdf), P(self.zd_z), off(fl, self.o_beta), P(u0) if u0 is not None else None, seed(2),
-                                                 n0, Su, self.n_imp, P(self.zd_rows), P(self.z), P(o), P(d), self.bhost, P(self.pts), st),
-                        "us_importance_z_rows")
+                self.zd_rows = torch.empty(self.max_rays, dtype=torch.int32, device=self.device)
+                self.zd_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self.zd_z = torch.empty(self.max_rays * Su, dtype=torch.float32, device=self.device)
+                self.zd_sdf, self.zd_pts = torch.empty_like(self.zd_z), torch.empty(self.max_rays * Su * 3, dtype=torch.float32, device=self.device)
+            tr0, u0 = zero_depth_draws if zero_depth_draws is not None else (None, None)
+            tr0 = L.f32(tr0) if (tr0 is not None and self.perturb) else None
+            u0 = L.f32(u0) if u0 is not None else None
+            feat = self.d_feat_s                            # free until the backward pass; R * Su <= R * S rows
+            L.check(lib.us_zero_depth_resample(ctypes.byref(self.es.desc), off(fl, self.o_tab_s), ctypes.byref(self.desc_s), off(fl, self.o_dec_s),
+                                               off(fl, self.o_beta), P(o), P(d), P(gd), R, self.bhost, P(self.t_uni), Su, self.n_imp,
+                                               P(tr0) if tr0 is not None else None, P(u0) if u0 is not None else None, seed(1), seed(2),
+                                               P(self.step_dev), 1 if self.perturb else 0, P(self.zd_rows), P(self.zd_count), P(self.zd_z), P(self.zd_pts),
+                                               P(feat), P(self.zd_sdf), P(self.z), P(self.pts), st), "us_zero_depth_resample")
         fl = self.flat
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
@@ -714,14 +718,14 @@ class MapStep:
                                               I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, P(self.step_dev),
                                               zero_mask, st), "us_adam_step_segments_dev")
 
-    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, presampled=False):
+    def iterate(self, rays_o, rays_d, gt_depth, gt_color, t_rand=None, has_zero_depth=None, presampled=False, zero_depth_draws=None):
         """One full mapping iteration (Mapper.py:366-445 minus ray selection). Returns the loss as a device tensor [1]."""
         if self.group is None:
-            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled)
+            self.forward(rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, zero_depth_draws, True, presampled)
             loss = self.backward(fold=True)
             self.adam_step()
             return loss
-        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, None, True, presampled), self.group)
+        return dp_iterate(self, (rays_o, rays_d, gt_depth, gt_color, t_rand, has_zero_depth, zero_depth_draws, True, presampled), self.group)
 
     def capture(self, n_rays, t_rand=False):
         """

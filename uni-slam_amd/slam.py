@@ -13,7 +13,8 @@ Left out: visualiser, logger/checkpoints, mesher (SURVEY.md 8 "out of scope").
 import torch
 
 from .common import cam_pose_to_matrix, get_samples, matrix_to_cam_pose, predict_cam_pose
-from .step import MapStep, TrackStep
+from .mapstep import MapStep
+from .trackstep import TrackStep
 from .window import MapWindow
 
 DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
@@ -134,7 +135,7 @@ class Mapper:
         # launches on static buffers (window.MapWindow); the pools are looked at once for pixels without a depth
         extra = (10, 200) if (not s.tracking_back and len(kl) > 20) else None           # extra rays from the newest frames (:381-390)
         win = MapWindow(self.step, c2ws, depths, colors, dirs, pixs_per_image, joint_opt=joint, cam_lr=c["joint_opt_cam_lr"], extra=extra)
-        replay = bool(c.get("graph_replay", False)) and not win.has_zero and int(iters) >= 4
+        replay = bool(c.get("graph_replay", False)) and int(iters) >= 4
         if replay:
             win.capture()
         for _ in range(int(iters)):

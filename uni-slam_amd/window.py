@@ -31,7 +31,9 @@ class MapWindow:
         dirs [b,P,3]: the frames' pixel pools (camera-frame directions); n_per_frame = mapping_pixels // b (src/Mapper.py:315);
         extra: None | (n_frames, n_pixels): n_pixels more rays from each of the newest n_frames frames (src/Mapper.py:385-393: 10 x 200
                once the keyframe list has more than 20 entries and the tracker is not tracking back);
-        cam_lr: cfg['mapping']['joint_opt_cam_lr'] (src/Mapper.py:362); has_zero_depth: None -> look at the pools once (one host sync).
+        cam_lr: cfg['mapping']['joint_opt_cam_lr'] (src/Mapper.py:362); has_zero_depth: False -> every pool pixel carries a depth (the
+               zero-depth branch's launches are skipped); None / True -> the branch of src/utils/Renderer.py:104-130 runs with its row
+               count on the device (no host synchronisation: the caller need not look at the pools).
         """
         self.step = step
         dev = step.device
@@ -57,8 +59,8 @@ class MapWindow:
         self.ro, self.rd, self.gd, self.gc, self.dirs = f(self.R, 3), f(self.R, 3), f(self.R), f(self.R, 3), f(self.R, 3)
         self.idx_a = torch.zeros((b, self.n_per), dtype=torch.int64, device=dev)
         self.idx_b = torch.zeros(self.extra, dtype=torch.int64, device=dev) if self.extra else None
-        self.has_zero = bool((self.pool_d <= 0).any()) if has_zero_depth is None else bool(has_zero_depth)
-        self._graph, self.t_rand = None, None
+        self.has_zero = True if has_zero_depth is None else bool(has_zero_depth)
+        self._graph, self.t_rand, self.zd_draws = None, None, None
         if self.R > step.max_rays:
             step._alloc(self.R)
 
@@ -100,6 +102,8 @@ class MapWindow:
         b = self.b
         if t_rand is None:
             t_rand = self.t_rand                                 # the static jitter tensor of capture(t_rand=True), if any
+        if zero_depth_draws is None:
+            zero_depth_draws = self.zd_draws                     # ... and the static draws of the zero-depth branch
         poses = P(self.poses) if b > 1 else None
         nf, ne = self.extra if self.extra else (0, 0)
         if self.R > s.max_rays:
@@ -112,7 +116,8 @@ class MapWindow:
                                      ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
                                      P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
         if not self.joint_opt:
-            return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero, presampled=True)
+            return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero, presampled=True,
+                             zero_depth_draws=zero_depth_draws)
         if s.group is not None:
             raise L.UniSlamHipError("MapWindow: joint pose optimisation runs in a single process (the poses are not all-reduced)")
         s.store_dydx = True                                      # the encoder leaves dy/dx for the pose gradient (no second gather pass)
@@ -141,15 +146,12 @@ class MapWindow:
 
     # ------------------------------------------------------------------------------------------ hipGraph
     def capture(self, t_rand=False, device_draw=True):
-        """capture _launches() (no zero-depth branch: that one reads a row count on the host) into a hipGraph: replay() is ONE graph
+        """capture _launches() (the zero-depth branch included: its row count stays on the device) into a hipGraph: replay() is ONE graph
         launch, pixel draw included (device_draw; False: replay(indices) / torch.randint fill the static index tensors first).  The
         jitter comes from the in-kernel generator (varied per replay by the device-side step count) unless t_rand=True: then
-        self.t_rand [R,S] is a static input to fill.  The model, the optimiser state and the poses are left as they were."""
+        self.t_rand [R,S] (and, for a window with depth holes, self.zd_draws) are static inputs to fill.  The model, the optimiser state and the poses are left as they were."""
         from .graph import CapturedIteration
         s = self.step
-        if self.has_zero:
-            raise L.UniSlamHipError("MapWindow.capture: the pools hold pixels without a depth (the zero-depth branch reads a row count on "
-                                    "the host); run iterate() for this window")
         if s.group is not None:
             raise L.UniSlamHipError("MapWindow.capture: single-process only")
         if s._step_advanced:
@@ -157,6 +159,8 @@ class MapWindow:
         s._join_side_streams()
         was, s.probe = s.probe, None
         self.t_rand = torch.zeros((self.R, s.S), dtype=torch.float32, device=s.device) if t_rand else None
+        # (static draws of the zero-depth branch, indexed by the compacted row: jitter of the coarse pass [R, n_strat], inverse-transform draws [R, n_imp])
+        self.zd_draws = (torch.zeros((self.R, s.n_strat), device=s.device), torch.zeros((self.R, s.n_imp), device=s.device)) if (t_rand and self.has_zero) else None
         keep = (s.flat.clone(), s.m.clone(), s.v.clone(), s.step_dev.clone(), s.opt_step, dict(s.lr), s.rng_calls, self.poses.clone(),
                 self.pm.clone(), self.pv.clone(), self.cam_lr)
         s.lr = {k: 0.0 for k in s.lr}
