@@ -382,6 +382,150 @@ def joint_opt_bench(us, build_step, bound, dev, steps, warmup):
     return out
 
 
+def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
+    """
+    What ONE rank of the data-parallel step costs by itself: a 1-rank RCCL process group, so every collective of the step is
+    issued and waited for but moves nothing.  MapStep(group=True) in its two dp_modes: eager, replayed as hipGraph segments between the
+    collectives (graph.SegmentedGraph), and replayed as ONE graph that holds the RCCL calls (the default); with the poses fixed and with
+    joint_opt (rank-owned poses, src/Mapper.py:359-376).
+    """
+    import torch.distributed as dist
+    out = {"note": "1-rank RCCL group on this GPU: collectives issued and waited for, no bytes moved; 4096 rays x 64 over 16 keyframes"}
+    own_pg = not dist.is_initialized()
+    try:
+        if own_pg:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        c2ws, pd, pc, pr = keyframe_pools(N_KEYFRAMES, bound, 3000, dev)
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            rounds = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+                rounds.append(1e3 * (time.perf_counter() - t0) / steps)
+            return sorted(rounds)[1]
+
+        for mode in ("local_fast", "colour_first"):
+            o = {}
+            for tag, jo in (("poses_fixed", False), ("joint_opt", True)):
+                step = build_step(group=True, dp_mode=mode)[0]
+                win = us.MapWindow(step, c2ws, pd, pc, pr, 4096 // N_KEYFRAMES, joint_opt=jo, cam_lr=1e-3, has_zero_depth=False)
+                o[tag + "_eager_ms"] = timed(win.iterate)
+                win.capture(collectives="between")
+                o[tag + "_graph_segments_ms"] = timed(win.replay)
+                o[tag + "_graph_segments"] = len(win._graph.segments)
+                win.capture()                                # RCCL: the collectives captured into the ONE graph (the default)
+                o[tag + "_replayed_ms"] = timed(win.replay)
+            out[mode] = o
+        step = build_step(group=True, dp_mode="local_fast")[0]
+        step.sharded_adam = True
+        win = us.MapWindow(step, c2ws, pd, pc, pr, 4096 // N_KEYFRAMES, joint_opt=False, has_zero_depth=False)
+        win.capture()
+        out["local_fast_sharded_adam"] = {"poses_fixed_replayed_ms": timed(win.replay), "note": "reduce-scatter + Adam on this rank's shard "
+                                          "(1 rank: the whole buffer) + all-gather"}
+    except Exception as e:                                # report, do not hide
+        out["error"] = repr(e)[:400]
+    finally:
+        if own_pg and dist.is_initialized():
+            dist.destroy_process_group()
+    return out
+
+
+SCANNET_BOUND = [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]]          # configs/ScanNet/scene0000.yaml:3
+SCANNET_CAM = dict(H=460, W=620, fx=577.590698, fy=578.729797, cx=308.702667, cy=232.809998)   # scannet.yaml:37-44 after crop_edge 10
+
+
+def config3_bench(us, dev, prec, steps, warmup):
+    """
+    BASELINE configs[2]: ScanNet scene0000, 8192 rays x 96 samples (80 stratified + 16 surface), tables log2T 16 / 16 at 2 cm (res 456),
+    lr 0.02 (configs/ScanNet/scannet.yaml:12-18,25,46-47), the reference's ScanNet decoders (2 hidden x 16 with bias,
+    src/networks/decoders.py:74-84), uncertainty-gated loss (m_mask_mode original), 25 % of the pool pixels WITHOUT a depth: those rays take
+    the importance-sampling branch of src/utils/Renderer.py:104-130 every iteration -- its row count stays on the device, so the
+    iteration is replayed from one hipGraph like the headline.  16 keyframes x 512 pixels; poses fixed, and with joint_opt.
+    """
+    out = {"workload": "BASELINE configs[2]: ScanNet scene0000 geometry, 8192 rays x 96 samples (80 + 16), L=16 F=2 tables log2T 16 / 16 res 456, 2 hidden x 16 "
+                       "decoders with bias, uncertainty-gated loss, 25 % of the pixels without a depth (zero-depth branch in every iteration, "
+                       "row count on the device), dense Adam; 16 keyframe pools x 512 pixels drawn inside the replayed graph"}
+    try:
+        global CAM
+        bound = load_bound(SCANNET_BOUND)
+        res = int((bound[:, 1] - bound[:, 0]).max() / 0.02)
+        pls = per_level_scale(res)
+        R, ns, ni, b = 8192, 80, 16, N_KEYFRAMES
+        S, N = ns + ni, 8192 * 96
+        cam_was, CAM = CAM, SCANNET_CAM
+        try:
+            c2ws, pd, pc, pr = keyframe_pools(b, bound, 4000, dev)
+        finally:
+            CAM = cam_was
+        g = torch.Generator().manual_seed(7)
+        holes = (torch.rand(pd.shape, generator=g) < 0.25).to(dev)
+        pd = torch.where(holes, torch.zeros_like(pd), pd)
+
+        def build():
+            torch.manual_seed(0)
+            mk = lambda: us.HashGridEncoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 16,
+                                                 "base_resolution": 16, "per_level_scale": pls}).to(dev)
+            cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
+            dec = us.Decoders(cfg, c_dim=32, hidden_size=16, truncation=0.06, n_blocks=2).to(dev)
+            return us.MapStep(mk(), mk(), dec, bound, ns, ni, 0.06, W, dict(decoders=0.001, sdf_grid=0.02, color_grid=0.02), mask_mode="original",
+                              max_rays=R)
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            rounds = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    loss = fn()
+                torch.cuda.synchronize()
+                rounds.append(1e3 * (time.perf_counter() - t0) / steps)
+            return sorted(rounds)[1], float(loss)
+
+        step = build()
+        win = us.MapWindow(step, c2ws, pd, pc, pr, R // b, joint_opt=False, has_zero_depth=None)
+        win.capture()
+        ms, loss = timed(win.replay)
+        n0 = int(step.zd_count)
+        out.update({"mapping_iter_ms": ms, "rays_per_s": R / (ms / 1e3), "samples_per_s": N / (ms / 1e3), "final_loss": loss, "rays": R,
+                    "samples_per_ray": S, "zero_depth_rays_last_iteration": n0, "n_params": int(step.n_flat),
+                    "launch": "hipGraph replay of MapWindow (pixel draw + sampling + zero-depth branch + iteration in one graph)"})
+        step.probe, step.probe_every, step._it = {}, 1, 0
+        for _ in range(10):
+            win.iterate()
+        torch.cuda.synchronize()
+        kern = {k: _median([a.elapsed_time(c) for a, c in v]) for k, v in step.probe.items()}
+        step.probe = None
+        if "hashgrid_bwd_joint" in kern and "hashgrid_scan_joint" in kern:
+            kern["hashgrid_bwd_joint"] += kern.pop("hashgrid_scan_joint")
+        out["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
+        alg = {"hashgrid_fwd_joint": 2 * 1024 * N, "hashgrid_bwd_joint": 2 * 2048 * N}
+        out["roofline"] = {k: {"bound": "hbm", "achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg[k],
+                               "avg_launch_ms": kern[k], "traffic": None} for k in alg if k in kern}
+        out["algorithmic_table_bytes_per_step"] = sum(alg.values())
+        step2 = build()
+        win2 = us.MapWindow(step2, c2ws, pd, pc, pr, R // b, joint_opt=True, cam_lr=1e-3, has_zero_depth=None)
+        win2.capture()
+        ms2, _ = timed(win2.replay)
+        out["joint_opt_iteration_ms"] = ms2
+        pd_full = torch.where(holes, torch.ones_like(pd), pd)
+        step3 = build()
+        win3 = us.MapWindow(step3, c2ws, pd_full, pc, pr, R // b, joint_opt=False, has_zero_depth=False)
+        win3.capture()
+        out["without_depth_holes_ms"] = timed(win3.replay)[0]
+    except Exception as e:                                # report, do not hide
+        out["error"] = repr(e)[:400]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     global torch
@@ -389,6 +533,11 @@ def run_rank(args):
     if wd > 0:                                                     # stacks of all its threads to stderr (where does a stuck rank wait?)
         import faulthandler
         faulthandler.dump_traceback_later(wd, repeat=False, file=sys.stderr)
+    # stdout carries ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for the whole run (RCCL prints a version banner to
+    # stdout when its first communicator comes up, other libraries may chat too), the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch as _torch
     torch = _torch
     import unislam_amd as us
@@ -415,7 +564,7 @@ def run_rank(args):
     # N > 1 default: plain fp32 all-reduce in two announced segments, the colour table's hidden behind the sdf branch
     sharded, comm = args.sharded_adam, args.grad_comm
 
-    def build_step(prec, table_std=None):
+    def build_step(prec, table_std=None, group="auto", dp_mode=None):
         torch.manual_seed(0)
         cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
         dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
@@ -424,24 +573,26 @@ def run_rank(args):
             with torch.no_grad():
                 es.params.normal_(0.0, table_std); ec.params.normal_(0.0, table_std)
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
-                        group=True if world > 1 else None, bwd_mode=args.bwd_mode, overlap=False if args.no_overlap else None,
-                        grad_comm=comm, sharded_adam=sharded,
-                        joint=None if args.joint == "auto" else args.joint == "1", dp_mode=args.dp_mode)
+                        group=(True if world > 1 else None) if group == "auto" else group, bwd_mode=args.bwd_mode,
+                        overlap=False if args.no_overlap else None, grad_comm=comm, sharded_adam=sharded,
+                        joint=None if args.joint == "auto" else args.joint == "1", dp_mode=dp_mode or args.dp_mode)
         st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
 
     step, es, ec, dec = build_step(args.mlp_precision)
     if world > 1:
         broadcast_parameters(step.flat)
-    use_graph = world == 1 and not args.no_graph
 
     # ---- inputs: a fresh batch per step from the keyframe pools (src/Mapper.py:379-393), gathered into static tensors
     R = args.rays
     fresh = not args.fixed_batch and R % N_KEYFRAMES == 0
+    use_graph = not args.no_graph and (world == 1 or fresh)      # N > 1: the rank-local launches as hipGraph segments between the collectives
     f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
     if fresh:
         c2ws, pool_d, pool_c, pool_dirs = keyframe_pools(N_KEYFRAMES, bound, 1000 + rank, dev)
         P, n_per = pool_d.shape[1], R // N_KEYFRAMES
+
+    launch_kind = {"graph": use_graph}
 
     def make_runner(st):
         """returns (next_step() -> loss, static ray tensors): one call = pixel draw + ray assembly + iteration.  Fresh batches: a
@@ -449,9 +600,18 @@ def run_rank(args):
         sampling are ONE launch inside the replayed graph (us_window_sample)."""
         if fresh:
             win = us.MapWindow(st, c2ws, pool_d, pool_c, pool_dirs, n_per, joint_opt=False, has_zero_depth=False)
-            if use_graph:
-                win.capture()
-            return (win.replay if use_graph else win.iterate), (win.ro, win.rd, win.gd, win.gc)
+            graph = use_graph
+            if graph:
+                try:
+                    win.capture()                                # N > 1: hipGraph segments between the collectives (graph.SegmentedGraph)
+                except Exception as e:                           # a runtime that refuses the capture: the eager step is the same arithmetic
+                    print(f"[bench rank {rank}] graph capture failed, running eagerly: {e!r}"[:400], file=sys.stderr, flush=True)
+                    graph = False
+                if world > 1:
+                    from unislam_amd.dist import all_agree as _agree
+                    graph = _agree(graph, True, dev)
+            launch_kind["graph"] = graph
+            return (win.replay if graph else win.iterate), (win.ro, win.rd, win.gd, win.gc)
         ins = st.capture(R) if use_graph else (f32(R, 3), f32(R, 3), f32(R), f32(R, 3))
         for dst, src in zip(ins, synthetic_rays(R, bound, 1000 + rank, dev)):
             dst.copy_(src)
@@ -525,8 +685,9 @@ def run_rank(args):
                                     if fresh else "one fixed batch re-rendered every step"),
                           "parallelism": f"dp{world} (frames/rays sharded, {comm_desc})"},
                "rays_per_s_per_gpu": R / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss),
-               "launch": ("hipGraph replay of MapWindow.iterate (joint_opt off): pixel draw + gather + sampling in one launch, then MapStep.iterate"
-                          if (use_graph and fresh) else "hipGraph replay of MapStep.iterate" if use_graph else "eager")}
+               "launch": (("hipGraph replay of MapWindow.iterate (joint_opt off): pixel draw + gather + sampling in one launch, then MapStep.iterate"
+                           if world == 1 else "hipGraph segments of MapWindow.iterate between the collectives (statistics all-reduce, gradient segments)")
+                          if (use_graph and fresh and launch_kind["graph"]) else "hipGraph replay of MapStep.iterate" if (use_graph and not fresh) else "eager")}
         if kern is not None:
             rec["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
             rec["kernel_ms_note"] = f"median over {max(1, args.probe_steps)} eager one-stream iterations after the timed region"
@@ -552,6 +713,9 @@ def run_rank(args):
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]}
+            # the other table kernels beside the dominant one (the encoder is the largest SINGLE kernel of the iteration)
+            rec["roofline_by_kernel"] = {k: {"achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "unit": "GB/s", "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": kern[k]} for k in alg}
         if world == 1 and not args.no_extras:
             # also the forward-only rate (the render_img / meshing use) and the iteration without Adam
             def timed(fn, k=max(10, args.steps // 2)):
@@ -585,13 +749,18 @@ def run_rank(args):
             rec["trained_like_tables"] = side_run(build_step(args.mlp_precision, table_std=0.1)[0])
         if world == 1 and not args.no_extras:
             rec["joint_opt"] = joint_opt_bench(us, lambda: build_step(args.mlp_precision), bound, dev, args.steps, args.warmup)
+        if world == 1 and not args.no_extras:
+            rec["config3"] = config3_bench(us, dev, args.mlp_precision, max(10, args.steps // 2), args.warmup)
         if world == 1 and not args.no_tracking:
             rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
         if world == 1 and not args.no_tracking and not args.no_extras:
             rec["slam_frame"] = slam_bench(us, dev, args.hidden, args.mlp_precision)
+        if world == 1 and not args.no_extras:
+            rec["dp_rank_local_ms"] = dp_rank_local_bench(us, lambda **kw: build_step(args.mlp_precision, **kw), bound, dev, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(bound, n_strat, n_imp, args.hidden, R)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -268,3 +268,109 @@ def test_all_agree_keeps_rank_local_budgets_in_step():
     assert r0["flags"] == r1["flags"] == [False, True, False]
     from unislam_amd.dist import all_agree
     assert all_agree(True, None) is True and all_agree(False, None) is False       # no process group: the flag itself
+
+
+# ------------------------------------------------------------------------------------------------ joint_opt windows (src/Mapper.py:359-376)
+class WindowOracleEngine(OracleEngine):
+    """OracleEngine + the camera poses of THIS rank's share of a mapping window as one more (rank-local) Adam group: forward() builds the
+    rays of its frames from the poses under autograd (src/Mapper.py:372-380), backward() leaves the pose gradients, pose_step() is what
+    dist.dp_iterate runs as `before_adam`.  fixed_first: this rank holds the window's oldest frame, which stays fixed (:374)."""
+
+    def __init__(self, c2ws, depths, colors, dirs, fixed_first):
+        super().__init__()
+        self.depths, self.colors, self.dirs = depths, colors, dirs
+        self.c2w_first = c2ws[0] if fixed_first else None
+        self.poses = torch.nn.Parameter(O.matrix_to_cam_pose(c2ws[(1 if fixed_first else 0):]))
+        self.pose_opt = torch.optim.Adam([self.poses], lr=1e-3)
+
+    def forward(self, idx, t_rand):
+        mats = O.cam_pose_to_matrix(self.poses)
+        c2ws = mats if self.c2w_first is None else torch.cat([self.c2w_first[None], mats], dim=0)
+        ro, rd, gd, gc = O.get_samples_all(idx.shape[1], c2ws, self.depths, self.colors, self.dirs, idx)
+        super().forward(ro, rd, gd, gc, t_rand)
+
+    def backward(self, on_ready=None, ray_grads=False):
+        self.pose_opt.zero_grad()
+        return super().backward(on_ready)
+
+    def pose_step(self):
+        self.pose_opt.step()
+
+    def c2ws(self):
+        mats = O.cam_pose_to_matrix(self.poses.detach())
+        return mats if self.c2w_first is None else torch.cat([self.c2w_first[None], mats], dim=0)
+
+
+def make_window(B, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    c2ws = []
+    for _ in range(B):
+        q = torch.randn(4, generator=g); q = q / q.norm()
+        m = torch.eye(4); m[:3, :3] = O.quaternion_to_matrix(q[None])[0]; m[:3, 3] = torch.tensor([3.0, 1.2, 0.0]) + torch.randn(3, generator=g) * 0.05
+        c2ws.append(m)
+    dirs = torch.randn(B, P, 3, generator=g); dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    depths = torch.rand(B, P, generator=g) * 2 + 0.4
+    depths[:, ::6] = 30.0
+    return torch.stack(c2ws), depths, torch.rand(B, P, 3, generator=g), dirs
+
+
+def _window_draws(B, P, n, it):
+    g = torch.Generator().manual_seed(500 + it)
+    return torch.randint(P, (B, n), generator=g), torch.rand(B, n, 40, generator=g)
+
+
+def _worker_window(rank, world, port, out_path, B):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from unislam_amd.dist import dp_iterate, init_from_env, shard_frames
+    init_from_env(backend="gloo")
+    P, n = 40, 6
+    c2ws, depths, colors, dirs = make_window(B, P, 77)
+    own = shard_frames(B, rank, world)
+    eng = WindowOracleEngine(c2ws[own], depths[own], colors[own], dirs[own], fixed_first=(own[0] == 0))
+    losses = []
+    for it in range(3):
+        idx, tr = _window_draws(B, P, n, it)
+        losses.append(float(dp_iterate(eng, (idx[own], tr[own].reshape(-1, 40)), group=True, ray_grads=True, before_adam=eng.pose_step)))
+    flat = eng.flat()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    n_max = -(-B // world)
+    mine = torch.zeros(n_max, 4, 4); mine[:len(own)] = eng.c2ws()
+    poses = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(poses, mine)
+    if rank == 0:
+        assert all(torch.equal(gathered[0], g) for g in gathered[1:])  # the model replicas stay bit-identical
+        full = torch.zeros(B, 4, 4)
+        for k in range(world):
+            fr = shard_frames(B, k, world)
+            full[fr] = poses[k][:len(fr)]
+        np.savez(out_path, flat=flat.numpy(), losses=np.array(losses), c2ws=full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 6), (8, 8)])
+def test_ranks_equal_one_process_on_a_joint_opt_window(world, B):
+    """the reference's default mapping iteration (joint_opt: the window's poses are an Adam group, src/Mapper.py:359-376,443-459) data-parallel:
+    rank r owns the frames {f : f mod W == r} with their poses and pose moments; the step exchanges loss statistics and model gradients
+    only (a frame's rays live on one rank, so its pose gradient is complete there).  Model parameters AND poses equal one process on the
+    whole window; the oldest pose stays fixed."""
+    from unislam_amd.dist import dp_iterate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r0.npz")
+        mp.spawn(_worker_window, args=(world, port, out, B), nprocs=world, join=True)
+        res = np.load(out)
+    P, n = 40, 6
+    c2ws, depths, colors, dirs = make_window(B, P, 77)
+    eng = WindowOracleEngine(c2ws, depths, colors, dirs, fixed_first=True)
+    losses = []
+    for it in range(3):
+        idx, tr = _window_draws(B, P, n, it)
+        losses.append(float(dp_iterate(eng, (idx, tr.reshape(-1, 40)), group=None, ray_grads=True, before_adam=eng.pose_step)))
+    np.testing.assert_allclose(res["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(res["flat"], eng.flat().numpy(), rtol=1e-4, atol=1e-6)
+    one = eng.c2ws().numpy()
+    np.testing.assert_allclose(res["c2ws"], one, rtol=0, atol=2e-6)
+    assert np.array_equal(res["c2ws"][0], c2ws[0].numpy())                        # "we fix the oldest c2w", src/Mapper.py:374
+    assert np.abs(one[1:] - c2ws[1:].numpy()).max() > 1e-4                        # the others did move

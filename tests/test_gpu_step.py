@@ -335,6 +335,69 @@ def test_mapstep_ranks_on_one_gpu(tmp_path, world, variant):
         assert float((r0["flat"] - one).norm() / one.norm()) < 1e-3
 
 
+@pytest.mark.parametrize("world,variant", [(2, "window"), (2, "window_extra"), (2, "window_graph"), (2, "window_sharded"), (4, "window"),
+                                           (4, "window_graph")])
+def test_joint_opt_window_ranks_on_one_gpu(tmp_path, world, variant):
+    """The reference's DEFAULT mapping iteration (joint_opt, src/Mapper.py:359-376,443-459,518) data-parallel through the real kernels:
+    every rank process (gloo, all on cuda:0) owns the frames {f : f mod W == rank} of a 6-frame window with their poses and pose moments
+    (MapWindow.sharded), exchanges loss statistics and model gradients, and steps its own poses.  Model AND poses end as in ONE process
+    that renders the whole window; the replicas stay bit-identical; the oldest pose stays fixed.  window_extra: with the extra rays of the
+    newest frames (src/Mapper.py:385-393); window_graph: the rank-local launches replayed as hipGraph segments between the collectives
+    (graph.SegmentedGraph); window_sharded: reduce-scatter + sharded Adam + all-gather."""
+    import socket
+    import subprocess
+    import sys
+    import unislam_amd as us
+    import test_gpu_window as TW
+    from _dp_two_ranks import window_draws
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    out = str(tmp_path / "dpw")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_two_ranks.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), out, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0].decode()[-3000:])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    rs = [torch.load(f"{out}.{r}") for r in range(world)]
+    r0 = rs[0]
+    assert all(torch.equal(r0["flat"], r["flat"]) for r in rs[1:])               # model replicas bit-identical
+    assert all(torch.equal(r0["c2ws_all"], r["c2ws_all"]) for r in rs[1:])       # every rank collects the same window
+    assert all(r["step_dev"] == 3.0 for r in rs)
+    if variant == "window_graph":
+        assert all(r["segments"] >= 4 for r in rs)                               # forward | stats | ... colour | rest | finish ... Adam
+    # one process, the whole window, the same draws and jitter
+    B, P, n_per = 6, 300, 40
+    extra = (4, 15) if variant == "window_extra" else None
+    c2ws, depths, colors, dirs = TW._window(B, P, 31)
+    dec, es, ec = _scene(us, False, seed=11)
+    step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=B * n_per + (60 if extra else 0))
+    win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=False)
+    losses = []
+    for it in range(3):
+        idx, idx2, tr, tr2 = window_draws(B, P, n_per, extra, 40, it)
+        t_rand = tr.reshape(-1, 40) if not extra else torch.cat([tr.reshape(-1, 40), tr2.reshape(-1, 40)])
+        losses.append(float(win.iterate(idx.to(DEV), idx2.to(DEV) if extra else None, t_rand=t_rand.to(DEV))))
+    np.testing.assert_allclose(r0["losses"], losses, rtol=2e-4)
+    one = step.flat.detach().cpu()
+    close = torch.isclose(r0["flat"], one, rtol=1e-4, atol=2e-5)
+    assert float((~close).float().mean()) < 1e-3, float((~close).float().mean())
+    assert float((r0["flat"] - one).norm() / one.norm()) < 1e-3
+    ref = win.c2ws().cpu()
+    assert torch.equal(r0["c2ws_all"][0], c2ws[0])                               # "we fix the oldest c2w", src/Mapper.py:374
+    # Adam on 7 numbers per pose, lr 1e-3: three steps move an entry by <= 3e-3; a gradient component at rounding level may take another sign
+    assert float((r0["c2ws_all"] - ref).abs().max()) < 2e-4, float((r0["c2ws_all"] - ref).abs().max())
+    assert float((ref[1:] - c2ws[1:]).abs().max()) > 1e-3                        # the poses did move
+    from unislam_amd.dist import shard_frames
+    for r in range(world):                                                       # a rank's own view = its frames of the gathered window
+        assert torch.equal(rs[r]["c2ws"], r0["c2ws_all"][shard_frames(B, r, world)])
+
+
 def test_sharded_adam_rank_without_elements_keeps_its_step_count():
     """MapStep.adam_step(ranges) on a range that holds no parameter (a rank that owns only padding) still advances the device-side
     step count: it is Adam's bias-correction step and the salt of the sampler's jitter, and has to agree on every rank."""

@@ -25,99 +25,141 @@ def _pg(group):
     return None if group is True else group
 
 
-def dp_iterate(engine, batch, group=None, grad_comm=None):
+class GradComm:
+    """
+    The collectives of one data-parallel optimiser step, as operations that can be issued eagerly or between the hipGraph segments of a
+    captured step (graph.SegmentedGraph): stats() -- the 40-byte all-reduce of the loss sums / counts; announce(view) -> op -- notes a
+    finished contiguous segment of engine.grad and returns the operation that starts its reduction (asynchronously: RCCL runs it on
+    its own stream, ordered after the kernels queued so far); finish() -- waits for all of them (stream-level for RCCL) and widens a
+    bf16 payload again; sharded: ranges() for engine.adam_step and gather() for the updated parameter slices.
+
+    payload "fp32": the gradient travels as it is (N ranks reproduce one process on the concatenated batch).  "bf16": every announced
+    segment is rounded to bfloat16 for the reduction (half the xGMI bytes; not bit-faithful to one process); "bf16_colour": only the
+    colour table's segment is.  sharded: each segment is
+    reduce-scattered in place, Adam runs on the 1/W slices this rank owns, the parameter slices are all-gathered.
+    """
+
+    def __init__(self, engine, group, grad_comm=None, sharded=None):
+        self.engine, self.group, self.pg = engine, group, _pg(group)
+        if grad_comm is None:
+            grad_comm = getattr(engine, "grad_comm", None)
+        if grad_comm not in (None, "fp32", "bf16", "bf16_colour", torch.bfloat16, torch.float32):
+            raise ValueError(f"dp_iterate: grad_comm {grad_comm!r} not in (None, 'fp32', 'bf16', 'bf16_colour')")
+        self.narrow = grad_comm in ("bf16", "bf16_colour", torch.bfloat16)
+        # "bf16_colour": only segments inside the colour table travel as bfloat16 (44.7 of the 51.7 MB of room0; they feed the colour
+        # decoder alone -- the geometry, i.e. sdf table, decoders and beta, keeps its fp32 sum over the ranks)
+        self.narrow_from = int(getattr(engine, "o_tab_c", 0)) if grad_comm == "bf16_colour" else 0
+        self.sharded = bool(getattr(engine, "sharded_adam", False) if sharded is None else sharded)
+        if self.sharded and self.narrow:                    # refused before any work is queued
+            raise ValueError("dp_iterate: a bf16 gradient payload and sharded Adam are exclusive (the reduce-scatter works in place "
+                             "on the fp32 gradient buffer)")
+        self.W, self.r = dist.get_world_size(self.pg), dist.get_rank(self.pg)
+        self.nccl = dist.get_backend(self.pg) == "nccl"
+        self.segments = []                                  # (lo, n) of the announced segments, in announcement order
+        self.works = []
+
+    # -- operations (each one is also a valid `op` of SegmentedGraph.cut)
+    def stats(self):
+        self.works = []
+        dist.all_reduce(self.engine.stats, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def announce(self, view):
+        e = self.engine
+        n = view.numel()
+        lo = (view.data_ptr() - e.grad.data_ptr()) // view.element_size()      # index of the segment in the flat buffers
+        if self.sharded and n % self.W:
+            raise ValueError(f"sharded Adam: a gradient segment of {n} elements does not split over {self.W} ranks")
+        self.segments.append((lo, n))
+        if self.sharded:
+            sz = n // self.W
+            mine = view[self.r * sz:(self.r + 1) * sz]
+
+            def op():
+                if self.nccl:                               # in place: slice r of the input
+                    w = dist.reduce_scatter_tensor(mine, view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                else:                                       # gloo has no reduce-scatter: the all-reduce leaves the same values in the slice
+                    w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self.works.append((w, None, None))
+            return op
+        buf = view
+        if self.narrow and lo >= self.narrow_from:          # one bf16 image of the gradient buffer, allocated once: its slices are the payloads
+            img = getattr(e, "_grad_bf16", None)
+            if img is None or img.shape != e.grad.shape or img.device != e.grad.device:
+                img = e._grad_bf16 = torch.empty_like(e.grad, dtype=torch.bfloat16)
+            buf = img[lo:lo + n]
+
+        def op():
+            if buf is not view:
+                buf.copy_(view)
+            self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), view, buf))
+        return op
+
+    def finish(self):
+        for w, view, buf in self.works:
+            w.wait()
+            if buf is not view:
+                view.copy_(buf)
+        self.works = []
+
+    def ranges(self):
+        return [(lo + self.r * (n // self.W), lo + (self.r + 1) * (n // self.W)) for lo, n in self.segments]
+
+    def gather(self):
+        e, W, r = self.engine, self.W, self.r
+        ws = []
+        for lo, n in self.segments:
+            sz = n // W
+            whole = e.flat[lo:lo + n]
+            if self.nccl:                                   # in place
+                ws.append(dist.all_gather_into_tensor(whole, whole[r * sz:(r + 1) * sz], group=self.pg, async_op=True))
+            else:
+                ws.append(dist.all_gather([whole[k * sz:(k + 1) * sz] for k in range(W)], whole[r * sz:(r + 1) * sz].clone(), group=self.pg,
+                                          async_op=True))
+        for w in ws:
+            w.wait()
+
+
+def dp_iterate(engine, batch, group=None, grad_comm=None, ray_grads=False, before_adam=None, cut=None, comm=None):
     """
     One optimiser step. group: None (single process) | True (default process group) | a process group.
     grad_comm: None / "fp32" -> the gradient travels as it is; "bf16" -> every announced segment is rounded to bfloat16 for
     the all-reduce and widened again before Adam (half the bytes on xGMI; the sum over ranks then carries bf16 rounding, so
     N ranks no longer reproduce one process bit for bit -- opt-in, for when the all-reduce bounds the step).
+    ray_grads: engine.backward also forms dL/d(rays) (the joint pose optimisation of src/Mapper.py:359-376); before_adam(): the caller's
+    rank-local work between the backward pass and the optimiser (MapWindow: the pose step of the frames this rank owns -- a frame's rays
+    live on ONE rank, so its pose gradient needs no reduction), queued while the gradient segments travel.
+    cut: None -> every collective is issued where it stands (eager); a SegmentedGraph's cut -> the rank-local launches are being
+    captured, each collective ends a graph segment and runs between the segments at replay time.
 
     Overlap: engine.backward(on_ready) calls on_ready(view) as soon as a contiguous segment of engine.grad is final; each
     segment's all-reduce is issued asynchronously right then (RCCL runs it on its own stream, ordered after the kernels
     launched so far) and overlaps with the rest of the backward pass.  MapStep finishes the 44.7 MB colour-table segment
-    first, so its reduction hides behind the SDF decoder + SDF table backward; all segments are waited for before Adam.
+    first, so its reduction hides behind the SDF table's share of the backward pass; all segments are waited for before Adam.
     """
-    if grad_comm is None:
-        grad_comm = getattr(engine, "grad_comm", None)
-    narrow = grad_comm in ("bf16", torch.bfloat16)
-    sharded = group is not None and getattr(engine, "sharded_adam", False)
-    if sharded and narrow:                              # refused before any work is queued
-        raise ValueError("dp_iterate: a bf16 gradient payload and sharded Adam are exclusive (the reduce-scatter works in place "
-                         "on the fp32 gradient buffer)")
+    if group is None:
+        engine.forward(*batch)
+        loss = engine.backward(**({"ray_grads": True} if ray_grads else {}))
+        if before_adam is not None:
+            before_adam()
+        engine.adam_step()
+        return loss
+    if comm is None:
+        comm = GradComm(engine, group, grad_comm)
+    comm.segments = []
+    run = (lambda op: op()) if cut is None else cut
     engine.forward(*batch)
-    if group is not None:
-        dist.all_reduce(engine.stats, op=dist.ReduceOp.SUM, group=_pg(group))
-    if sharded:
-        return _finish_sharded(engine, group)
-    works = []
-
-    def on_ready(view):
-        if group is not None:
-            buf = view
-            if narrow:                                  # one bf16 image of the gradient buffer, allocated once: its slices are the payloads
-                img = getattr(engine, "_grad_bf16", None)
-                if img is None or img.shape != engine.grad.shape or img.device != engine.grad.device:
-                    img = engine._grad_bf16 = torch.empty_like(engine.grad, dtype=torch.bfloat16)
-                lo = (view.data_ptr() - engine.grad.data_ptr()) // view.element_size()
-                buf = img[lo:lo + view.numel()]
-                buf.copy_(view)
-            works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_pg(group), async_op=True), view, buf))
-
-    loss = engine.backward(on_ready if group is not None else None)     # (a single process has no use for per-segment readiness)
-    if group is not None:
-        if not works:                                   # an engine that does not announce segments: one reduction at the end
-            on_ready(engine.grad)
-        for w, view, buf in works:
-            w.wait()
-            if buf is not view:
-                view.copy_(buf)
-    engine.adam_step()
-    return loss
-
-
-def _finish_sharded(engine, group):
-    """
-    The same step with the optimiser sharded over the ranks ("reduce-scatter + sharded Adam + all-gather"): every
-    announced gradient segment is reduce-scattered (rank r receives the sum of slice r), Adam runs on the slices this rank owns
-    (1/W of the 7 x 51.7 MB of optimiser traffic, 1/W of the moment memory in use), and the updated parameter slices are
-    all-gathered.  Same bytes on the wire as the all-reduce, replicas stay identical.  Needs engine.flat / engine.grad (flat
-    buffers with the same indexing), segments whose length is a multiple of the world size, and engine.adam_step(ranges=...).
-    gloo has no reduce-scatter: there (CPU tests) the segment is all-reduced, which leaves the same values in the slice.
-    """
-    pg = _pg(group)
-    W, r = dist.get_world_size(pg), dist.get_rank(pg)
-    nccl = dist.get_backend(pg) == "nccl"
-    pending = []
-
-    def on_ready(view):
-        n = view.numel()
-        if n % W:
-            raise ValueError(f"sharded Adam: a gradient segment of {n} elements does not split over {W} ranks")
-        sz = n // W
-        lo = (view.data_ptr() - engine.grad.data_ptr()) // view.element_size()     # index of the segment in the flat buffers
-        mine = view[r * sz:(r + 1) * sz]
-        if nccl:
-            w = dist.reduce_scatter_tensor(mine, view, op=dist.ReduceOp.SUM, group=pg, async_op=True)   # in place: slice r of the input
-        else:
-            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=pg, async_op=True)
-        pending.append((w, lo, n, sz))
-
-    loss = engine.backward(on_ready)
-    if not pending:
-        on_ready(engine.grad)
-    for w, _, _, _ in pending:
-        w.wait()
-    engine.adam_step(ranges=[(lo + r * sz, lo + (r + 1) * sz) for _, lo, _, sz in pending])
-    gathers = []
-    for _, lo, n, sz in pending:
-        whole = engine.flat[lo:lo + n]
-        if nccl:
-            gathers.append(dist.all_gather_into_tensor(whole, whole[r * sz:(r + 1) * sz], group=pg, async_op=True))   # in place
-        else:
-            gathers.append(dist.all_gather([whole[k * sz:(k + 1) * sz] for k in range(W)], whole[r * sz:(r + 1) * sz].clone(), group=pg,
-                                           async_op=True))
-    for w in gathers:
-        w.wait()
+    run(comm.stats)
+    loss = engine.backward(lambda view: run(comm.announce(view)), **({"ray_grads": True} if ray_grads else {}))
+    if not comm.segments:                                   # an engine that does not announce segments: one reduction at the end
+        run(comm.announce(engine.grad))
+    if before_adam is not None:
+        before_adam()
+    run(comm.finish)
+    if comm.sharded:
+        engine.adam_step(ranges=comm.ranges())
+        run(comm.gather)
+    else:
+        engine.adam_step()
     return loss
 
 

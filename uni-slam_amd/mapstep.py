@@ -68,6 +68,7 @@ class MapStep:
         self.decoder_pair = True        # the two decoders, where they have one shape, as one launch each way (a launch costs ~5 us whatever it computes)
         self._dec_grad_clean = False
         self._step_advanced = False
+        self._scan_pending = self._side_pending = False          # work queued on the scan / side stream since its last join
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
         # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
         # window.MapWindow for the iterations that optimise camera poses (src/Mapper.py:372-376); costs 2 x 24 B per point and level.
@@ -81,9 +82,9 @@ class MapStep:
         # the gradient tables, the others adding: 4096 x 64 needs 0.8 GB, the 32 768-ray sweep point 6.6 GB -> two ranges.
         self.max_ws = int(max_workspace_bytes)
         self.count_in_forward, self._counted = True, False
-        self.grad_comm = grad_comm      # None/"fp32" | "bf16": payload type of the gradient all-reduce (dist.dp_iterate)
+        self.grad_comm = grad_comm      # None/"fp32" | "bf16" | "bf16_colour": payload type of the gradient all-reduce (dist.GradComm)
         self.sharded_adam = bool(sharded_adam)   # dist.dp_iterate: reduce-scatter, Adam on this rank's shard, all-gather
-        if self.sharded_adam and grad_comm in ("bf16", torch.bfloat16):
+        if self.sharded_adam and grad_comm in ("bf16", "bf16_colour", torch.bfloat16):
             raise L.UniSlamHipError("MapStep: grad_comm='bf16' and sharded_adam=True are exclusive (the reduce-scatter runs in place on "
                                     "the fp32 gradient buffer); choose one")
         self.rng_seed, self.rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0    # in-kernel jitter / pixel-draw generator
@@ -180,9 +181,13 @@ class MapStep:
     def _join_side_streams(self):
         """the main stream waits for whatever a previous call left on the scan / side streams (the scans of a forward pass whose backward
         pass never came read the workspace; a queued step increment touches step_dev)"""
-        for q in (getattr(self, "scan_stream", None), getattr(self, "side", None)):
-            if q is not None:
-                torch.cuda.current_stream().wait_stream(q)
+        # (only streams that hold work since their last join: a wait for an idle side stream is harmless when launched eagerly, but inside
+        #  a hipGraph capture it would tie the capturing stream to an event recorded outside the capture)
+        if getattr(self, "_scan_pending", False) and self.scan_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.scan_stream)
+        if getattr(self, "_side_pending", False) and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._scan_pending = self._side_pending = False
 
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self, R):
@@ -260,6 +265,7 @@ class MapStep:
                 s.side.wait_event(self.after)
             else:
                 s.side.wait_stream(torch.cuda.current_stream())
+            s._side_pending = True
             self.ctx = torch.cuda.stream(s.side)
             self.ctx.__enter__()
             return L.stream()
@@ -273,8 +279,14 @@ class MapStep:
         return MapStep._Branch(self, after)
 
     def _join(self):
-        if self.overlap and not self._probing and self.side is not None:
+        if self.overlap and not self._probing and self.side is not None and self._side_pending:
             torch.cuda.current_stream().wait_stream(self.side)
+            self._side_pending = False
+
+    def _wait_scans(self):
+        if self.scan_stream is not None and self._scan_pending:
+            torch.cuda.current_stream().wait_stream(self.scan_stream)
+            self._scan_pending = False
 
     def _timed(self, name, rc_fn):
         """run one C-ABI launch; with self.probe set, bracket it with HIP events on the launch stream"""
@@ -365,8 +377,7 @@ class MapStep:
         if self.joint and backward_follows:
             # both encoders in one launch (cells, positions and hashes computed once; the binning counts of both grids ride along),
             # then the two decoders side by side
-            if self.scan_stream is not None:                     # a scan of the previous call may still read the workspace
-                torch.cuda.current_stream().wait_stream(self.scan_stream)
+            self._wait_scans()                                   # a scan of the previous call may still read the workspace
             self._jcounted = True
             self._dydx_valid = False
             if self.store_dydx:
@@ -400,6 +411,7 @@ class MapStep:
                     self.scan_stream.wait_event(ev)
                 else:
                     self.scan_stream.wait_stream(torch.cuda.current_stream())
+                self._scan_pending = True
                 with torch.cuda.stream(self.scan_stream):
                     L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
                     if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
@@ -570,8 +582,7 @@ class MapStep:
                     if not self._step_advanced:
                         L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st2), "us_adam_step_inc")
                         self._step_advanced = True
-            if self.scan_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.scan_stream)
+            self._wait_scans()
             jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
             if on_ready is not None:
                 # someone waits for the segments (the data-parallel step): the record pass for both grids, then the accumulate pass per

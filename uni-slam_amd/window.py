@@ -11,8 +11,11 @@ i.e. for nearly the whole sequence.  Per iteration the reference runs
 through autograd.  Here the same iteration is a fixed sequence of HIP launches on static buffers -- us_window_rays (quaternion ->
 rotation -> gather + rotate), MapStep.forward / backward (+ us_hashgrid_bwd_input_rays: both grids' input gradient reduced to the
 rays in one launch), us_pose_window_step (per-frame pose gradient + Adam), MapStep.adam_step -- with no torch autograd and no host
-synchronisation, so it can be captured into ONE hipGraph (capture() / replay(); the pixel draw stays outside the graph).
+synchronisation, so it can be captured into ONE hipGraph (capture() / replay(), pixel draw included).
 With joint_opt off the window is the same machine without the pose step (the poses then never move).
+Data-parallel (a process group on the MapStep): MapWindow.sharded() gives every rank its share of the window's frames; a frame's rays
+live on one rank, so its pose and the pose's Adam state do too -- the iteration exchanges loss statistics and model gradients only, and
+c2ws_all() collects the poses when the window is done.
 """
 import ctypes
 
@@ -23,7 +26,8 @@ from .common import cam_pose_to_matrix, matrix_to_cam_pose
 
 
 class MapWindow:
-    def __init__(self, step, c2ws, depths, colors, dirs, n_per_frame, joint_opt=True, cam_lr=1e-3, extra=None, has_zero_depth=None):
+    def __init__(self, step, c2ws, depths, colors, dirs, n_per_frame, joint_opt=True, cam_lr=1e-3, extra=None, has_zero_depth=None,
+                 fixed_first=True):
         """
         step: MapStep (owns the model, the optimiser state and the render buffers; call step.reset_optimizer() first, as
               Mapper.optimize_mapping builds a fresh Adam per mapped frame, src/Mapper.py:358-364);
@@ -31,6 +35,8 @@ class MapWindow:
         dirs [b,P,3]: the frames' pixel pools (camera-frame directions); n_per_frame = mapping_pixels // b (src/Mapper.py:315);
         extra: None | (n_frames, n_pixels): n_pixels more rays from each of the newest n_frames frames (src/Mapper.py:385-393: 10 x 200
                once the keyframe list has more than 20 entries and the tracker is not tracking back);
+        fixed_first: frame 0 is the window's oldest frame and keeps its pose (src/Mapper.py:374).  False: every frame given here is
+               optimised -- a data-parallel rank whose share of the window does not hold the oldest frame (MapWindow.sharded);
         cam_lr: cfg['mapping']['joint_opt_cam_lr'] (src/Mapper.py:362); has_zero_depth: False -> every pool pixel carries a depth (the
                zero-depth branch's launches are skipped); None / True -> the branch of src/utils/Renderer.py:104-130 runs with its row
                count on the device (no host synchronisation: the caller need not look at the pools).
@@ -41,13 +47,17 @@ class MapWindow:
         if b < 1 or c2ws.shape != (b, 4, 4) or colors.shape != (b, P, 3) or dirs.shape != (b, P, 3):
             raise L.UniSlamHipError("MapWindow: c2ws [b,4,4], depths [b,P], colors [b,P,3], dirs [b,P,3] expected")
         self.b, self.P, self.n_per = b, P, int(n_per_frame)
-        self.joint_opt = bool(joint_opt) and b > 1
+        self.first = 1 if fixed_first else 0                       # frames [first, b) are optimised: pose j belongs to frame j + first
+        self.joint_opt = bool(joint_opt) and b > self.first
         self.cam_lr = float(cam_lr)
         self.pool_d, self.pool_c, self.pool_r = L.f32(depths.to(dev)), L.f32(colors.to(dev)), L.f32(dirs.to(dev))
         c2ws = L.f32(c2ws.detach().to(dev))
-        self.c2w_first = c2ws[0].clone()
-        n_p = max(b - 1, 1)
-        self.poses = matrix_to_cam_pose(c2ws[1:]).contiguous() if b > 1 else torch.zeros((1, 7), device=dev)   # src/Mapper.py:360
+        self.c2w_first = c2ws[0].clone() if fixed_first else None
+        n_p = max(b - self.first, 1)
+        # (With joint_opt off the reference renders from the matrices as given, src/Mapper.py:377-378; here frames first.. always pass
+        #  through quaternion + translation, src/common.py:182-208 -- an fp32 round trip of ~1e-7 that also re-orthonormalises a pose
+        #  that is not exactly a rotation.)
+        self.poses = matrix_to_cam_pose(c2ws[self.first:]).contiguous() if b > self.first else torch.zeros((1, 7), device=dev)   # src/Mapper.py:360
         self.pm, self.pv = torch.zeros((n_p, 7), device=dev), torch.zeros((n_p, 7), device=dev)
         self.g_pose = torch.zeros((n_p, 7), device=dev)
         if extra is not None and (extra[0] <= 0 or extra[1] <= 0):
@@ -61,6 +71,7 @@ class MapWindow:
         self.idx_b = torch.zeros(self.extra, dtype=torch.int64, device=dev) if self.extra else None
         self.has_zero = True if has_zero_depth is None else bool(has_zero_depth)
         self._graph, self.t_rand, self.zd_draws = None, None, None
+        self._comm, self._shard = None, None                      # data-parallel: dist.GradComm of the step; (own frames, B, group) of sharded()
         if self.R > step.max_rays:
             step._alloc(self.R)
 
@@ -80,7 +91,7 @@ class MapWindow:
     def rays(self):
         """(rays_o, rays_d, gt_depth, gt_color) of the drawn pixels (self.idx_a / idx_b) at the current poses: us_window_rays alone"""
         lib, st, P, b = L.lib(), L.stream(), L.ptr, self.b
-        poses = P(self.poses) if b > 1 else None
+        poses = P(self.poses) if b > self.first else None
         L.check(lib.us_window_rays(P(self.c2w_first), poses, P(self.pool_d), P(self.pool_c), P(self.pool_r), P(self.idx_a), self.P, 0, b,
                                    self.n_per, P(self.ro), P(self.rd), P(self.gd), P(self.gc), P(self.dirs), st), "us_window_rays")
         if self.extra:
@@ -94,17 +105,19 @@ class MapWindow:
     def _off(self, t, rows, width):
         return ctypes.c_void_p(t.data_ptr() + 4 * rows * width)
 
-    def _launches(self, t_rand=None, zero_depth_draws=None, device_draw=False):
+    def _launches(self, t_rand=None, zero_depth_draws=None, device_draw=False, cut=None):
         """everything after the draw: rays from the current poses + samples (ONE launch: us_window_sample; with device_draw it also
         draws the pixels, like the jitter from a counter-based generator salted with the device-side step count), render + loss +
-        backward, pose step, Adam"""
+        backward, pose step, Adam.  With a process group on the MapStep the same launches run as a data-parallel step (dist.dp_iterate):
+        loss statistics and gradient segments are reduced over the ranks, the pose step stays rank-local (a frame's rays live on one
+        rank); cut: the SegmentedGraph hook of capture()."""
         lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
         b = self.b
         if t_rand is None:
             t_rand = self.t_rand                                 # the static jitter tensor of capture(t_rand=True), if any
         if zero_depth_draws is None:
             zero_depth_draws = self.zd_draws                     # ... and the static draws of the zero-depth branch
-        poses = P(self.poses) if b > 1 else None
+        poses = P(self.poses) if b > self.first else None
         nf, ne = self.extra if self.extra else (0, 0)
         if self.R > s.max_rays:
             s._alloc(self.R)
@@ -115,28 +128,44 @@ class MapWindow:
                                      s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation),
                                      ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
                                      P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
+        if s.group is not None:
+            from .dist import dp_iterate, GradComm
+            if self._comm is None or self._comm.engine is not s:
+                self._comm = GradComm(s, s.group)
+            s.store_dydx = self.joint_opt                        # the encoder leaves dy/dx for the pose gradient (no second gather pass)
+            try:
+                return dp_iterate(s, (self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws, True, True), s.group,
+                                  ray_grads=self.joint_opt, before_adam=self._pose_step if self.joint_opt else None, cut=cut, comm=self._comm)
+            finally:
+                s.store_dydx = False
         if not self.joint_opt:
             return s.iterate(self.ro, self.rd, self.gd, self.gc, t_rand=t_rand, has_zero_depth=self.has_zero, presampled=True,
                              zero_depth_draws=zero_depth_draws)
-        if s.group is not None:
-            raise L.UniSlamHipError("MapWindow: joint pose optimisation runs in a single process (the poses are not all-reduced)")
-        s.store_dydx = True                                      # the encoder leaves dy/dx for the pose gradient (no second gather pass)
+        s.store_dydx = True
         try:
             s.forward(self.ro, self.rd, self.gd, self.gc, t_rand, self.has_zero, zero_depth_draws, presampled=True)
         finally:
             s.store_dydx = False
         loss = s.backward(ray_grads=True, fold=True)              # (adam_step() below sums the decoder-gradient partials itself)
-        g_o, g_d = s.g_o, s.g_d
+        self._pose_step()
+        s.adam_step()
+        return loss
+
+    def _pose_step(self):
+        """gradient + Adam of the poses this window optimises (one workgroup per pose), from the ray gradients the backward pass left"""
+        lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
+        b, first = self.b, self.first
+        nf, ne = self.extra if self.extra else (0, 0)
         if not s._step_advanced:                                 # the poses are one more group of the SAME optimiser: one step count
             L.check(lib.us_adam_step_inc(P(s.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
             s._step_advanced = True
         lr = self.cam_lr                                         # the pose group is appended with its plain lr (src/Mapper.py:362): no lr_factor
-        # pose j = window frame j + 1: rows [(j+1) n_per, (j+2) n_per) of the first block, and rows of the extra block for the newest nf frames
-        L.check(lib.us_pose_window_step(P(self.poses), b - 1, P(g_o), P(g_d), P(self.dirs), self.n_per, self.n_per, max(b - nf - 1, 0),
-                                        self.R_a + (ne if (nf == b and nf > 0) else 0), ne if nf else 0, P(self.pm), P(self.pv), P(self.g_pose),
+        # pose j = window frame j + first: rows [(j + first) n_per, (j + first + 1) n_per) of the first block, and -- for the newest nf
+        # frames, b - nf .. b - 1 -- ne rows each of the extra block behind it
+        f_b = max(b - nf, first)                                 # the first optimised frame that owns rows of the extra block
+        L.check(lib.us_pose_window_step(P(self.poses), b - first, P(s.g_o), P(s.g_d), P(self.dirs), first * self.n_per, self.n_per, f_b - first,
+                                        self.R_a + (f_b - (b - nf)) * ne, ne if nf else 0, P(self.pm), P(self.pv), P(self.g_pose),
                                         lr, lr, 0.9, 0.999, 1e-8, P(s.step_dev), 0, st), "us_pose_window_step")
-        s.adam_step()
-        return loss
 
     def iterate(self, indices=None, indices_extra=None, t_rand=None, zero_depth_draws=None):
         """one eager iteration; returns the loss tensor [1] (device).  indices None: the pixels are drawn inside us_window_sample"""
@@ -145,45 +174,75 @@ class MapWindow:
         return self._launches(t_rand, zero_depth_draws, device_draw=indices is None)
 
     # ------------------------------------------------------------------------------------------ hipGraph
-    def capture(self, t_rand=False, device_draw=True):
+    def capture(self, t_rand=False, device_draw=True, collectives=None):
         """capture _launches() (the zero-depth branch included: its row count stays on the device) into a hipGraph: replay() is ONE graph
         launch, pixel draw included (device_draw; False: replay(indices) / torch.randint fill the static index tensors first).  The
         jitter comes from the in-kernel generator (varied per replay by the device-side step count) unless t_rand=True: then
-        self.t_rand [R,S] (and, for a window with depth holes, self.zd_draws) are static inputs to fill.  The model, the optimiser state and the poses are left as they were."""
-        from .graph import CapturedIteration
+        self.t_rand [R,S] (and, for a window with depth holes, self.zd_draws) are static inputs to fill.  The model, the optimiser state
+        and the poses are left as they were.  With a process group on the MapStep every rank must call capture() (its warm-up iterations
+        hold collectives); collectives: see below."""
+        from .graph import CapturedIteration, SegmentedGraph
         s = self.step
-        if s.group is not None:
-            raise L.UniSlamHipError("MapWindow.capture: single-process only")
         if s._step_advanced:
             raise L.UniSlamHipError("MapWindow.capture: a forward pass of the MapStep is pending; finish its optimiser step first")
         s._join_side_streams()
-        was, s.probe = s.probe, None
+        self._graph = None
         self.t_rand = torch.zeros((self.R, s.S), dtype=torch.float32, device=s.device) if t_rand else None
         # (static draws of the zero-depth branch, indexed by the compacted row: jitter of the coarse pass [R, n_strat], inverse-transform draws [R, n_imp])
         self.zd_draws = (torch.zeros((self.R, s.n_strat), device=s.device), torch.zeros((self.R, s.n_imp), device=s.device)) if (t_rand and self.has_zero) else None
+        # warm-up iterations would move the model: they run with all learning rates at zero, and EVERYTHING they touch is put back in the
+        # `finally` below -- also when a warm-up iteration or the capture itself raises, so that a caller who catches the error can go on
+        # with iterate() on an intact optimiser state
         keep = (s.flat.clone(), s.m.clone(), s.v.clone(), s.step_dev.clone(), s.opt_step, dict(s.lr), s.rng_calls, self.poses.clone(),
-                self.pm.clone(), self.pv.clone(), self.cam_lr)
+                self.pm.clone(), self.pv.clone(), self.cam_lr, s.probe)
         s.lr = {k: 0.0 for k in s.lr}
         self.cam_lr = 0.0
-        self.draw()
+        s.probe = None
         self._device_draw = bool(device_draw)
-        run = lambda: self._launches(device_draw=self._device_draw)
-        try:
-            side = torch.cuda.Stream(device=s.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    run()
-            torch.cuda.current_stream().wait_stream(side)
-        finally:
+        graph, side = None, None
+
+        def restore():
             s.lr, self.cam_lr = keep[5], keep[10]
-        s.flat.copy_(keep[0]); s.m.copy_(keep[1]); s.v.copy_(keep[2]); s.step_dev.copy_(keep[3])
-        self.poses.copy_(keep[7]); self.pm.copy_(keep[8]); self.pv.copy_(keep[9])
-        s.opt_step, s.rng_calls = keep[4], keep[6]
-        s._dec_grad_clean = False
-        self._graph = CapturedIteration(run, warmup=0)
-        s.opt_step = keep[4]
-        s.probe = was
+            s.flat.copy_(keep[0]); s.m.copy_(keep[1]); s.v.copy_(keep[2]); s.step_dev.copy_(keep[3])
+            self.poses.copy_(keep[7]); self.pm.copy_(keep[8]); self.pv.copy_(keep[9])
+            s.opt_step, s.rng_calls = keep[4], keep[6]
+            s._dec_grad_clean = False                            # the captured backward clears the decoder gradient itself
+            s._step_advanced = False
+            s._folded = False
+
+        try:
+            try:
+                self.draw()
+                side = torch.cuda.Stream(device=s.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._launches(device_draw=self._device_draw)
+            finally:
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                restore()                                        # the real learning rates are what the capture records
+            if s.group is None:
+                graph = CapturedIteration(lambda: self._launches(device_draw=self._device_draw), warmup=0)
+            else:
+                # data-parallel: the rank-local launches as hipGraph segments, the collectives between them (dist.dp_iterate's `cut`)
+                # collectives "inside" (default over RCCL): the process group's calls are captured INTO the one graph -- RCCL kernels as graph
+                # nodes, one launch per step: measured 0.536 ms of rank-local time against 0.585 eager and 0.642 with "between" (each
+                # segment boundary leaves the GPU idle for a graph launch); "between" (default over gloo, which cannot be captured): the
+                # collectives stay eager between hipGraph segments
+                import torch.distributed as dist
+                from .dist import _pg
+                if collectives is None:
+                    collectives = "inside" if dist.get_backend(_pg(s.group)) == "nccl" else "between"
+                if collectives not in ("inside", "between"):
+                    raise L.UniSlamHipError(f"MapWindow.capture: collectives {collectives!r} not in ('inside', 'between')")
+                inside = collectives == "inside"
+                graph = SegmentedGraph(lambda cut: self._launches(device_draw=self._device_draw, cut=(lambda op: op()) if inside else cut),
+                                       join=s._join_side_streams)
+        finally:
+            restore()                                            # (the capture pass does not execute; its host-side counters are undone)
+            s.probe = keep[11]
+        self._graph = graph
 
     def replay(self, indices=None, indices_extra=None):
         if self._graph is None:
@@ -198,7 +257,57 @@ class MapWindow:
 
     # ------------------------------------------------------------------------------------------ results
     def c2ws(self):
-        """the window's poses now: [b,4,4] (frame 0 as given; the others from the optimised quaternion / translation, src/Mapper.py:449)"""
-        if self.b == 1:
-            return self.c2w_first[None].clone()
-        return torch.cat([self.c2w_first[None], cam_pose_to_matrix(self.poses)], dim=0)
+        """this window's poses now: [b,4,4] (a fixed first frame as given; the others from the optimised quaternion / translation,
+        src/Mapper.py:449).  Of a sharded window: the frames THIS rank owns (c2ws_all() collects the whole window)."""
+        opt = [cam_pose_to_matrix(self.poses)] if self.b > self.first else []
+        return torch.cat(([self.c2w_first[None]] if self.first else []) + opt, dim=0).clone()
+
+    # ------------------------------------------------------------------------------------------ data-parallel
+    @classmethod
+    def sharded(cls, step, c2ws, depths, colors, dirs, n_per_frame, joint_opt=True, cam_lr=1e-3, extra=None, has_zero_depth=None):
+        """
+        The window of a data-parallel mapping step (step.group set): every rank is handed the WHOLE window (B frames, the
+        oldest first) and keeps the frames {f : f mod W == rank} -- n_per_frame rays from each, and its frames' share of the extra rays
+        of the newest frames.  The rank that owns frame 0 keeps it fixed (src/Mapper.py:374).  Poses, their Adam moments and their
+        gradients are rank-local for the whole loop: the iteration all-reduces the loss statistics and the model gradients, nothing else.
+        """
+        import torch.distributed as dist
+        from .dist import shard_frames, _pg
+        if step.group is None:
+            raise L.UniSlamHipError("MapWindow.sharded: the MapStep has no process group")
+        pg = _pg(step.group)
+        W, r = dist.get_world_size(pg), dist.get_rank(pg)
+        B = depths.shape[0]
+        own = shard_frames(B, r, W)
+        if not own:
+            raise L.UniSlamHipError(f"MapWindow.sharded: {B} frames do not give rank {r} of {W} a frame")
+        if extra is not None:                                    # the newest extra[0] frames of the WINDOW: those of them this rank owns
+            k = sum(1 for f in own if f >= B - min(int(extra[0]), B))
+            extra = (k, int(extra[1])) if k else None
+        sel = torch.as_tensor(own, device=depths.device)
+        pick = lambda t: t.index_select(0, sel.to(t.device))
+        win = cls(step, pick(c2ws), pick(depths), pick(colors), pick(dirs), n_per_frame, joint_opt, cam_lr, extra, has_zero_depth,
+                  fixed_first=(own[0] == 0))
+        win._shard = (own, B, pg)
+        return win
+
+    def c2ws_all(self):
+        """[B,4,4]: the poses of the whole window, every rank's frames at their window positions (one all-gather, when the loop is done:
+        src/Mapper.py:447-457 writes them back to the keyframes)"""
+        if self._shard is None:
+            return self.c2ws()
+        import torch.distributed as dist
+        from .dist import shard_frames
+        own, B, pg = self._shard
+        W = dist.get_world_size(pg)
+        n_max = -(-B // W)
+        mine = torch.zeros((n_max, 4, 4), dtype=torch.float32, device=self.poses.device)
+        mine[:len(own)] = self.c2ws()
+        parts = [torch.empty_like(mine) for _ in range(W)]
+        dist.all_gather(parts, mine, group=pg)
+        out = torch.empty((B, 4, 4), dtype=torch.float32, device=mine.device)
+        for k in range(W):
+            fr = shard_frames(B, k, W)
+            if fr:
+                out[torch.as_tensor(fr, device=out.device)] = parts[k][:len(fr)]
+        return out
