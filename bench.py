@@ -54,8 +54,11 @@ def parse_args(argv=None):
                     help="MFMA operand type of the decoders.  bf16 (headline): v_mfma_f32_16x16x32_bf16 with split operands (hi + lo) in the "
                          "forward products -- rendered depth / colour within 4e-5 of the fp32 decoders on identical parameters "
                          "(tools/bf16_deviation.py; bound 1e-3), bf16 operands in the gradient products; fp32: f32-input MFMA throughout")
-    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
-                    help="payload type of the gradient all-reduce (N > 1); bf16 halves the xGMI bytes, not bit-faithful to one process")
+    ap.add_argument("--grad-comm", default="bf16_colour", choices=["fp32", "bf16", "bf16_colour"],
+                    help="payload type of the gradient all-reduce (N > 1).  bf16_colour (default): the colour table's segment -- 44.7 of the 51.7 MB -- "
+                         "travels as bfloat16, the geometry (sdf table, decoders, beta) as fp32: a 15-iteration window converges to the same map "
+                         "(held-out depth 7e-7, colour 8e-6 from fp32 gradients; tests/test_gpu_step.py); fp32: N ranks reproduce one process on "
+                         "the concatenated batch to rounding; bf16: everything narrow")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--dp-mode", default="local_fast", choices=["local_fast", "colour_first"],
@@ -423,8 +426,7 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
                 win.capture()                                # RCCL: the collectives captured into the ONE graph (the default)
                 o[tag + "_replayed_ms"] = timed(win.replay)
             out[mode] = o
-        step = build_step(group=True, dp_mode="local_fast")[0]
-        step.sharded_adam = True
+        step = build_step(group=True, dp_mode="local_fast", sharded_adam=True)[0]
         win = us.MapWindow(step, c2ws, pd, pc, pr, 4096 // N_KEYFRAMES, joint_opt=False, has_zero_depth=False)
         win.capture()
         out["local_fast_sharded_adam"] = {"poses_fixed_replayed_ms": timed(win.replay), "note": "reduce-scatter + Adam on this rank's shard "
@@ -563,8 +565,10 @@ def run_rank(args):
                                             "log2_hashmap_size": l2, "base_resolution": 16, "per_level_scale": pls}).to(dev)
     # N > 1 default: plain fp32 all-reduce in two announced segments, the colour table's hidden behind the sdf branch
     sharded, comm = args.sharded_adam, args.grad_comm
+    if sharded:
+        comm = "fp32"                                                                    # (the reduce-scatter works in place on the fp32 buffer)
 
-    def build_step(prec, table_std=None, group="auto", dp_mode=None):
+    def build_step(prec, table_std=None, group="auto", dp_mode=None, sharded_adam=None):
         torch.manual_seed(0)
         cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
         dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
@@ -574,7 +578,8 @@ def run_rank(args):
                 es.params.normal_(0.0, table_std); ec.params.normal_(0.0, table_std)
         st = us.MapStep(es, ec, dec, bound, n_strat, n_imp, 0.06, W, LR, max_rays=args.rays,
                         group=(True if world > 1 else None) if group == "auto" else group, bwd_mode=args.bwd_mode,
-                        overlap=False if args.no_overlap else None, grad_comm=comm, sharded_adam=sharded,
+                        overlap=False if args.no_overlap else None, grad_comm="fp32" if sharded_adam else comm,
+                        sharded_adam=sharded if sharded_adam is None else sharded_adam,
                         joint=None if args.joint == "auto" else args.joint == "1", dp_mode=dp_mode or args.dp_mode)
         st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
@@ -666,7 +671,7 @@ def run_rank(args):
         S = n_strat + n_imp
         N = R * S
         comm_desc = ("reduce-scatter + sharded Adam + all-gather" if sharded else "all-reduce") + \
-                    f" of {(4 if comm == 'fp32' else 2) * step.n_flat / 1e6:.1f} MB {comm} grads per step" + (f", dp_mode {args.dp_mode}" if world > 1 else "")
+                    f" of {(4 * step.n_flat if comm == 'fp32' else 2 * step.n_flat if comm == 'bf16' else 4 * step.o_tab_c + 2 * (step.n_flat - step.o_tab_c)) / 1e6:.1f} MB {comm} grads per step" + (f", dp_mode {args.dp_mode}" if world > 1 else "")
         rec = {"metric": "rays/s (64 samples, L=16 hash, 2x32 MLP), Replica room0 mapping iteration",
                "value": world * R / (ms / 1e3), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",

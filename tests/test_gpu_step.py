@@ -948,6 +948,58 @@ def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():
     assert dev(d0, d1) < 1e-3 and dev(c0, c1) < 1e-3
 
 
+def test_bf16_gradient_payload_does_not_change_what_a_window_converges_to():
+    """The data-parallel step's payload options (dist.GradComm) on the convergence bar of the test above: a 15-iteration window from
+    identical state, identical draws -- single process (fp32 gradients) against a process group whose colour-table segment ("bf16_colour")
+    or whole gradient ("bf16") passes through bfloat16 on its way to Adam (1-rank RCCL group: every contribution is rounded once, as each
+    rank's is).  Held-out view: depth / colour within 1e-3 norm-wise; with "bf16_colour" the depth does not move at all beyond the fp32
+    noise floor (the geometry's gradients stay fp32)."""
+    import socket
+    import torch.distributed as dist
+    import unislam_amd as us
+    from unislam_amd.synthetic import SyntheticRoom
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        R, iters, nf = 2048, 15, 4
+        room = SyntheticRoom(n_frames=12, H=96, W=128, device=DEV)
+        bound = O.load_bound([[-0.5, 6.5], [-1.1, 3.5], [-1.7, 1.5]])
+        frames = [room[k] for k in (0, 3, 6, 9)]
+        held = room[5]
+        c2ws = torch.stack([f[3] for f in frames])
+        depths = torch.stack([f[2].reshape(-1) for f in frames]); colors = torch.stack([f[1].reshape(-1, 3) for f in frames])
+        dirs = torch.stack([f[4].reshape(-1, 3) for f in frames])
+        ecfg = lambda l2: {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2, "base_resolution": 16,
+                           "per_level_scale": O.per_level_scale(int((bound[:, 1] - bound[:, 0]).max() / 0.02))}
+        outs = []
+        for group, comm in ((None, None), (True, "bf16_colour"), (True, "bf16"), (True, None)):
+            torch.manual_seed(0)
+            dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+            es, ec = us.HashGridEncoding(3, ecfg(14)).to(DEV), us.HashGridEncoding(3, ecfg(15)).to(DEV)
+            step = us.MapStep(es, ec, dec, bound, 32, 8, 0.06, W, LR, max_rays=R, group=group, grad_comm=comm)
+            step.rng_seed = 1234                                                 # (a group salts the sampler's seed with the rank; the draws here are given)
+            win = us.MapWindow(step, c2ws, depths, colors, dirs, R // nf, joint_opt=False, has_zero_depth=False)
+            g = torch.Generator().manual_seed(1)
+            losses = []
+            for _ in range(iters):
+                idx = torch.randint(depths.shape[1], (nf, R // nf), generator=g).to(DEV)
+                losses.append(float(win.iterate(idx, t_rand=torch.rand(R, 40, generator=g).to(DEV))))
+            assert losses[-1] < 0.5 * losses[0]
+            rend = us.Renderer({"rendering": {"perturb": False, "n_stratified": 32, "n_importance": 8}, "scale": 1, "grid_mode": "hash_grid"},
+                               types.SimpleNamespace(bound=bound, device=DEV, H=room.H, W=room.W, fx=room.fx, fy=room.fy, cx=room.cx, cy=room.cy))
+            out = rend.render_img(([es], [ec]), dec, held[3], 0.06, DEV, gt_depth=held[2])
+            outs.append((out[0].float(), out[1].float()))
+        dev = lambda a, b: float((a - b).norm() / a.norm())
+        (d0, c0), (d1, c1), (d2, c2), (d3, c3) = outs
+        print("payload bf16_colour vs fp32:", dev(d0, d1), dev(c0, c1), " bf16:", dev(d0, d2), dev(c0, c2), " fp32 over the group:", dev(d0, d3), dev(c0, c3))
+        assert dev(d0, d3) < 1e-5 and dev(c0, c3) < 1e-5                          # the group by itself changes nothing but summation order
+        assert dev(d0, d1) < 1e-5 and dev(c0, c1) < 1e-3                          # colour payload: the depth is untouched
+        assert dev(d0, d2) < 1e-3 and dev(c0, c2) < 1e-3
+    finally:
+        dist.destroy_process_group()
+
+
 def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
     """iterate() (single process, joint kernels, bf16 decoder pair): the decoder-gradient and beta reductions run inside the decoders'
     optimiser launch (us_mlp_reduce_pair_adam).  Same parameters, moments and gradients, bit for bit, as forward() + backward() +
