@@ -215,8 +215,11 @@ enum { US_ACT_NONE = 0, US_ACT_TANH = 1, US_ACT_SIGMOID = 2 };
 /* MFMA operand type; accumulation, parameters and parameter gradients are always fp32.
  * US_PREC_BF16: bf16 MFMA (v_mfma_f32_16x16x32_bf16) with SPLIT operands in the forward products (x = hi + lo, W x = W_hi x_hi +
  * W_hi x_lo + W_lo x_hi: operands good to 2^-16), plain bf16 operands in the gradient products; US_PREC_BF16_PLAIN: one MFMA per
- * product everywhere (operands good to 2^-8: rendered colour deviates 1.4e-3 from the fp32 decoders). */
-enum { US_PREC_F32 = 0, US_PREC_BF16 = 1, US_PREC_BF16_PLAIN = 2 };
+ * product everywhere (operands good to 2^-8: rendered colour deviates 1.4e-3 from the fp32 decoders); US_PREC_F16: f16 MFMA
+ * (v_mfma_f32_16x16x32_f16), ONE product per layer, operands good to 2^-11 -- the arithmetic of the reference's tcnn FullyFusedMLP
+ * (src/networks/decoders.py:50-70) --, inputs pre-scaled by a constant and the gradient chain by a per-chunk power of two so that
+ * f16's exponent range does not reach the results (csrc/mlp_bf16.inc). */
+enum { US_PREC_F32 = 0, US_PREC_BF16 = 1, US_PREC_BF16_PLAIN = 2, US_PREC_F16 = 3 };
 
 typedef struct us_mlp_desc {
     uint32_t n_in;        /* 32 */

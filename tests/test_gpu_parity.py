@@ -283,19 +283,24 @@ def _bf(x):
 @pytest.mark.parametrize("width,n_hidden,n_out,act,bias,n", [
     (16, 1, 1, "tanh", False, 1000), (16, 2, 3, "sigmoid", True, 4099), (32, 2, 1, "tanh", True, 8192 + 17),
     (32, 2, 3, "sigmoid", True, 70001), (32, 1, 3, "sigmoid", False, 333), (64, 2, 3, "sigmoid", True, 5000), (64, 1, 1, "none", True, 31)])
-@pytest.mark.parametrize("prec", ["bf16", "bf16_plain"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16_plain", "f16"])
 def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n, prec):
-    """bf16 MFMA decoders against a torch emulation that rounds the MFMA operands to bf16 (tight) and against fp32.
+    """bf16 / f16 MFMA decoders against a torch emulation that rounds the MFMA operands to that type (tight) and against fp32.
     bf16_plain: every operand of every product rounded once.  bf16 (US_PREC_BF16, the default): the forward products carry split
-    operands (hi + lo), so outputs and activations are fp32-accurate (1e-4) and only the gradient products see bf16 operands."""
+    operands (hi + lo), so outputs and activations are fp32-accurate (1e-4) and only the gradient products see bf16 operands.
+    f16 (US_PREC_F16): one product with f16 operands (2^-11) everywhere -- the reference's tcnn arithmetic, src/networks/decoders.py:50-70 --,
+    the gradient chain scaled per chunk; the dL/dout handed in spans eight decades, as loss gradients do."""
     g = torch.Generator().manual_seed(width * 7 + n_hidden)
     desc = us.make_mlp_desc(32, width, n_hidden, n_out, act, bias, prec)
-    assert desc.precision == {"bf16": 1, "bf16_plain": 2}[prec]
+    assert desc.precision == {"bf16": 1, "bf16_plain": 2, "f16": 3}[prec]
     shapes = [(width, 32)] + [(width, width)] * (n_hidden - 1) + [(16, width)]
     n_p = us.network.mlp_n_params(desc)
     params = (torch.rand(n_p, generator=g) * 2 - 1) * 0.4
     x = torch.randn(n, 32, generator=g)
     dy = torch.randn(n, n_out, generator=g)
+    if prec == "f16":                                            # f16's exponent range must not show: gradients from 1e-9 to 1e-1, features at 1e-4
+        dy = dy * torch.pow(10.0, -1.0 - 8.0 * torch.rand(n, 1, generator=g))
+        x[: n // 2] *= 1e-4
     ws, bs, o = [], [], 0
     for (a, b) in shapes:
         ws.append(params[o:o + a * b].view(a, b)); o += a * b
@@ -319,7 +324,10 @@ def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n, prec):
         gp = torch.cat([t.reshape(-1) for t in gw[::-1]] + ([t for t in gb[::-1]] if bias else []))
         return y, d, gp
     ident = lambda t: t
-    y_e, dx_e, gp_e = run(_bf) if prec == "bf16_plain" else run(_bf, ident)
+    def _hf(t):                                                  # 11 significant bits at any exponent (the kernel's scalings keep f16's range out)
+        m, e = torch.frexp(t)
+        return torch.ldexp(torch.round(m * 2048.0) / 2048.0, e)
+    y_e, dx_e, gp_e = run(_bf) if prec == "bf16_plain" else run(_hf) if prec == "f16" else run(_bf, ident)
     y_f, dx_f, gp_f = run(ident)
     pg = params.to(DEV).requires_grad_(True); xg = x.to(DEV).requires_grad_(True)
     y = us.fused_mlp(xg, pg, desc)
@@ -327,12 +335,20 @@ def test_mlp_bf16(us, width, n_hidden, n_out, act, bias, n, prec):
     # last-matrix rows >= n_out receive no gradient in either implementation
     def rel(a, b):
         return ((a.cpu() - b).norm() / (b.norm() + 1e-12)).item()
-    gtol = 3e-3 if prec == "bf16_plain" else 1e-2                # (the emulation of the mixed path does not model where its sums round)
+    gtol = 3e-3 if prec in ("bf16_plain", "f16") else 1e-2       # (the emulation of the mixed path does not model where its sums round)
     assert rel(y, y_e) < 2e-3 and rel(xg.grad, dx_e) < gtol and rel(pg.grad, gp_e) < gtol, (rel(y, y_e), rel(xg.grad, dx_e), rel(pg.grad, gp_e))
     if prec == "bf16":
         # split operands: the forward pass is fp32-accurate; the gradients carry one bf16 rounding per operand of their products
         assert rel(y, y_f) < 1e-4 and (y.cpu() - y_f).abs().max().item() < 2e-4, (rel(y, y_f), (y.cpu() - y_f).abs().max().item())
         assert rel(xg.grad, dx_f) < 1e-2 and rel(pg.grad, gp_f) < 1e-2, (rel(xg.grad, dx_f), rel(pg.grad, gp_f))
+    elif prec == "f16":
+        # 8 x finer operands than bf16_plain: outputs to ~1e-3; gradients: ReLU masks at rounding distance from 0 flip (half of the inputs
+        # are scaled to 1e-4 here, so without biases every pre-activation of those rows sits near 0) -- the tight check is the emulation above
+        assert rel(y, y_f) < 3e-3 and rel(xg.grad, dx_f) < 0.15 and rel(pg.grad, gp_f) < 0.15, (rel(y, y_f), rel(xg.grad, dx_f), rel(pg.grad, gp_f))
+        # a point's input gradient is as good relative to ITS OWN size whatever the size (per-chunk scale): the rows with the smallest dL/dout
+        small = dy.abs().amax(1) < 1e-6
+        if int(small.sum()) > 8:
+            assert rel(xg.grad[small.to(DEV)], dx_e[small]) < 1e-2, rel(xg.grad[small.to(DEV)], dx_e[small])
     else:
         # vs fp32: ReLU masks of neurons whose pre-activation is within bf16 rounding of 0 flip, so gradients differ by a few %
         assert rel(y, y_f) < 2e-2 and rel(xg.grad, dx_f) < 0.15 and rel(pg.grad, gp_f) < 0.08, (rel(y, y_f), rel(xg.grad, dx_f), rel(pg.grad, gp_f))

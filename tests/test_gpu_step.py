@@ -141,7 +141,7 @@ def test_mapstep_bench_shape_runs_and_decreases_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
 def test_mapstep_full_size_against_oracle(prec):
     """BASELINE cfg2 at its full size -- 4096 rays x 64 samples (48 + 16), room0 tables (log2T 16 / 19, res 816), 2 x 32 MLP -- one
     mapping iteration against the CPU oracle on the same rays and jitter: rendered depth / colour within 1e-3 relative (the
@@ -169,8 +169,15 @@ def test_mapstep_full_size_against_oracle(prec):
     step = us.MapStep(es, ec, dec, BOUND, 48, 16, 0.06, W, LR, max_rays=R)
     loss = step.forward_backward(ro, rd, gd, gc, t_rand=t_rand.to(DEV), has_zero_depth=False)
     term, unc, depth, rgb = [t.cpu() for t in step.rendered()[:4]]
-    np.testing.assert_allclose(depth.numpy(), ret_o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(rgb.numpy(), ret_o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
+    if prec == "f16":
+        # one f16 product per layer (the reference's tcnn arithmetic): inside the north star's 1e-3 norm-wise with a factor 5 to spare, the
+        # worst single ray at 2e-3 -- which is why the split-operand bf16 kernels, not these, are the bench's decoders
+        for a, b in ((depth, ret_o[2].detach()), (rgb, ret_o[3].detach())):
+            assert float((a - b).norm() / b.norm()) < 3e-4
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=5e-3, atol=1e-5)
+    else:
+        np.testing.assert_allclose(depth.numpy(), ret_o[2].detach().numpy(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(rgb.numpy(), ret_o[3].detach().numpy(), rtol=1e-3, atol=1e-5)
     m_o = (gd.cpu() > 0) & ((1 - ret_o[1].detach()) > 0.99)
     assert abs(int(step.stats[9]) - int(m_o.sum())) <= 2          # rays sitting on the 0.99 opacity threshold may flip
     np.testing.assert_allclose(float(loss), float(loss_o), rtol=1e-3)
@@ -926,7 +933,7 @@ def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():
     ecfg = lambda l2: {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2, "base_resolution": 16,
                        "per_level_scale": O.per_level_scale(int((bound[:, 1] - bound[:, 0]).max() / 0.02))}
     outs = []
-    for prec, joint in (("fp32", True), ("bf16", True), ("fp32", False)):
+    for prec, joint in (("fp32", True), ("bf16", True), ("fp32", False), ("f16", True)):
         torch.manual_seed(0)
         dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": prec}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
         es, ec = us.HashGridEncoding(3, ecfg(14)).to(DEV), us.HashGridEncoding(3, ecfg(15)).to(DEV)
@@ -942,10 +949,12 @@ def test_bf16_gradient_products_do_not_change_what_a_window_converges_to():
                            types.SimpleNamespace(bound=bound, device=DEV, H=room.H, W=room.W, fx=room.fx, fy=room.fy, cx=room.cx, cy=room.cy))
         out = rend.render_img(([es], [ec]), dec, held[3], 0.06, DEV, gt_depth=held[2])
         outs.append((out[0].float(), out[1].float()))
-    (d0, c0), (d1, c1), (d2, c2) = outs
+    (d0, c0), (d1, c1), (d2, c2), (d3, c3) = outs
     dev = lambda a, b: float((a - b).norm() / a.norm())
-    print("bf16 vs fp32:", dev(d0, d1), dev(c0, c1), " fp32 one-grid kernels vs fp32 joint kernels:", dev(d0, d2), dev(c0, c2))
+    print("bf16 vs fp32:", dev(d0, d1), dev(c0, c1), " fp32 one-grid kernels vs fp32 joint kernels:", dev(d0, d2), dev(c0, c2),
+          " f16 vs fp32:", dev(d0, d3), dev(c0, c3))
     assert dev(d0, d1) < 1e-3 and dev(c0, c1) < 1e-3
+    assert dev(d0, d3) < 1e-3 and dev(c0, c3) < 1e-3                              # f16 operands, one product (US_PREC_F16)
 
 
 def test_bf16_gradient_payload_does_not_change_what_a_window_converges_to():

@@ -7,8 +7,9 @@ import unislam_amd as us
 from unislam_amd import _lib as L
 DEV = "cuda:0"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 lib, st = L.lib(), L.stream()
-ds = us.make_mlp_desc(32, 32, 2, 1, "tanh", True, "bf16"); dc = us.make_mlp_desc(32, 32, 2, 3, "sigmoid", True, "bf16")
+ds = us.make_mlp_desc(32, 32, 2, 1, "tanh", True, prec); dc = us.make_mlp_desc(32, 32, 2, 3, "sigmoid", True, prec)
 ps = torch.randn(us.network.mlp_n_params(ds), device=DEV) * 0.3; pc = torch.randn(us.network.mlp_n_params(dc), device=DEV) * 0.3
 fa, fb = torch.randn(16, n, 2, device=DEV), torch.randn(16, n, 2, device=DEV)
 raw, d_raw = torch.empty(n, 4, device=DEV), torch.randn(n, 4, device=DEV)
@@ -34,5 +35,5 @@ def t(fn, reps=50):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-print(f"n {n}: fwd_pair {t(fwd):.1f} us  bwd_pair {t(bwd):.1f} us  bwd_pair (input gradients only) {t(bwd_in):.1f} us  "
+print(f"{prec} n {n}: fwd_pair {t(fwd):.1f} us  bwd_pair {t(bwd):.1f} us  bwd_pair (input gradients only) {t(bwd_in):.1f} us  "
       f"bwd_pair (parameter gradients only) {t(bwd_w):.1f} us")

@@ -554,7 +554,7 @@ static int check_mlp(const char* fn, const us_mlp_desc* d) {
     US_REQUIRE(d->n_hidden == 1 || d->n_hidden == 2, US_ERR_CONFIG, "%s: n_hidden %u not in {1,2}", fn, d->n_hidden);
     US_REQUIRE(d->n_out >= 1 && d->n_out <= 16, US_ERR_CONFIG, "%s: n_out %u not in 1..16", fn, d->n_out);
     US_REQUIRE(d->out_act <= US_ACT_SIGMOID, US_ERR_CONFIG, "%s: out_act %u", fn, d->out_act);
-    US_REQUIRE(d->precision <= US_PREC_BF16_PLAIN, US_ERR_CONFIG, "%s: precision %u", fn, d->precision);
+    US_REQUIRE(d->precision <= US_PREC_F16, US_ERR_CONFIG, "%s: precision %u", fn, d->precision);
     return US_OK;
 }
 
@@ -594,6 +594,7 @@ int us_mlp_fwd_counted_rows(const us_mlp_desc* d, const float* params, const flo
     int64_t nb = us_cdiv(n, pts * MLP_WAVES); if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(MLP_THREADS);
     if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_fwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
+    else if (d->precision == US_PREC_F16) MLP_DISPATCH(k_mlp_fwd_f16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
     else if (bf) MLP_DISPATCH(k_mlp_fwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
     else MLP_DISPATCH(k_mlp_fwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, n, out, out_stride, lm, n_dev, n_mul);
     US_CHECK_LAUNCH("us_mlp_fwd");
@@ -646,6 +647,8 @@ extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float
     }
     if (d->precision == US_PREC_BF16) MLP_DISPATCH(k_mlp_bwd_bf16x3, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                                                    dout_stride, n, dL_din, grad_params, lm, partials);
+    else if (d->precision == US_PREC_F16) MLP_DISPATCH(k_mlp_bwd_f16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
+                                                       dout_stride, n, dL_din, grad_params, lm, partials);
     else if (bf) MLP_DISPATCH(k_mlp_bwd_bf16, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
                               dout_stride, n, dL_din, grad_params, lm, partials);
     else MLP_DISPATCH(k_mlp_bwd, params, (int)d->has_bias, (int)d->n_out, (int)d->out_act, in, out, out_stride, dL_dout,
@@ -676,7 +679,7 @@ extern "C" int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t
 // ---- two decoders of equal shape in one launch each way (k_mlp_fwd_pair / k_mlp_bwd_pair in mlp_bf16.inc)
 static bool mlp_pair_ok(const us_mlp_desc* a, const us_mlp_desc* b) {
     return a && b && a->n_in == 32 && b->n_in == 32 && a->width == b->width && a->n_hidden == b->n_hidden && a->precision == b->precision &&
-           (a->precision == US_PREC_BF16 || a->precision == US_PREC_BF16_PLAIN) && (a->width == 16 || a->width == 32 || a->width == 64) &&
+           (a->precision == US_PREC_BF16 || a->precision == US_PREC_BF16_PLAIN || a->precision == US_PREC_F16) && (a->width == 16 || a->width == 32 || a->width == 64) &&
            (a->n_hidden == 1 || a->n_hidden == 2) && a->n_out >= 1 && a->n_out <= 16 && b->n_out >= 1 && b->n_out <= 16 &&
            a->out_act <= US_ACT_SIGMOID && b->out_act <= US_ACT_SIGMOID;
 }
@@ -697,28 +700,22 @@ static int64_t mlp_pair_rows(const us_mlp_desc* d, int64_t n) {
     return nb > MLP_BWD_PAIR_WG ? MLP_BWD_PAIR_WG : nb;
 }
 
+#define MLP_PAIR_CASES(KERNEL, MODE, ...)                                                                          \
+    switch (key) {                                                                                                 \
+        case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+        case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+        case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+        case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+        case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+        default:  hipLaunchKernelGGL((KERNEL<32, 64, 2, MODE>), grid, block, 0, s, __VA_ARGS__); break;            \
+    }
+// MODE (mlp_bf16.inc): 1 = bf16 with split operands, 2 = f16, 0 = bf16 with one product
 #define MLP_PAIR_DISPATCH(KERNEL, ...)                                                                             \
     do {                                                                                                           \
         const int key = (int)da->width * 10 + (int)da->n_hidden;                                                   \
-        if (da->precision == US_PREC_BF16) {                                                                       \
-            switch (key) {                                                                                         \
-                case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-                case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-                case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-                case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-                case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-                default:  hipLaunchKernelGGL((KERNEL<32, 64, 2, true>), grid, block, 0, s, __VA_ARGS__); break;    \
-            }                                                                                                      \
-        } else {                                                                                                   \
-            switch (key) {                                                                                         \
-                case 161: hipLaunchKernelGGL((KERNEL<32, 16, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-                case 162: hipLaunchKernelGGL((KERNEL<32, 16, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-                case 321: hipLaunchKernelGGL((KERNEL<32, 32, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-                case 322: hipLaunchKernelGGL((KERNEL<32, 32, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-                case 641: hipLaunchKernelGGL((KERNEL<32, 64, 1, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-                default:  hipLaunchKernelGGL((KERNEL<32, 64, 2, false>), grid, block, 0, s, __VA_ARGS__); break;   \
-            }                                                                                                      \
-        }                                                                                                          \
+        if (da->precision == US_PREC_BF16) { MLP_PAIR_CASES(KERNEL, 1, __VA_ARGS__) }                              \
+        else if (da->precision == US_PREC_F16) { MLP_PAIR_CASES(KERNEL, 2, __VA_ARGS__) }                          \
+        else { MLP_PAIR_CASES(KERNEL, 0, __VA_ARGS__) }                                                            \
     } while (0)
 
 extern "C" int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,

@@ -19,7 +19,7 @@ from . import _lib as L
 
 ACT = {"none": 0, "None": 0, "tanh": 1, "Tanh": 1, "sigmoid": 2, "Sigmoid": 2}
 # MFMA operand type (us_mlp_desc.precision): parameters, gradients and accumulation are fp32 in both
-PREC = {"fp32": 0, "f32": 0, "float": 0, "bf16": 1, "bfloat16": 1, "bf16_plain": 2}   # bf16: split-operand forward products (network.py docs)
+PREC = {"fp32": 0, "f32": 0, "float": 0, "bf16": 1, "bfloat16": 1, "bf16_plain": 2, "f16": 3, "fp16": 3, "half": 3}   # bf16: split-operand forward products (network.py docs)
 
 
 def make_mlp_desc(n_in, width, n_hidden, n_out, out_act, has_bias, precision=0):
