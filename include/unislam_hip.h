@@ -549,6 +549,23 @@ int us_window_sample(const float* c2w_first, const float* poses7, int b, int64_t
 int us_pose_window_step(float* poses7, int n_poses, const float* g_rays_o, const float* g_rays_d, const float* dirs, int64_t row_a,
                         int64_t n_a, int first_pose_b, int64_t row_b, int64_t n_b, float* m7, float* v7, float* g7_out, double lr_q,
                         double lr_t, double beta1, double beta2, double eps, float* step_dev, int flags, void* stream);
+/* The same two launches for a window whose SHAPE lives on the device, over a persistent arena of keyframe pools -- so that ONE captured
+ * hipGraph serves every window of a run, whatever its number of frames (src/Mapper.py:276-364: the window grows with the keyframe list).
+ *   shape_dev int32[8] = { frames b, pixels per frame, extra frames, extra pixels, 1 if frame 0 is the fixed one, -, -, - };
+ *   slots int32[b]: window frame -> row of pool_*[K][P]...;  poses7 [cap][7] (frame f uses row f - fixed).
+ * Fixed row layout: rows [0, rows_a) carry the b * n_per rays of the first block, rows [rows_a, rows_a + rows_b) the extra block; rows
+ * beyond a block's real rays are padding -- sampled like any ray, flagged invalid (dropped by the loss like a ray the pre-filter
+ * rejects).  idx_a [rows_a] / idx_b [rows_b] or NULL (in-kernel draw; rng_counter = the optimiser's float[8] step_dev, whose [1] is
+ * mixed in as the window's epoch).  us_arena_pose_step launches n_poses_cap workgroups; those beyond b - fixed leave. */
+int us_arena_window_sample(const float* c2w_first, const float* poses7, const int32_t* shape_dev, const int32_t* slots, int64_t rows_a,
+                           int64_t rows_b, const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size,
+                           const int64_t* idx_a, const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat,
+                           const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
+                           uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
+                           float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, void* stream);
+int us_arena_pose_step(float* poses7, int n_poses_cap, const int32_t* shape_dev, int64_t rows_a, const float* g_rays_o,
+                       const float* g_rays_d, const float* dirs, float* m7, float* v7, float* g7_out, double lr_q, double lr_t,
+                       double beta1, double beta2, double eps, float* step_dev, void* stream);
 /* The tracker's pose step with the loop's minimum-loss bookkeeping in the same launch (src/Tracker.py:240-242 and :346-348):
  * us_pose_window_step(pose7, 1, ..., rows [0, n_rays), US_POSE_OWN_STEP), and before the step: where loss[0] -- the loss of THIS iteration,
  * rendered at pose7 as it is on entry -- is below min_loss[0], min_loss[0] takes it and best7[7] that pose (`candidate_cam_pose`).  A NaN

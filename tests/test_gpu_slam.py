@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _build(us, n_frames, seed=0, mlp_precision="fp32", graph_replay=False):
+def _build(us, n_frames, seed=0, mlp_precision="fp32", graph_replay=None):
     from unislam_amd.synthetic import SyntheticRoom
     from unislam_amd.slam import SLAM
     torch.manual_seed(seed)
@@ -29,14 +29,15 @@ def _build(us, n_frames, seed=0, mlp_precision="fp32", graph_replay=False):
     dec.bound = bound
     slam = SLAM(frames, (frames.H, frames.W, frames.fx, frames.fy, frames.cx, frames.cy), es, ec, dec, bound,
                 cfg={"tracking": dict(ignore_edge_W=8, ignore_edge_H=8, pixels=1000, iters=10),
-                     "mapping": dict(pixels=2000, iters=20, iters_first=300, every_frame=2, keyframe_every=2, graph_replay=graph_replay)})
+                     "mapping": dict(dict(pixels=2000, iters=20, iters_first=300, every_frame=2, keyframe_every=2),
+                                     **({} if graph_replay is None else dict(graph_replay=graph_replay)))})
     return slam, frames
 
 
 def test_slam_recovers_the_trajectory():
     import unislam_amd as us
     n = 26
-    slam, frames = _build(us, n)
+    slam, frames = _build(us, n, graph_replay=False)                       # eager iterations; the default (replayed graphs) below
     est = slam.run()
     print('ATE', slam.ate_rmse(), 'LC', slam.mapper.LC_cnt, 'kf', slam.mapper.keyframe_list)
     gt = slam.gt_c2w_list[:n]
@@ -66,13 +67,65 @@ def test_slam_recovers_the_trajectory():
 
 
 def test_slam_with_replayed_mapping_windows():
-    """cfg['mapping']['graph_replay']: every mapped frame captures its MapWindow (joint_opt from the fifth keyframe on, the pixel draw
-    inside the graph) and replays it `iters` times; the trajectory comes out as with eager iterations"""
+    """the DEFAULT settings: every mapped frame binds its window (arena rows, poses, shape) to one of a handful of graphs captured ahead
+    (slam.Mapper.prewarm: poses fixed / joint_opt, keyed by the kind of window, not by its number of frames) and replays it `iters`
+    times; the trajectory comes out as with eager iterations, and no graph is captured inside the sequence"""
     import unislam_amd as us
     n = 16
-    slam, frames = _build(us, n, graph_replay=True, mlp_precision="bf16")
+    slam, frames = _build(us, n, mlp_precision="bf16")
+    assert slam.cfg["mapping"]["graph_replay"] is True
     slam.run()
     assert slam.mapper.joint_opt and slam.ate_rmse() < 0.02, slam.ate_rmse()
+    kinds = sorted(slam.mapper._wins)
+    assert all(w._graph is not None for w in slam.mapper._wins.values())
+    # first frame (lr x 5), poses fixed, joint_opt, joint_opt + extra rays (captured ahead, unused in a 16-frame run): windows of 1 .. 8 frames
+    assert len(kinds) == 4 and len(slam.mapper.keyframe_list) >= 7, kinds
+
+
+def test_arena_window_equals_a_plain_window():
+    """ArenaWindow (window shape on the device, pools in a KeyframeArena, padded rows) against MapWindow on the same frames, pixel indices
+    and jitter: windows of 3 and of 7 frames through ONE captured graph, 4 joint_opt iterations each -- losses, model and poses agree;
+    rows beyond b * n_per are flagged invalid"""
+    import unislam_amd as us
+    from test_gpu_window import _window, _cfg, _ecfg, BOUND, W, LR
+    P, rows_a = 400, 420
+    g = torch.Generator().manual_seed(4)
+    arena = us.KeyframeArena(12, P, DEV)
+    c2ws, depths, colors, dirs = _window(9, P, 17)
+    for k in range(9):
+        row = arena.alloc()
+        arena.put(row, colors[k].to(DEV), depths[k].to(DEV), dirs[k].to(DEV))
+
+    def scene():
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        return us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=rows_a)
+
+    step_a = scene()
+    awin = us.ArenaWindow(step_a, arena, rows_a, 0, joint_opt=True, cam_lr=1e-3, has_zero_depth=False)
+    awin.capture(t_rand=True, device_draw=False)
+    for frames in ([2, 5, 7], [0, 1, 3, 4, 6, 7, 8]):
+        b = len(frames)
+        n_per = rows_a // b
+        step_p = scene()
+        step_a.flat.copy_(step_p.flat); step_a.reset_optimizer(1.0); step_p.reset_optimizer(1.0)
+        sel = torch.tensor(frames)
+        pwin = us.MapWindow(step_p, c2ws[sel], depths[sel], colors[sel], dirs[sel], n_per, joint_opt=True, cam_lr=1e-3, has_zero_depth=False)
+        awin.bind([f + 1 for f in frames], c2ws[sel].to(DEV), n_per)                 # (arena row 0 is the scratch row)
+        for it in range(4):
+            idx = torch.randint(P, (b, n_per), generator=g)
+            tr = torch.rand(b * n_per, 40, generator=g)
+            la = pwin.iterate(idx.to(DEV), t_rand=tr.to(DEV))
+            awin.t_rand.zero_(); awin.t_rand[:b * n_per].copy_(tr.to(DEV))
+            lb = awin.replay(idx.to(DEV))
+            np.testing.assert_allclose(float(lb), float(la), rtol=1e-5)
+        assert int(step_a.valid[:b * n_per].sum()) == int(step_p.valid[:b * n_per].sum()) and int(step_a.valid[b * n_per:rows_a].sum()) == 0
+        assert torch.allclose(step_a.flat, step_p.flat, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(awin.c2ws(), pwin.c2ws(), rtol=0, atol=1e-6)
+        assert float((awin.c2ws()[1:] - c2ws[sel][1:].to(DEV)).abs().max()) > 1e-4     # the poses did move
 
 
 def test_keyframe_selection_on_device():

@@ -14,11 +14,11 @@ from .renderer import Renderer, sample_z
 from .losses import sdf_losses, mapping_loss, tracking_loss, fused_loss
 from .mapstep import MapStep
 from .trackstep import TrackStep
-from .window import MapWindow
+from .window import MapWindow, ArenaWindow, KeyframeArena
 from .graph import CapturedIteration
 from .mesher import eval_points
 from . import common, tcnn
 
 __all__ = ["HashGridEncoding", "FusedMLP", "Decoders", "Renderer", "sdf_losses", "mapping_loss", "tracking_loss",
            "fused_loss", "common", "tcnn", "UniSlamHipError", "LIB_PATH", "get_model", "make_grid_desc",
-           "grid_indices", "fused_mlp", "make_mlp_desc", "sample_z", "MapStep", "MapWindow", "TrackStep", "CapturedIteration", "eval_points"]
+           "grid_indices", "fused_mlp", "make_mlp_desc", "sample_z", "MapStep", "MapWindow", "ArenaWindow", "KeyframeArena", "TrackStep", "CapturedIteration", "eval_points"]

@@ -1130,8 +1130,21 @@ __global__ __launch_bounds__(256) void k_window_sample(const float* __restrict__
                                                        unsigned long long seed, const float* __restrict__ rng_counter, int perturb,
                                                        float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ dirs,
                                                        float* __restrict__ gt_depth, float* __restrict__ gt_color, uint8_t* __restrict__ valid,
-                                                       float* __restrict__ z_vals, float* __restrict__ pts, int rays_per_block) {
+                                                       float* __restrict__ z_vals, float* __restrict__ pts, int rays_per_block,
+                                                       const int32_t* __restrict__ shape_dev, const int32_t* __restrict__ slots,
+                                                       int64_t rows_a) {
     if (rng_counter) seed += 0xD1B54A32D192ED03ull * (unsigned long long)__float_as_uint(rng_counter[0]);
+    // shape_dev (us_arena_window_sample): the window's shape lives on the device -- {frames b, pixels per frame, extra frames, extra
+    // pixels, first-frame-fixed} -- and the launch has a FIXED row layout: rows [0, rows_a) hold the b * n_per rays of the first block,
+    // rows [rows_a, n_rays) the extra block; rows beyond a block's real rays are padding: sampled like any ray (finite values all the way
+    // down) and flagged invalid, i.e. dropped like a ray the pre-filter rejects.  slots: window frame -> row of the pool arena.  One
+    // captured hipGraph then serves every window of a run, whatever its number of frames.
+    bool first_fixed = c2w_first != nullptr;
+    if (shape_dev) {
+        ws.b = shape_dev[0]; ws.n_per = shape_dev[1]; ws.xf = shape_dev[2]; ws.xn = shape_dev[3] > 0 ? shape_dev[3] : 1;
+        first_fixed = shape_dev[4] != 0;
+        if (rng_counter) seed += 0xA24BAED4963EE407ull * (unsigned long long)__float_as_uint(rng_counter[1]);   // the window's epoch (float[8] step_dev)
+    }
     extern __shared__ __attribute__((aligned(16))) float zs[];       // [rays_per_block][S] sorted samples
     const int S = n_strat + n_imp;
     const int rl = threadIdx.x / S, j = threadIdx.x - rl * S;
@@ -1139,26 +1152,32 @@ __global__ __launch_bounds__(256) void k_window_sample(const float* __restrict__
     const bool active = rl < rays_per_block && ray < n_rays;
     float v = 0.0f, gt = 0.0f, o3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
     int64_t src = 0;
+    bool padding = false;
     if (active) {
-        const int64_t ra = (int64_t)ws.b * ws.n_per;
+        const int64_t ra = shape_dev ? rows_a : (int64_t)ws.b * ws.n_per;
         int64_t f, p;
         const int64_t* ix;
         int64_t k;
-        if (ray < ra) { f = ray / ws.n_per; ix = idx_a; k = ray; }
-        else { k = ray - ra; f = (ws.b - ws.xf) + k / ws.xn; ix = idx_b; }
+        if (ray < ra) {
+            f = ray / ws.n_per; ix = idx_a; k = ray;
+            if (f >= ws.b) { padding = true; f = ray % ws.b; }
+        } else {
+            k = ray - ra; f = (ws.b - ws.xf) + k / ws.xn; ix = idx_b;
+            if (k >= (int64_t)ws.xf * ws.xn) { padding = true; f = k % ws.b; }
+        }
         if (idx_a) p = ix[k];
         else {
             unsigned long long zz = (seed ^ 0x8CB92BA72F3D8DD7ull) + ((unsigned long long)ray + 1ull) * 0x9E3779B97F4A7C15ull;
             zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull; zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull; zz = zz ^ (zz >> 31);
             p = (int64_t)(((zz >> 32) * (unsigned long long)ws.P) >> 32);
         }
-        src = f * ws.P + p;
+        src = (slots ? (int64_t)slots[f] : f) * ws.P + p;
         float R[9];
-        if (f == 0 && c2w_first) {
+        if (f == 0 && first_fixed) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) { R[a * 3] = c2w_first[a * 4]; R[a * 3 + 1] = c2w_first[a * 4 + 1]; R[a * 3 + 2] = c2w_first[a * 4 + 2]; o3[a] = c2w_first[a * 4 + 3]; }
-        } else {                                                   // c2w_first NULL: no frame here is the window's fixed one, frame f reads poses7[f]
-            const float* q = poses7 + (f - (c2w_first ? 1 : 0)) * 7;
+        } else {                                                   // no fixed first frame: frame f reads poses7[f]
+            const float* q = poses7 + (f - (first_fixed ? 1 : 0)) * 7;
             quat_rot(q, R);
             o3[0] = q[4]; o3[1] = q[5]; o3[2] = q[6];
         }
@@ -1207,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_window_sample(const float* __restrict__
                 gt_color[ray * 3 + a] = pool_color[src * 3 + a];
             }
             gt_depth[ray] = gt;
-            valid[ray] = (far >= gt) ? 1 : 0;                    // Mapper.py:396-402 (rays without a depth pass: gt = 0)
+            valid[ray] = (far >= gt) && !padding ? 1 : 0;        // Mapper.py:396-402 (rays without a depth pass: gt = 0)
         }
     }
 }
@@ -1829,28 +1848,61 @@ extern "C" int us_track_loss_bwd(const float* raw, const float* z_vals, const fl
     return US_OK;
 }
 
+static int window_sample(const char* fn, const float* c2w_first, const float* poses7, int b, int64_t n_per_frame, int n_extra_frames, int64_t n_extra,
+                         const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size,
+                         const int64_t* idx_a, const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat,
+                         const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
+                         uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
+                         float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, const int32_t* shape_dev,
+                         const int32_t* slots, int64_t rows_a, int64_t rows_b, void* stream) {
+    int64_t n_rays;
+    if (shape_dev) {                                             // fixed row layout; the real shape is read on the device
+        US_REQUIRE(rows_a >= 1 && rows_b >= 0 && pool_size >= 1, US_ERR_SHAPE, "%s: bad row layout", fn);
+        US_REQUIRE(slots && c2w_first && poses7, US_ERR_NULL, "%s: slots, c2w_first and poses7 are required", fn);
+        n_rays = rows_a + rows_b;
+        b = 1; n_per_frame = rows_a; n_extra_frames = 0; n_extra = 1;
+    } else {
+        US_REQUIRE(b >= 1 && n_per_frame >= 0 && n_extra_frames >= 0 && n_extra_frames <= b && n_extra >= 0 && pool_size >= 1, US_ERR_SHAPE,
+                   "%s: bad window shape", fn);
+        if (n_extra_frames == 0 || n_extra == 0) { n_extra_frames = 0; n_extra = 1; }
+        n_rays = (int64_t)b * n_per_frame + (int64_t)n_extra_frames * (n_extra_frames ? n_extra : 0);
+        if (n_rays == 0) return US_OK;
+        US_REQUIRE((c2w_first || poses7) && ((c2w_first && b == 1) || poses7), US_ERR_NULL, "%s: NULL pointer", fn);
+        US_REQUIRE(!n_extra_frames || ((idx_a == nullptr) == (idx_b == nullptr)), US_ERR_NULL, "%s: idx_a and idx_b together, or neither (in-kernel draw)", fn);
+    }
+    US_REQUIRE(pool_depth && pool_color && pool_dirs && bound_host && t_uni && t_surf && rays_o && rays_d &&
+               gt_depth && gt_color && valid && z_vals && pts, US_ERR_NULL, "%s: NULL pointer", fn);
+    const int S = n_strat + n_imp;
+    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "%s: n_strat %d n_imp %d (S must be <= 256)", fn, n_strat, n_imp);
+    WinShape ws; ws.b = b; ws.n_per = n_per_frame; ws.P = pool_size; ws.xf = n_extra_frames; ws.xn = n_extra;
+    const int rpb = 256 / S;
+    hipLaunchKernelGGL(k_window_sample, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float), (hipStream_t)stream,
+                       c2w_first, poses7, ws, pool_depth, pool_color, pool_dirs, idx_a, idx_b, n_rays, make_bound3x(bound_host), t_uni, n_strat,
+                       t_surf, n_imp, c_free, surf_off, surf_span, t_rand, (unsigned long long)rng_seed, rng_counter, perturb, rays_o, rays_d, dirs,
+                       gt_depth, gt_color, valid, z_vals, pts, rpb, shape_dev, slots, rows_a);
+    US_CHECK_LAUNCH(fn);
+    return US_OK;
+}
+
 extern "C" int us_window_sample(const float* c2w_first, const float* poses7, int b, int64_t n_per_frame, int n_extra_frames, int64_t n_extra,
                                 const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size,
                                 const int64_t* idx_a, const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat,
                                 const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
                                 uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
                                 float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, void* stream) {
-    US_REQUIRE(b >= 1 && n_per_frame >= 0 && n_extra_frames >= 0 && n_extra_frames <= b && n_extra >= 0 && pool_size >= 1, US_ERR_SHAPE,
-               "us_window_sample: bad window shape");
-    if (n_extra_frames == 0 || n_extra == 0) { n_extra_frames = 0; n_extra = 1; }
-    const int64_t n_rays = (int64_t)b * n_per_frame + (int64_t)n_extra_frames * (n_extra_frames ? n_extra : 0);
-    if (n_rays == 0) return US_OK;
-    US_REQUIRE((c2w_first || poses7) && ((c2w_first && b == 1) || poses7) && pool_depth && pool_color && pool_dirs && bound_host && t_uni && t_surf && rays_o && rays_d &&
-               gt_depth && gt_color && valid && z_vals && pts, US_ERR_NULL, "us_window_sample: NULL pointer");
-    US_REQUIRE(!n_extra_frames || ((idx_a == nullptr) == (idx_b == nullptr)), US_ERR_NULL, "us_window_sample: idx_a and idx_b together, or neither (in-kernel draw)");
-    const int S = n_strat + n_imp;
-    US_REQUIRE(n_strat >= 1 && n_imp >= 0 && S <= 256, US_ERR_SHAPE, "us_window_sample: n_strat %d n_imp %d (S must be <= 256)", n_strat, n_imp);
-    WinShape ws; ws.b = b; ws.n_per = n_per_frame; ws.P = pool_size; ws.xf = n_extra_frames; ws.xn = n_extra;
-    const int rpb = 256 / S;
-    hipLaunchKernelGGL(k_window_sample, dim3((unsigned)us_cdiv(n_rays, rpb)), dim3(256), (size_t)rpb * S * sizeof(float), (hipStream_t)stream,
-                       c2w_first, poses7, ws, pool_depth, pool_color, pool_dirs, idx_a, idx_b, n_rays, make_bound3x(bound_host), t_uni, n_strat,
-                       t_surf, n_imp, c_free, surf_off, surf_span, t_rand, (unsigned long long)rng_seed, rng_counter, perturb, rays_o, rays_d, dirs,
-                       gt_depth, gt_color, valid, z_vals, pts, rpb);
-    US_CHECK_LAUNCH("us_window_sample");
-    return US_OK;
+    return window_sample("us_window_sample", c2w_first, poses7, b, n_per_frame, n_extra_frames, n_extra, pool_depth, pool_color, pool_dirs, pool_size,
+                         idx_a, idx_b, bound_host, t_uni, n_strat, t_surf, n_imp, c_free, surf_off, surf_span, t_rand, rng_seed, rng_counter, perturb,
+                         rays_o, rays_d, dirs, gt_depth, gt_color, valid, z_vals, pts, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int us_arena_window_sample(const float* c2w_first, const float* poses7, const int32_t* shape_dev, const int32_t* slots, int64_t rows_a,
+                                      int64_t rows_b, const float* pool_depth, const float* pool_color, const float* pool_dirs, int64_t pool_size,
+                                      const int64_t* idx_a, const int64_t* idx_b, const float* bound_host, const float* t_uni, int n_strat,
+                                      const float* t_surf, int n_imp, float c_free, float surf_off, float surf_span, const float* t_rand,
+                                      uint64_t rng_seed, const float* rng_counter, int perturb, float* rays_o, float* rays_d, float* dirs,
+                                      float* gt_depth, float* gt_color, uint8_t* valid, float* z_vals, float* pts, void* stream) {
+    US_REQUIRE(shape_dev, US_ERR_NULL, "us_arena_window_sample: shape_dev is NULL");
+    return window_sample("us_arena_window_sample", c2w_first, poses7, 0, 0, 0, 0, pool_depth, pool_color, pool_dirs, pool_size, idx_a, idx_b, bound_host,
+                         t_uni, n_strat, t_surf, n_imp, c_free, surf_off, surf_span, t_rand, rng_seed, rng_counter, perturb, rays_o, rays_d, dirs,
+                         gt_depth, gt_color, valid, z_vals, pts, shape_dev, slots, rows_a, rows_b, stream);
 }

@@ -68,10 +68,21 @@ __global__ __launch_bounds__(THREADS) void k_pose_window_step(float* __restrict_
                                                           const float* __restrict__ dirs, float* __restrict__ m7, float* __restrict__ v7,
                                                           float* __restrict__ g7_out, float* __restrict__ step_dev, PoseStep ps,
                                                           const float* __restrict__ loss = nullptr, float* __restrict__ min_loss = nullptr,
-                                                          float* __restrict__ best7 = nullptr, float* __restrict__ draw_counter = nullptr) {
+                                                          float* __restrict__ best7 = nullptr, float* __restrict__ draw_counter = nullptr,
+                                                          const int32_t* __restrict__ shape_dev = nullptr, int64_t rows_a = 0) {
     __shared__ double sh[12][THREADS / 64];
     __shared__ float g7[7];
     const int j = blockIdx.x;
+    if (shape_dev) {
+        // the window's shape on the device (us_arena_pose_step; layout of us_arena_window_sample): the launch covers the arena's pose
+        // capacity, workgroups beyond the window's optimised frames leave; rows as laid out there (first block from row 0, extra block
+        // from row rows_a)
+        const int b = shape_dev[0], n_per = shape_dev[1], xf = shape_dev[2], xn = shape_dev[3], first = shape_dev[4] != 0 ? 1 : 0;
+        if (j >= b - first) return;                                // (uniform over the workgroup)
+        const int fb = (b - xf) > first ? (b - xf) : first;        // the first optimised frame that owns rows of the extra block
+        ps.nA = n_per; ps.rowA = (int64_t)first * n_per;
+        ps.nB = xf > 0 ? xn : 0; ps.jB = fb - first; ps.rowB = rows_a + (int64_t)(fb - (b - xf)) * xn;
+    }
     double acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.0;
@@ -199,6 +210,24 @@ extern "C" int us_pose_window_step(float* poses7, int n_poses, const float* g_ra
     hipLaunchKernelGGL(k_pose_window_step<256>, dim3((unsigned)n_poses), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
                        g7_out, step_dev, ps);
     US_CHECK_LAUNCH("us_pose_window_step");
+    return US_OK;
+}
+
+// us_pose_window_step with the window's shape read on the device: n_poses_cap workgroups are launched, the window's b - first run
+extern "C" int us_arena_pose_step(float* poses7, int n_poses_cap, const int32_t* shape_dev, int64_t rows_a, const float* g_rays_o,
+                                  const float* g_rays_d, const float* dirs, float* m7, float* v7, float* g7_out, double lr_q, double lr_t,
+                                  double beta1, double beta2, double eps, float* step_dev, void* stream) {
+    US_REQUIRE(poses7 && shape_dev && g_rays_o && g_rays_d && dirs && m7 && v7 && step_dev, US_ERR_NULL, "us_arena_pose_step: NULL pointer");
+    US_REQUIRE(n_poses_cap >= 1 && rows_a >= 1, US_ERR_SHAPE, "us_arena_pose_step: bad shape");
+    US_REQUIRE(((uintptr_t)step_dev & 7u) == 0, US_ERR_SHAPE, "us_arena_pose_step: step_dev (float[8]) must be 8-byte aligned");
+    PoseStep ps;
+    ps.nA = 0; ps.rowA = 0; ps.nB = 0; ps.rowB = 0; ps.jB = 0;
+    ps.lr_q = (float)lr_q; ps.lr_t = (float)lr_t; ps.b1 = (float)beta1; ps.b2 = (float)beta2; ps.eps = (float)eps;
+    ps.own_step = 0; ps.apply = 1;
+    const float* nulf = nullptr; float* nulw = nullptr;
+    hipLaunchKernelGGL(k_pose_window_step<256>, dim3((unsigned)n_poses_cap), dim3(256), 0, (hipStream_t)stream, poses7, g_rays_o, g_rays_d, dirs, m7, v7,
+                       g7_out, step_dev, ps, nulf, nulw, nulw, nulw, shape_dev, rows_a);
+    US_CHECK_LAUNCH("us_arena_pose_step");
     return US_OK;
 }
 

@@ -174,6 +174,10 @@ class MapStep:
         self.m.zero_(); self.v.zero_()
         self.opt_step = 0
         self.step_dev.zero_()
+        # step_dev[1]: the optimiser's EPOCH (how many times it was reset), read by the arena window's in-kernel pixel draw and jitter: a graph
+        # that is replayed for every mapped frame carries one host-side seed, and the step count restarts with every frame
+        self._epoch = getattr(self, "_epoch", 0) + 1
+        self.step_dev[1] = float(self._epoch)
         self._step_advanced = False
         self.lr_factor = float(lr_factor)
         self._graph = None              # a captured iteration holds the old learning rates

@@ -15,14 +15,14 @@ import torch
 from .common import cam_pose_to_matrix, get_samples, matrix_to_cam_pose, predict_cam_pose
 from .mapstep import MapStep
 from .trackstep import TrackStep
-from .window import MapWindow
+from .window import ArenaWindow, KeyframeArena, MapWindow
 
 DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
     "tracking": dict(ignore_edge_W=75, ignore_edge_H=75, const_speed_assumption=True, lr_T=0.002, lr_R=0.001, pixels=2000, iters=8,
                      activated_mapping_mode=True, uncertainty_ts=0.001,
                      w=dict(fs=10, center=200, tail=50, depth=1, color=5)),
     "mapping": dict(every_frame=4, keyframe_every=4, joint_opt=True, joint_opt_cam_lr=0.001, mapping_window_size=20,
-                    lr_first_factor=5, lr_factor=1, pixels=4000, iters_first=10, iters=15, LC=True, LC_ts=0.95,
+                    lr_first_factor=5, lr_factor=1, pixels=4000, iters_first=10, iters=15, LC=True, LC_ts=0.95, graph_replay=True,
                     lr=dict(decoders=0.001, sdf_grid=0.05, color_grid=0.05), w=dict(fs=5, center=200, tail=10, depth=0.1, color=5)),
     "rendering": dict(n_stratified=32, n_importance=8, perturb=True), "truncation": 0.06,
     "m_mask_mode": "original", "t_mask_mode": "original",
@@ -32,7 +32,7 @@ DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
 def keyframe_overlap(pts, keyframes_c2ws, H, W, fx, fy, cx, cy, edge=20):
     """Mapper.py:217-240: fraction of the sample points `pts` [M,3] that project inside each keyframe's image."""
     device = pts.device
-    w2cs = torch.inverse(keyframes_c2ws)
+    w2cs = rigid_inverse(keyframes_c2ws)                             # (Mapper.py:222 calls torch.inverse: the poses are rigid)
     ones = torch.ones_like(pts[..., :1])
     homo = torch.cat([pts, ones], dim=-1).reshape(1, -1, 4, 1).expand(w2cs.shape[0], -1, -1, -1)
     cam = (w2cs.unsqueeze(1).expand(-1, homo.shape[1], -1, -1) @ homo)[:, :, :3]
@@ -87,8 +87,24 @@ def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyf
     return selected, percent_inside, loop
 
 
+def rigid_inverse(c2ws):
+    """inverse of [n,4,4] rigid transforms in closed form: [R^T | -R^T t] (torch.inverse initialises a solver library on its first call:
+    0.3 s in the middle of the sequence)"""
+    Rt = c2ws[:, :3, :3].transpose(1, 2)
+    out = torch.zeros_like(c2ws)
+    out[:, :3, :3] = Rt
+    out[:, :3, 3] = -(Rt @ c2ws[:, :3, 3:4])[:, :, 0]
+    out[:, 3, 3] = 1.0
+    return out
+
+
 class Mapper:
-    """Mapper.run body for one frame + optimize_mapping (src/Mapper.py:276-459,461-545)"""
+    """Mapper.run body for one frame + optimize_mapping (src/Mapper.py:276-459,461-545).
+
+    The keyframes' pixel pools live in a KeyframeArena (one row per keyframe, written once); a mapping window is a list of rows.  The
+    15 / 20 / 30 iterations of a mapped frame replay ONE captured hipGraph per kind of window -- (joint_opt, extra rays, depth holes,
+    lr factor): at most a handful per run, captured ahead by prewarm() -- whatever the number of frames in the window (ArenaWindow: the
+    window's shape is read on the device).  cfg['mapping']['graph_replay'] False runs the same windows eagerly."""
 
     def __init__(self, slam):
         self.s = slam
@@ -98,17 +114,55 @@ class Mapper:
         self.step = MapStep(slam.es, slam.ec, slam.decoders, slam.bound, r["n_stratified"], r["n_importance"], slam.cfg["truncation"],
                             c["w"], c["lr"], mask_mode=slam.cfg["m_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"] + 2000)
         self.keyframe_list, self.keyframe_dict = [], []
-        self.init_phase, self.LC_cnt = True, 0
+        self.init_phase, self.LC_cnt, self.joint_opt = True, 0, False
+        H, W = slam.cam[0], slam.cam[1]
+        n_kf = int(c.get("arena_keyframes", len(slam.frames) // max(1, c["keyframe_every"]) + 8))
+        self.arena = KeyframeArena(n_kf + 1, int(H * W * 0.1), slam.device)
+        self.kf_c2w = torch.zeros((self.arena.K, 4, 4), device=slam.device)             # est_c2w per arena row (src/Mapper.py:447-457 writes them back)
+        self._wins = {}
+        self.cur_has_zero = False
 
-    def _pool(self, color, depth, rays_d):
-        """10 % of the pixels of a frame as its sampling pool (Mapper.py:329-337,516-523)"""
+    # ---------------------------------------------------------------------------------------------- pools
+    def _pool_into(self, row, color, depth, rays_d):
+        """10 % of the pixels of a frame as its sampling pool (Mapper.py:329-337,516-523), written into arena row `row`; returns whether the
+        pool holds pixels without a depth (one host read per pool: it picks the window's graph)"""
         total = color.shape[0] * color.shape[1]
-        ind = torch.randperm(total, device=color.device)[:int(total * 0.1)]
-        return color.reshape(-1, 3)[ind], depth.reshape(-1)[ind], rays_d.reshape(-1, 3)[ind]
+        ind = torch.randperm(total, device=color.device)[:self.arena.P]
+        pd = depth.reshape(-1)[ind]
+        self.arena.put(row, color.reshape(-1, 3)[ind], pd, rays_d.reshape(-1, 3)[ind])
+        return bool((pd <= 0).any())
 
+    def _window(self, joint, extra_on, has_zero, lr_factor):
+        """the ArenaWindow (and its graph) for this kind of mapped frame"""
+        c = self.c
+        if self.arena.generation != getattr(self, "_gen", 0):                           # the arena grew: captured graphs hold old addresses
+            self._wins.clear(); self._gen = self.arena.generation
+            kc = torch.zeros((self.arena.K, 4, 4), device=self.s.device); kc[:self.kf_c2w.shape[0]] = self.kf_c2w; self.kf_c2w = kc
+        key = (bool(joint), bool(extra_on), bool(has_zero), float(lr_factor))
+        win = self._wins.get(key)
+        if win is None:
+            self.step.reset_optimizer(lr_factor)                                        # the learning rates the graph records
+            win = ArenaWindow(self.step, self.arena, c["pixels"], 2000 if extra_on else 0, joint_opt=joint, cam_lr=c["joint_opt_cam_lr"],
+                              has_zero_depth=has_zero)
+            if bool(c.get("graph_replay", True)):
+                win.capture()
+            self._wins[key] = win
+        return win
+
+    def prewarm(self, kinds=None):
+        """capture the graphs of the window kinds a run meets -- first keyframes (poses fixed), joint_opt, joint_opt with the extra rays of
+        the newest frames -- before the first frame, with the arena's placeholder pixels; also allocates the joint_opt scratch.  Nothing
+        the model, the optimiser or the sequence sees is changed."""
+        c = self.c
+        if kinds is None:
+            kinds = [(False, False, False, c["lr_factor"]), (c["joint_opt"], False, False, c["lr_factor"]), (c["joint_opt"], True, False, c["lr_factor"])]
+        for k in kinds:
+            self._window(*k)
+        self.step.reset_optimizer(1.0)
+
+    # ---------------------------------------------------------------------------------------------- one mapped frame
     def optimize_mapping(self, iters, lr_factor, idx, cur_color, cur_depth, cur_c2w, cur_rays_d):
         s, c, dev = self.s, self.c, self.s.device
-        H, W, fx, fy, cx, cy = s.cam
         kd, kl = self.keyframe_dict, self.keyframe_list
         if len(kd) == 0:
             optimize_frame = []
@@ -120,34 +174,27 @@ class Mapper:
         if len(kl) > 1:
             optimize_frame = sorted(optimize_frame + [len(kl) - 1] + [len(kl) - 2])
         optimize_frame += [-1]                                                          # -1 = the current frame
-        pixs_per_image = c["pixels"] // len(optimize_frame)
-        depths, colors, c2ws, dirs = [], [], [], []
-        for f in optimize_frame:
-            if f != -1:
-                depths.append(kd[f]["depth"]); colors.append(kd[f]["color"]); dirs.append(kd[f]["rays_d"]); c2ws.append(kd[f]["est_c2w"])
-            else:
-                pc, pd, pr = self._pool(cur_color, cur_depth, cur_rays_d)
-                depths.append(pd); colors.append(pc); dirs.append(pr); c2ws.append(cur_c2w)
-        depths, colors, c2ws, dirs = torch.stack(depths), torch.stack(colors), torch.stack(c2ws), torch.stack(dirs)
-        joint = self.joint_opt and c2ws.shape[0] > 1
-        self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
-        # the loop of :366-445 with the window's poses on the device: pose -> rays, render, loss, backward, pose step and Adam are HIP
-        # launches on static buffers (window.MapWindow); the pools are looked at once for pixels without a depth
+        b = len(optimize_frame)
+        pixs_per_image = c["pixels"] // b
+        # the window = arena rows: the selected keyframes' (written when they were made), row 0 = the pool of the frame being mapped
+        self.cur_has_zero = self._pool_into(0, cur_color, cur_depth, cur_rays_d)
+        rows = [kd[f]["row"] if f != -1 else 0 for f in optimize_frame]
+        self.kf_c2w[0] = cur_c2w
+        c2ws = self.kf_c2w[torch.as_tensor(rows, device=dev)]
+        has_zero = self.cur_has_zero or any(kd[f]["has_zero"] for f in optimize_frame if f != -1)
+        joint = self.joint_opt and b > 1
         extra = (10, 200) if (not s.tracking_back and len(kl) > 20) else None           # extra rays from the newest frames (:381-390)
-        win = MapWindow(self.step, c2ws, depths, colors, dirs, pixs_per_image, joint_opt=joint, cam_lr=c["joint_opt_cam_lr"], extra=extra)
-        replay = bool(c.get("graph_replay", False)) and int(iters) >= 4
-        if replay:
-            win.capture()
+        win = self._window(joint, extra is not None, has_zero, lr_factor)
+        self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
+        win.bind(rows, c2ws, pixs_per_image, extra)
+        # the loop of :366-445: pose -> rays, render, loss, backward, pose step and Adam are HIP launches on static buffers, one graph
+        step = win.replay if win._graph is not None else win.iterate
         for _ in range(int(iters)):
-            win.replay() if replay else win.iterate()
+            step()
         if joint:
-            opt_c2ws = win.c2ws()[1:]                                                   # put the updated camera poses back (:447-457)
-            k = 0
-            for f in optimize_frame[1:]:
-                if f != -1:
-                    kd[f]["est_c2w"] = opt_c2ws[k]; k += 1
-                else:
-                    cur_c2w = opt_c2ws[-1]
+            opt = win.c2ws()                                                            # put the updated camera poses back (:447-457)
+            self.kf_c2w[torch.as_tensor(rows[1:], device=dev)] = opt[1:]
+            cur_c2w = opt[-1]
         return cur_c2w
 
     def map_frame(self, idx, color, depth, gt_c2w, rays_d):
@@ -162,9 +209,17 @@ class Mapper:
             s.estimate_c2w_list[idx] = cur_c2w
         if idx % c["keyframe_every"] == 0 or s.tracking_back:
             self.keyframe_list.append(idx)
-            pc, pd, pr = self._pool(color, depth, rays_d)
-            self.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "color": pc, "depth": pd, "est_c2w": cur_c2w.clone(), "rays_d": pr})
+            row = self.arena.alloc()
+            if self.arena.generation != getattr(self, "_gen", 0):
+                self._window(False, False, False, c["lr_factor"])                       # (rebuilds kf_c2w and the graphs for the grown arena)
+            hz = self._pool_into(row, color, depth, rays_d)
+            self.kf_c2w[row] = cur_c2w
+            self.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "row": row, "has_zero": hz})
         self.init_phase = False
+
+    def keyframe_pose(self, k):
+        """est_c2w of keyframe k (the reference keeps it in keyframe_dict[k]['est_c2w'])"""
+        return self.kf_c2w[self.keyframe_dict[k]["row"]]
 
 
 class Tracker:
@@ -206,16 +261,7 @@ class Tracker:
                     out = self.step.iterate_fused(n_pix)
                 return out
             if k not in self._graphs:
-                from .graph import CapturedIteration
-                if not self._graphs:
-                    self.step.iterate_fused(n_pix)                                      # eager once: lazy buffers, then the frame's state again
-                    begin()
-
-                def body():
-                    for _ in range(k):
-                        out = self.step.iterate_fused(n_pix)
-                    return out
-                self._graphs[k] = CapturedIteration(body, warmup=0)                     # (a capture records, it does not execute)
+                self._capture(k, begin)
             return self._graphs[k].replay()
 
         it = 0
@@ -234,6 +280,40 @@ class Tracker:
                     self.num_cam_iters = c["iters"]
                     s.m_iters, s.tracking_back = s.cfg["mapping"]["iters"], False
         return cam_pose_to_matrix(self.step.best_pose.reshape(1, 7))[0]
+
+
+    def _capture(self, k, begin):
+        """the graph of a run of k tracking iterations (a capture records, it does not execute); begin(): the frame's set-up, run again after
+        the one eager iteration that allocates the lazy buffers"""
+        from .graph import CapturedIteration
+        n_pix = self.c["pixels"]
+        if not self._graphs:
+            self.step.iterate_fused(n_pix)
+            begin()
+
+        def body():
+            for _ in range(k):
+                out = self.step.iterate_fused(n_pix)
+            return out
+        self._graphs[k] = CapturedIteration(body, warmup=0)
+
+    def prewarm(self, color, depth, c2w):
+        """capture the run lengths a sequence meets (iters - 1 up to the loop's host decision, 1 behind it, and their doubled forms while
+        tracking back) on a stand-in frame, so that no tracked frame pays for a capture"""
+        s, c = self.s, self.c
+        if not bool(c.get("graph_replay", True)):
+            return
+        H, W, fx, fy, cx, cy = s.cam
+        pose = matrix_to_cam_pose(c2w.unsqueeze(0))
+        begin = lambda: self.step.begin_frame(pose[0], color, depth, c["lr_T"], c["lr_R"], H, W, fx, fy, cx, cy, c["ignore_edge_H"],
+                                              c["ignore_edge_W"], betas=(0.5, 0.999), refresh=True)
+        begin()
+        # the loop's run lengths (track_frame): k = max(n - 1 - it, 1) with n = iters or 2 * iters, n possibly switching at it = n - 1
+        n1, n2 = c["iters"], 2 * c["iters"]
+        for k in sorted({max(n1 - 1, 1), 1, max(n2 - 1, 1), max(n2 - 1 - (n1 - 1), 1)}):
+            if k not in self._graphs:
+                self._capture(k, begin)
+        self.params_stale = True
 
 
 class SLAM:
@@ -262,6 +342,18 @@ class SLAM:
     def run(self, n_frames=None, log=None):
         every = self.cfg["mapping"]["every_frame"]
         n = len(self.frames) if n_frames is None else n_frames
+        if n > 0 and self.cfg.get("prewarm", True) and not getattr(self, "_prewarmed", False):
+            # everything a frame would otherwise pay for once, somewhere in the sequence: graph captures of both loops, the joint_opt
+            # scratch, first launches of every kernel -- on a stand-in (frame 0), before the first frame is timed by anyone
+            _, color, depth, gt_c2w, rays_d = self.frames[0]
+            color, depth, gt_c2w = (t.to(self.device) for t in (color, depth, gt_c2w))
+            hz = bool((depth <= 0).any())
+            c = self.cfg["mapping"]
+            if bool(c.get("graph_replay", True)):
+                self.mapper.prewarm([(False, False, hz, c["lr_factor"]), (c["joint_opt"], False, hz, c["lr_factor"]),
+                                     (c["joint_opt"], True, hz, c["lr_factor"])])
+            self.tracker.prewarm(color, depth, gt_c2w)
+            self._prewarmed = True
         for idx in range(n):
             _, color, depth, gt_c2w, rays_d = self.frames[idx]
             color, depth, gt_c2w, rays_d = (t.to(self.device, non_blocking=True) for t in (color, depth, gt_c2w, rays_d))   # disk readers yield CPU tensors (UNISLAM/Tracker.py:303-306)

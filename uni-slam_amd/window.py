@@ -111,23 +111,15 @@ class MapWindow:
         backward, pose step, Adam.  With a process group on the MapStep the same launches run as a data-parallel step (dist.dp_iterate):
         loss statistics and gradient segments are reduced over the ranks, the pose step stays rank-local (a frame's rays live on one
         rank); cut: the SegmentedGraph hook of capture()."""
-        lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
-        b = self.b
+        P, s = L.ptr, self.step
         if t_rand is None:
             t_rand = self.t_rand                                 # the static jitter tensor of capture(t_rand=True), if any
         if zero_depth_draws is None:
             zero_depth_draws = self.zd_draws                     # ... and the static draws of the zero-depth branch
-        poses = P(self.poses) if b > self.first else None
-        nf, ne = self.extra if self.extra else (0, 0)
         if self.R > s.max_rays:
             s._alloc(self.R)
         s.rng_calls += 1
-        tr = P(L.f32(t_rand)) if (s.perturb and t_rand is not None) else None
-        ia, ib = (None, None) if device_draw else (P(self.idx_a), P(self.idx_b) if self.extra else None)
-        L.check(lib.us_window_sample(P(self.c2w_first), poses, b, self.n_per, nf, ne, P(self.pool_d), P(self.pool_c), P(self.pool_r), self.P, ia, ib,
-                                     s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation),
-                                     ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
-                                     P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
+        self._sample(P(L.f32(t_rand)) if (s.perturb and t_rand is not None) else None, device_draw)
         if s.group is not None:
             from .dist import dp_iterate, GradComm
             if self._comm is None or self._comm.engine is not s:
@@ -150,6 +142,17 @@ class MapWindow:
         self._pose_step()
         s.adam_step()
         return loss
+
+    def _sample(self, tr, device_draw):
+        """poses -> pool pixels -> rays -> pre-filter flag, sorted + jittered z, unit-cube points: ONE launch (us_window_sample)"""
+        lib, st, P, s, b = L.lib(), L.stream(), L.ptr, self.step, self.b
+        poses = P(self.poses) if b > self.first else None
+        nf, ne = self.extra if self.extra else (0, 0)
+        ia, ib = (None, None) if device_draw else (P(self.idx_a), P(self.idx_b) if self.extra else None)
+        L.check(lib.us_window_sample(P(self.c2w_first), poses, b, self.n_per, nf, ne, P(self.pool_d), P(self.pool_c), P(self.pool_r), self.P, ia, ib,
+                                     s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation),
+                                     ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
+                                     P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
 
     def _pose_step(self):
         """gradient + Adam of the poses this window optimises (one workgroup per pose), from the ray gradients the backward pass left"""
@@ -311,3 +314,140 @@ class MapWindow:
             if fr:
                 out[torch.as_tensor(fr, device=out.device)] = parts[k][:len(fr)]
         return out
+
+
+class KeyframeArena:
+    """
+    Persistent device store of the keyframes' pixel pools (10 % of a frame each, src/Mapper.py:329-337,516-523): depth [K,P], color
+    [K,P,3], dirs [K,P,3], one row per keyframe, written once when the keyframe is made.  The reference stacks the selected keyframes'
+    pools into fresh tensors for every mapped frame (src/Mapper.py:317-356: b x 2.3 MB, and b grows with the sequence); here a mapping
+    window is a list of ROW NUMBERS, and the pools never move -- 288 GB of HBM hold 500 Replica keyframes in 1.2 GB.
+    Row 0 is scratch: the pool of the frame being mapped.  grow() doubles the store (new addresses: `generation` tells holders of
+    captured graphs).
+    """
+
+    def __init__(self, capacity, pool_size, device):
+        self.K, self.P, self.device = int(capacity), int(pool_size), device
+        self.generation, self.used = 0, 1                        # row 0 = the current frame
+        self._new(self.K)
+
+    def _new(self, K):
+        f = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
+        self.depth, self.color, self.dirs = f(K, self.P) + 1.0, f(K, self.P, 3), f(K, self.P, 3)
+        self.dirs[..., 2] = -1.0                                 # (unused rows hold a harmless pixel: straight ahead, 1 m)
+
+    def grow(self):
+        old = (self.depth, self.color, self.dirs)
+        self.K *= 2
+        self._new(self.K)
+        for new, o in zip((self.depth, self.color, self.dirs), old):
+            new[:o.shape[0]].copy_(o)
+        self.generation += 1
+
+    def alloc(self):
+        if self.used >= self.K:
+            self.grow()
+        self.used += 1
+        return self.used - 1
+
+    def put(self, row, color, depth, dirs):
+        self.color[row].copy_(color.reshape(self.P, 3)); self.depth[row].copy_(depth.reshape(self.P)); self.dirs[row].copy_(dirs.reshape(self.P, 3))
+
+
+class ArenaWindow(MapWindow):
+    """
+    MapWindow over a KeyframeArena with the window's SHAPE on the device (us_arena_window_sample / us_arena_pose_step): a fixed row layout
+    -- rows_a rays for the frames' shares, rows_b for the extra rays of the newest frames -- whatever the number of frames, so ONE captured
+    graph serves every mapped frame of a run: bind() writes the window (arena rows, poses, shape: a few hundred bytes), replay() runs
+    an iteration.  Rows beyond b * (rows_a // b) are padding: rendered, flagged invalid, dropped by the loss like pre-filtered rays.
+    """
+
+    def __init__(self, step, arena, rows_a, rows_b=0, joint_opt=True, cam_lr=1e-3, has_zero_depth=None):
+        self.step, self.arena = step, arena
+        dev = step.device
+        self.P, self.cap = arena.P, arena.K
+        self.rows_a, self.rows_b = int(rows_a), int(rows_b)
+        self.R_a, self.R = self.rows_a, self.rows_a + self.rows_b
+        self.first, self.joint_opt, self.cam_lr = 1, bool(joint_opt), float(cam_lr)
+        self.b, self.n_per, self.extra = 1, self.rows_a, None     # host mirror of the bound window (bind() sets it)
+        self.shape_dev = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.slots = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self._stage = [torch.zeros(8 + self.cap, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._stage_k = 0
+        self.c2w_first = torch.eye(4, device=dev)
+        f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.poses, self.pm, self.pv, self.g_pose = f(self.cap, 7), f(self.cap, 7), f(self.cap, 7), f(self.cap, 7)
+        self.poses[:, 0] = 1.0
+        self.ro, self.rd, self.gd, self.gc, self.dirs = f(self.R, 3), f(self.R, 3), f(self.R), f(self.R, 3), f(self.R, 3)
+        self.idx_a = torch.zeros(self.rows_a, dtype=torch.int64, device=dev)
+        self.idx_b = torch.zeros(max(self.rows_b, 1), dtype=torch.int64, device=dev)
+        self.has_zero = True if has_zero_depth is None else bool(has_zero_depth)
+        self._graph, self.t_rand, self.zd_draws = None, None, None
+        self._comm, self._shard = None, None
+        self.generation = arena.generation
+        self._write_shape([0], self.rows_a, None)
+        if self.R > step.max_rays:
+            step._alloc(self.R)
+
+    def _write_shape(self, slots, n_per, extra):
+        b = len(slots)
+        if b > self.cap:
+            raise L.UniSlamHipError(f"ArenaWindow: {b} frames, capacity {self.cap}")
+        xf, xn = (min(int(extra[0]), b), int(extra[1])) if extra else (0, 0)
+        if b * n_per > self.rows_a or xf * xn > self.rows_b or n_per < 1:
+            raise L.UniSlamHipError(f"ArenaWindow: window of {b} x {n_per} + {xf} x {xn} rays does not fit rows {self.rows_a} + {self.rows_b}")
+        st = self._stage[self._stage_k]; self._stage_k = (self._stage_k + 1) % len(self._stage)
+        st[:8] = torch.tensor([b, n_per, xf, xn, 1, 0, 0, 0], dtype=torch.int32)
+        st[8:8 + b] = torch.as_tensor(slots, dtype=torch.int32)
+        self.shape_dev.copy_(st[:8], non_blocking=True)
+        self.slots[:b].copy_(st[8:8 + b], non_blocking=True)
+        self.b, self.n_per, self.extra = b, int(n_per), ((xf, xn) if xf and xn else None)
+
+    def bind(self, slots, c2ws, n_per, extra=None):
+        """the next window: arena rows of its frames (oldest first, the frame being mapped last), their poses [b,4,4], pixels per frame,
+        extra = None | (n_frames, n_pixels).  Fresh pose moments (src/Mapper.py:358-364: a new optimiser per mapped frame)."""
+        if self.arena.generation != self.generation:
+            raise L.UniSlamHipError("ArenaWindow.bind: the arena has grown since this window (and its graph) was built; build a new one")
+        self._write_shape(slots, n_per, extra)
+        c2ws = L.f32(c2ws.detach().to(self.poses.device))
+        self.c2w_first.copy_(c2ws[0])
+        if self.b > 1:
+            L.check(L.lib().us_matrix_to_cam_pose(L.ptr(c2ws[1:].contiguous()), self.b - 1, 0, L.ptr(self.poses), L.stream()), "us_matrix_to_cam_pose")
+        self.pm.zero_(); self.pv.zero_()
+        return self
+
+    def draw(self, indices=None, indices_extra=None):
+        if indices is None:
+            torch.randint(self.P, (self.rows_a,), device=self.idx_a.device, out=self.idx_a)
+        else:
+            self.idx_a[:indices.numel()].copy_(indices.reshape(-1))
+        if self.rows_b:
+            if indices_extra is None:
+                torch.randint(self.P, (self.rows_b,), device=self.idx_b.device, out=self.idx_b)
+            else:
+                self.idx_b[:indices_extra.numel()].copy_(indices_extra.reshape(-1))
+
+    def rays(self):
+        raise L.UniSlamHipError("ArenaWindow: rays are formed inside the iteration (us_arena_window_sample)")
+
+    def _sample(self, tr, device_draw):
+        lib, st, P, s, a = L.lib(), L.stream(), L.ptr, self.step, self.arena
+        ia, ib = (None, None) if device_draw else (P(self.idx_a), P(self.idx_b))
+        L.check(lib.us_arena_window_sample(P(self.c2w_first), P(self.poses), P(self.shape_dev), P(self.slots), self.rows_a, self.rows_b, P(a.depth),
+                                           P(a.color), P(a.dirs), self.P, ia, ib, s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp,
+                                           ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation), ctypes.c_float(3 * s.truncation), tr, s._seed(0),
+                                           P(s.step_dev), 1 if s.perturb else 0, P(self.ro), P(self.rd), P(self.dirs), P(self.gd), P(self.gc),
+                                           P(s.valid), P(s.z), P(s.pts), st), "us_arena_window_sample")
+
+    def _pose_step(self):
+        lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
+        if not s._step_advanced:
+            L.check(lib.us_adam_step_inc(P(s.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
+            s._step_advanced = True
+        lr = self.cam_lr
+        L.check(lib.us_arena_pose_step(P(self.poses), self.cap, P(self.shape_dev), self.rows_a, P(s.g_o), P(s.g_d), P(self.dirs), P(self.pm), P(self.pv),
+                                       P(self.g_pose), lr, lr, 0.9, 0.999, 1e-8, P(s.step_dev), st), "us_arena_pose_step")
+
+    def c2ws(self):
+        opt = [cam_pose_to_matrix(self.poses[:self.b - 1])] if self.b > 1 else []
+        return torch.cat([self.c2w_first[None]] + opt, dim=0).clone()
