@@ -566,6 +566,19 @@ int us_arena_window_sample(const float* c2w_first, const float* poses7, const in
 int us_arena_pose_step(float* poses7, int n_poses_cap, const int32_t* shape_dev, int64_t rows_a, const float* g_rays_o,
                        const float* g_rays_d, const float* dirs, float* m7, float* v7, float* g7_out, double lr_q, double lr_t,
                        double beta1, double beta2, double eps, float* step_dev, void* stream);
+/* A keyframe's pixel pool (src/Mapper.py:329-337,516-523: torch.randperm(n_pixels)[:pool_size] + three gathers) in one launch: pool row i =
+ * pixel pi(i) of the frame (color [n_pixels][3], depth [n_pixels], dirs [n_pixels][3]), pi a pseudo-random bijection of [0, n_pixels)
+ * keyed by `seed` -- pool_size distinct pixels, no sort.  has_zero (nullable, device int32[1], cleared by the caller): |= 1 if a pool
+ * pixel has no depth. */
+int us_pool_cut(const float* color, const float* depth, const float* dirs, int64_t n_pixels, int64_t pool_size, uint64_t seed,
+                float* pool_color, float* pool_depth, float* pool_dirs, int32_t* has_zero, void* stream);
+/* Mapper.keyframe_selection_LC's overlap measure (src/Mapper.py:188-240) in one launch: pix[n_pix] (flat pixel numbers y * W + x of the
+ * current frame, c2w [4][4], depth [H*W]) -> for each of n_keyframes keyframes (pose pose_list[kf_frames[k]], a rigid [4][4]) the share of
+ * the n_pix * n_samples ray points (pixels without a depth left out; z from 0.8 d to d + 0.5) that project inside its image with an
+ * `edge`-pixel margin and in front of the camera.  intr_host4 = {fx, fy, cx, cy} (host).  percent [n_keyframes]. */
+int us_keyframe_overlap(const float* c2w, const float* depth, const int64_t* pix, int n_pix, int n_samples, const float* intr_host4,
+                        int H, int W, int edge, const float* pose_list, const int64_t* kf_frames, int n_keyframes, float* percent,
+                        void* stream);
 /* The tracker's pose step with the loop's minimum-loss bookkeeping in the same launch (src/Tracker.py:240-242 and :346-348):
  * us_pose_window_step(pose7, 1, ..., rows [0, n_rays), US_POSE_OWN_STEP), and before the step: where loss[0] -- the loss of THIS iteration,
  * rendered at pose7 as it is on entry -- is below min_loss[0], min_loss[0] takes it and best7[7] that pose (`candidate_cam_pose`).  A NaN

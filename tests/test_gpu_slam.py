@@ -147,6 +147,28 @@ def test_keyframe_selection_on_device():
     assert sel == [0, 1, 2]                                                 # "global": every keyframe joins the window
     sel, pct, loop = keyframe_selection_LC(3, 10, color, depth, c2w, 2, [0, 1, 2, 3, 4], est, cam, DEV, tracking_back=True)
     assert sorted(sel) == [0, 1]                                            # tracking back: the best-overlapping ones
+    # device tensors take the fused path (us_keyframe_overlap: one launch for all keyframes); the torch chain of src/Mapper.py:188-240 on
+    # the SAME pixel draw gives the same shares (a point within rounding of an image border may count differently: 1 / 400)
+    from unislam_amd import slam as S
+    from unislam_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(3)
+    pix = torch.randint(frames.H * frames.W, (50,), device=DEV, generator=g)
+    d = depth.clone(); d.view(-1)[pix[:5]] = 0.0                            # pixels without a depth are left out
+    out = torch.zeros(3, device=DEV)
+    kf = torch.tensor([0, 1, 2], device=DEV)
+    L.check(L.lib().us_keyframe_overlap(L.ptr(c2w.contiguous()), L.ptr(d), L.ptr(pix), 50, 8, L.host_floats([frames.fx, frames.fy, frames.cx, frames.cy]),
+                                        frames.H, frames.W, 20, L.ptr(est.contiguous()), L.ptr(kf), 3, L.ptr(out), L.stream()), "us_keyframe_overlap")
+    x, y = (pix % frames.W).float(), (pix // frames.W).float()
+    dirs = torch.stack([(x - frames.cx) / frames.fx, -(y - frames.cy) / frames.fy, -torch.ones_like(x)], -1)
+    rd = (dirs[:, None, :] * c2w[:3, :3]).sum(-1); ro = c2w[:3, 3].expand(rd.shape)
+    gd = d.view(-1)[pix]
+    nz = gd > 0
+    t = torch.linspace(0., 1., 8, device=DEV)
+    z = gd[nz][:, None] * 0.8 * (1 - t) + (gd[nz][:, None] + 0.5) * t
+    pts = (ro[nz][:, None] + rd[nz][:, None] * z[..., None]).reshape(-1, 3)
+    ref = S.keyframe_overlap(pts, est[:3], frames.H, frames.W, frames.fx, frames.fy, frames.cx, frames.cy)
+    assert float((out - ref).abs().max()) <= 1.01 / pts.shape[0], (out, ref)
+    assert float(out[0]) > 0.3 and float(out[2]) == 0.0
 
 
 def test_slam_from_a_sequence_on_disk(tmp_path):
@@ -221,3 +243,32 @@ def test_config5_standin_full_loop_4096_rays_bf16():
     assert rep["compared_pose_pairs"] == n
     assert ate < 0.02, ate                                                  # 2 cm over ~0.4 m of motion
     assert rq["frames"] == 5 and rq["avg_psnr"] > 18.0 and rq["depth_l1_render"] < 0.05, rq
+
+
+@pytest.mark.parametrize("H,W", [(680, 1200), (120, 160), (7, 5)])
+def test_pool_cut_is_a_random_subset_without_repetition(H, W):
+    """us_pool_cut (KeyframeArena.cut): src/Mapper.py:329-337's `randperm(H * W)[:10 %]` + three gathers as one launch -- the pool's rows are
+    DISTINCT pixels of the frame with their colour / depth / direction, a different subset per seed, spread evenly over the frame; the
+    flag reports pixels without a depth"""
+    import unislam_amd as us
+    g = torch.Generator().manual_seed(H)
+    n = H * W
+    color = torch.rand(H, W, 3, generator=g).to(DEV); dirs = torch.randn(H, W, 3, generator=g).to(DEV)
+    depth = (torch.arange(n, dtype=torch.float32).reshape(H, W) + 1.0).to(DEV)      # depth = pixel number + 1: the pool tells which pixels it took
+    P = max(1, int(n * 0.1))
+    arena = us.KeyframeArena(3, P, DEV)
+    flag = arena.cut(1, color, depth, dirs, seed=5)
+    pix = (arena.depth[1] - 1.0).long()
+    assert int(flag) == 0 and int(pix.min()) >= 0 and int(pix.max()) < n
+    assert torch.unique(pix).numel() == P                                           # no pixel twice
+    assert torch.equal(arena.color[1], color.reshape(-1, 3)[pix]) and torch.equal(arena.dirs[1], dirs.reshape(-1, 3)[pix])
+    arena.cut(2, color, depth, dirs, seed=6)
+    if P > 8:
+        assert not torch.equal(arena.depth[1], arena.depth[2])                      # another seed, another subset
+        both = torch.cat([pix, (arena.depth[2] - 1.0).long()])
+        assert torch.unique(both).numel() > 1.7 * P                                 # two independent 10 % subsets share ~1 % of the frame
+    if n > 500000:                                                                  # evenly spread: every sixteenth of the frame holds its share (5100 +- 71)
+        share = torch.bincount(pix * 16 // n, minlength=16).float() / P
+        assert float((share - 1 / 16).abs().max()) < 0.08 / 16, share
+    depth2 = depth.clone(); depth2.view(-1)[pix[:1]] = 0.0                          # a hole at a pixel this seed takes
+    assert int(arena.cut(1, color, depth2, dirs, seed=5)) == 1

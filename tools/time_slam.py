@@ -12,7 +12,7 @@ from unislam_amd.slam import SLAM
 
 DEV = "cuda:0"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-replay = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+replay = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 torch.manual_seed(0)
 frames = SyntheticRoom(n_frames=n, H=680, W=1200, device=DEV)
 for i in range(n):
@@ -41,6 +41,7 @@ def timed(fn, sink):
     return f
 
 
+slam.mapper.timing = {} if os.environ.get("US_SLAM_TIMING") else None
 slam.tracker.track_frame = timed(tr, t_track)
 slam.mapper.map_frame = timed(mp, t_map)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -52,3 +53,6 @@ print(f"frames {n} graph_replay {replay}: {1e3 * el / n:.2f} ms per frame ({n / 
       f"ATE {100 * slam.ate_rmse():.2f} cm; keyframes {len(slam.mapper.keyframe_list)}")
 print("tracking ms:", " ".join(f"{1e3 * t:.1f}" for t in t_track[:24]))
 print("mapping  ms:", " ".join(f"{1e3 * t:.1f}" for t in t_map[:24]))
+if slam.mapper.timing:
+    for k, v in slam.mapper.timing.items():
+        print(f"  {k:36s} median {sorted(v)[len(v) // 2]:.3f} ms   all: " + " ".join(f"{x:.2f}" for x in v[:14]))

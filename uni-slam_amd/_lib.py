@@ -142,6 +142,8 @@ SIGNATURES = {
     "us_arena_window_sample": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_f, c_i64, c_f, c_f, _HF, c_f, c_int, c_f, c_int, c_flt, c_flt, c_flt,
                                        c_f, ctypes.c_uint64, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_arena_pose_step": (c_int, [c_f, c_int, c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
+    "us_pool_cut": (c_int, [c_f, c_f, c_f, c_i64, c_i64, ctypes.c_uint64, c_f, c_f, c_f, c_f, c_f]),
+    "us_keyframe_overlap": (c_int, [c_f, c_f, c_f, c_int, c_int, _HF, c_int, c_int, c_int, c_f, c_f, c_int, c_f, c_f]),
     "us_window_rays": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "us_pose_window_step": (c_int, [c_f, c_int, c_f, c_f, c_f, c_i64, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_f, c_dbl, c_dbl, c_dbl, c_dbl,
                                     c_dbl, c_f, c_int, c_f]),

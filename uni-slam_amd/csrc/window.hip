@@ -253,6 +253,124 @@ extern "C" int us_pose_track_step(float* pose7, const float* g_rays_o, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A keyframe's pixel pool (src/Mapper.py:329-337,516-523: `torch.randperm(H * W)[:int(0.1 * H * W)]`, then three gathers): a uniformly
+// random subset of the frame's pixels WITHOUT repetition.  The reference sorts 816 000 random keys for it; here thread i takes pixel
+// pi(i), pi a keyed pseudo-random bijection of [0, n_pixels) -- a four-round Feistel network on the next even power of two with cycle
+// walking (values that land beyond n_pixels are permuted again: 1.3 rounds on average for a 680 x 1200 frame) -- so the first pool_size
+// images are distinct pixels and no sort, no index tensor and no second pass exist.  One launch; has_zero[0] |= 1 where the pool holds
+// a pixel without a depth (it decides whether the window's iterations carry the branch of src/utils/Renderer.py:104-130).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pool_mix(uint32_t x, uint32_t k) {
+    x ^= k; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_pool_cut(const float* __restrict__ color, const float* __restrict__ depth, const float* __restrict__ dirs,
+                                                  uint32_t n_pixels, uint32_t pool_size, int half_bits, uint32_t k0, uint32_t k1, uint32_t k2,
+                                                  uint32_t k3, float* __restrict__ pool_color, float* __restrict__ pool_depth,
+                                                  float* __restrict__ pool_dirs, int32_t* __restrict__ has_zero) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool zero = false;
+    if (i < pool_size) {
+        const uint32_t mask = (1u << half_bits) - 1u;
+        uint32_t x = i;
+        do {                                                       // a bijection of [0, 4^half_bits); walked until it lands in [0, n_pixels)
+            uint32_t l = x >> half_bits, r = x & mask;
+            const uint32_t keys[4] = {k0, k1, k2, k3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const uint32_t t = l ^ (pool_mix(r, keys[q]) & mask); l = r; r = t; }
+            x = (l << half_bits) | r;
+        } while (x >= n_pixels);
+        const float d = depth[x];
+        pool_depth[i] = d;
+        zero = !(d > 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pool_color[i * 3 + c] = color[(size_t)x * 3 + c]; pool_dirs[i * 3 + c] = dirs[(size_t)x * 3 + c]; }
+    }
+    if (has_zero && __any(zero) && (threadIdx.x & 63) == 0) atomicOr(has_zero, 1);
+}
+
+extern "C" int us_pool_cut(const float* color, const float* depth, const float* dirs, int64_t n_pixels, int64_t pool_size, uint64_t seed,
+                           float* pool_color, float* pool_depth, float* pool_dirs, int32_t* has_zero, void* stream) {
+    US_REQUIRE(color && depth && dirs && pool_color && pool_depth && pool_dirs, US_ERR_NULL, "us_pool_cut: NULL pointer");
+    US_REQUIRE(n_pixels >= 1 && n_pixels <= (1ll << 30) && pool_size >= 0 && pool_size <= n_pixels, US_ERR_SHAPE,
+               "us_pool_cut: n_pixels %lld, pool_size %lld", (long long)n_pixels, (long long)pool_size);
+    if (pool_size == 0) return US_OK;
+    int half = 1;
+    while ((1ll << (2 * half)) < n_pixels) ++half;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;                    // four round keys: splitmix64 of the seed
+    uint32_t k[4];
+    for (int q = 0; q < 4; q += 2) {
+        z += 0x9E3779B97F4A7C15ull;
+        uint64_t t = z; t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ull; t = (t ^ (t >> 27)) * 0x94D049BB133111EBull; t ^= t >> 31;
+        k[q] = (uint32_t)t; k[q + 1] = (uint32_t)(t >> 32);
+    }
+    hipLaunchKernelGGL(k_pool_cut, dim3((unsigned)us_cdiv(pool_size, 256)), dim3(256), 0, (hipStream_t)stream, color, depth, dirs, (uint32_t)n_pixels,
+                       (uint32_t)pool_size, half, k[0], k[1], k[2], k[3], pool_color, pool_depth, pool_dirs, has_zero);
+    US_CHECK_LAUNCH("us_pool_cut");
+    return US_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keyframe overlap (Mapper.keyframe_selection_LC, src/Mapper.py:188-240): n_pix random pixels of the current frame with a depth, n_samples
+// points along each ray between 0.8 d and d + 0.5, and for every keyframe the share of those points that project inside its image
+// (20-pixel margin, in front of the camera).  The reference runs ~25 torch ops over [K, M, 4, 1] temporaries and a batched matrix
+// inverse; here one workgroup per keyframe forms the points on the fly.  kf_frames[k]: row of pose_list (the estimated trajectory) that
+// keyframe k uses; its world -> camera transform is the rigid inverse.
+// ---------------------------------------------------------------------------------------------------------------
+struct OverlapCam { float fx, fy, cx, cy; int H, W, edge; };
+__global__ __launch_bounds__(256) void k_keyframe_overlap(const float* __restrict__ c2w, const float* __restrict__ depth, const int64_t* __restrict__ pix,
+                                                          int n_pix, int n_samples, OverlapCam cam, const float* __restrict__ pose_list,
+                                                          const int64_t* __restrict__ kf_frames, float* __restrict__ percent) {
+    __shared__ int sh_in[4], sh_all[4];
+    const float* Mk = pose_list + kf_frames[blockIdx.x] * 16;
+    int n_in = 0, n_all = 0;
+    for (int m = threadIdx.x; m < n_pix * n_samples; m += 256) {
+        const int r = m / n_samples, sidx = m - r * n_samples;
+        const int64_t p = pix[r];
+        const float gd = depth[p];
+        if (!(gd > 0.0f)) continue;                                 // Mapper.py:196-199: rays without a depth are left out
+        const float x = (float)(p % cam.W), y = (float)(p / cam.W);
+        const float dc[3] = {(x - cam.cx) / cam.fx, -(y - cam.cy) / cam.fy, -1.0f};
+        const float t = n_samples > 1 ? (float)sidx / (float)(n_samples - 1) : 0.0f;
+        const float z = gd * 0.8f * (1.0f - t) + (gd + 0.5f) * t;
+        float pw[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            pw[a] = c2w[a * 4 + 3] + ((dc[0] * c2w[a * 4] + dc[1] * c2w[a * 4 + 1]) + dc[2] * c2w[a * 4 + 2]) * z;
+        float pc[3];                                                // R^T (p - t): the keyframe's camera frame
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            pc[a] = Mk[a] * (pw[0] - Mk[3]) + Mk[4 + a] * (pw[1] - Mk[7]) + Mk[8 + a] * (pw[2] - Mk[11]);
+        pc[0] = -pc[0];
+        const float zz = pc[2] + 1e-5f;
+        const float u = (cam.fx * pc[0] + cam.cx * pc[2]) / zz, v = (cam.fy * pc[1] + cam.cy * pc[2]) / zz;
+        const bool in = u < (float)(cam.W - cam.edge) && u > (float)cam.edge && v < (float)(cam.H - cam.edge) && v > (float)cam.edge && zz < 0.0f;
+        ++n_all; n_in += in ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { n_in += __shfl_xor(n_in, o, 64); n_all += __shfl_xor(n_all, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh_in[threadIdx.x >> 6] = n_in; sh_all[threadIdx.x >> 6] = n_all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = sh_in[0] + sh_in[1] + sh_in[2] + sh_in[3], b = sh_all[0] + sh_all[1] + sh_all[2] + sh_all[3];
+        percent[blockIdx.x] = b > 0 ? (float)a / (float)b : 0.0f;
+    }
+}
+
+extern "C" int us_keyframe_overlap(const float* c2w, const float* depth, const int64_t* pix, int n_pix, int n_samples, const float* intr_host4,
+                                   int H, int W, int edge, const float* pose_list, const int64_t* kf_frames, int n_keyframes, float* percent,
+                                   void* stream) {
+    if (n_keyframes <= 0) return n_keyframes == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(c2w && depth && pix && intr_host4 && pose_list && kf_frames && percent, US_ERR_NULL, "us_keyframe_overlap: NULL pointer");
+    US_REQUIRE(n_pix >= 1 && n_samples >= 1 && H >= 1 && W >= 1, US_ERR_SHAPE, "us_keyframe_overlap: bad shape");
+    OverlapCam cam;
+    cam.fx = intr_host4[0]; cam.fy = intr_host4[1]; cam.cx = intr_host4[2]; cam.cy = intr_host4[3]; cam.H = H; cam.W = W; cam.edge = edge;
+    hipLaunchKernelGGL(k_keyframe_overlap, dim3((unsigned)n_keyframes), dim3(256), 0, (hipStream_t)stream, c2w, depth, pix, n_pix, n_samples, cam,
+                       pose_list, kf_frames, percent);
+    US_CHECK_LAUNCH("us_keyframe_overlap");
+    return US_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // pose <-> matrix (src/common.py:182-208): the per-frame glue of both drivers.  On torch ops one conversion is a chain of ~30 / ~20
 // small launches (0.43 / 0.25 ms of host time each, MI355X box) -- a third of a tracked frame; here one launch each.
 // ---------------------------------------------------------------------------------------------------------------

@@ -56,6 +56,9 @@ def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyf
     Returns (selected list, percent_inside, loop_closure).
     """
     H, W, fx, fy, cx, cy = cam
+    if gt_depth.is_cuda and torch.is_tensor(estimate_c2w_list) and estimate_c2w_list.is_cuda:
+        return _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, tracking_back,
+                                          activated_mapping_mode, LC, num_samples, num_rays)
     rays_o, rays_d, gd, _ = get_samples(0, H, 0, W, num_rays, H, W, fx, fy, cx, cy, c2w.unsqueeze(0), gt_depth.unsqueeze(0),
                                         gt_color.unsqueeze(0), device)
     gd = gd.reshape(-1, 1)
@@ -64,13 +67,18 @@ def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyf
     t_vals = torch.linspace(0., 1., steps=num_samples).to(device)
     z_vals = gd * 0.8 * (1. - t_vals) + (gd + 0.5) * t_vals
     pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]).reshape(-1, 3)
-    kf_c2ws = torch.stack([estimate_c2w_list[k] for k in keyframe_list], dim=0)[:-2]      # the last two are included anyway
+    if torch.is_tensor(estimate_c2w_list):                                               # (one gather instead of a slice per keyframe)
+        kf_c2ws = estimate_c2w_list[torch.as_tensor(keyframe_list[:-2], dtype=torch.long, device=estimate_c2w_list.device)] if len(keyframe_list) > 2 \
+            else estimate_c2w_list[:0]
+    else:
+        kf_c2ws = torch.stack([estimate_c2w_list[k] for k in keyframe_list], dim=0)[:-2]  # the last two are included anyway
     loop = False
     if kf_c2ws.shape[0] > 0:
         percent_inside = keyframe_overlap(pts, kf_c2ws, H, W, fx, fy, cx, cy)
-        idx1 = keyframe_list[int(torch.argmax(percent_inside))]
-        if percent_inside.max() > 0.95 and (idx - idx1) > 100 and LC:
-            selected = list(range(0, num))[int(torch.argmax(percent_inside)):]           # only the frames of this loop
+        best = int(torch.argmax(percent_inside))
+        idx1 = keyframe_list[best]
+        if (idx - idx1) > 100 and LC and float(percent_inside[best]) > 0.95:
+            selected = list(range(0, num))[best:]                                        # only the frames of this loop
             loop = True
         else:
             selected = list(range(0, num))
@@ -98,6 +106,34 @@ def rigid_inverse(c2ws):
     return out
 
 
+def _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, tracking_back,
+                               activated_mapping_mode, LC, num_samples, num_rays):
+    """keyframe_selection_LC for device tensors: the pixel draw, ONE launch for the overlap of every keyframe (us_keyframe_overlap: rays,
+    points, rigid inverse and projection on the fly), ONE read of the K shares; the selection rules on the host as above"""
+    from . import _lib as L
+    H, W, fx, fy, cx, cy = cam
+    dev = gt_depth.device
+    K = len(keyframe_list) - 2
+    loop, selected = False, list(range(0, num))
+    pct = torch.zeros(max(K, 0), device=dev)
+    vals = []
+    if K > 0:
+        pix = torch.randint(H * W, (num_rays,), device=dev)                              # common.py:116: the draw of get_samples
+        kf = torch.as_tensor(keyframe_list[:K], dtype=torch.int64, device=dev)
+        L.check(L.lib().us_keyframe_overlap(L.ptr(L.f32(c2w)), L.ptr(L.f32(gt_depth)), L.ptr(pix), num_rays, num_samples, L.host_floats([fx, fy, cx, cy]),
+                                            H, W, 20, L.ptr(L.f32(estimate_c2w_list)), L.ptr(kf), K, L.ptr(pct), L.stream()), "us_keyframe_overlap")
+        vals = pct.tolist()                                                              # the one host read of the selection
+        best = max(range(K), key=lambda k: (vals[k], -k))                                # argmax, the first of equal maxima
+        if vals[best] > 0.95 and (idx - keyframe_list[best]) > 100 and LC:
+            selected, loop = list(range(0, num))[best:], True
+    if tracking_back and activated_mapping_mode:
+        selected = []
+        if K > 0:
+            order = sorted(range(K), key=lambda k: vals[k], reverse=True)
+            selected = [k for k in order if vals[k] > 0.00][:num_keyframes]
+    return selected, pct, loop
+
+
 class Mapper:
     """Mapper.run body for one frame + optimize_mapping (src/Mapper.py:276-459,461-545).
 
@@ -121,16 +157,15 @@ class Mapper:
         self.kf_c2w = torch.zeros((self.arena.K, 4, 4), device=slam.device)             # est_c2w per arena row (src/Mapper.py:447-457 writes them back)
         self._wins = {}
         self.cur_has_zero = False
+        self.timing = None
 
     # ---------------------------------------------------------------------------------------------- pools
     def _pool_into(self, row, color, depth, rays_d):
         """10 % of the pixels of a frame as its sampling pool (Mapper.py:329-337,516-523), written into arena row `row`; returns whether the
         pool holds pixels without a depth (one host read per pool: it picks the window's graph)"""
-        total = color.shape[0] * color.shape[1]
-        ind = torch.randperm(total, device=color.device)[:self.arena.P]
-        pd = depth.reshape(-1)[ind]
-        self.arena.put(row, color.reshape(-1, 3)[ind], pd, rays_d.reshape(-1, 3)[ind])
-        return bool((pd <= 0).any())
+        self._pool_count = getattr(self, "_pool_count", 0) + 1
+        seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._pool_count) & (2 ** 64 - 1)
+        return bool(int(self.arena.cut(row, color, depth, rays_d, seed)))
 
     def _window(self, joint, extra_on, has_zero, lr_factor):
         """the ArenaWindow (and its graph) for this kind of mapped frame"""
@@ -159,11 +194,35 @@ class Mapper:
         for k in kinds:
             self._window(*k)
         self.step.reset_optimizer(1.0)
+        # keyframe selection on a stand-in list: its first call loads a dozen torch kernels and the BLAS library behind the batched
+        # projection (0.25 s when that happened at the fourth keyframe)
+        s = self.s
+        H, W = s.cam[0], s.cam[1]
+        eye = torch.eye(4, device=s.device)
+        est = eye[None].repeat(5, 1, 1)
+        keyframe_selection_LC(3, 4, torch.zeros((H, W, 3), device=s.device), torch.ones((H, W), device=s.device), eye, c["mapping_window_size"] - 1,
+                              [0, 1, 2, 3, 4], est, s.cam, s.device, False, s.cfg["tracking"]["activated_mapping_mode"], c["LC"])
+        keyframe_selection_LC(3, 4, torch.zeros((H, W, 3), device=s.device), torch.ones((H, W), device=s.device), eye, c["mapping_window_size"] - 1,
+                              [0, 1, 2, 3, 4], est, s.cam, s.device, True, s.cfg["tracking"]["activated_mapping_mode"], c["LC"])
+        self._pool_into(0, torch.zeros((H, W, 3), device=s.device), torch.ones((H, W), device=s.device), torch.zeros((H, W, 3), device=s.device))
+        torch.cuda.synchronize()
 
     # ---------------------------------------------------------------------------------------------- one mapped frame
+    def _mark(self, name):
+        """development: with self.timing = {} set, wall time (device synchronised) of the phases of a mapped frame"""
+        if self.timing is not None:
+            import time
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            self.timing.setdefault(name, []).append(1e3 * (t - self._t_mark))
+            self._t_mark = t
+
     def optimize_mapping(self, iters, lr_factor, idx, cur_color, cur_depth, cur_c2w, cur_rays_d):
         s, c, dev = self.s, self.c, self.s.device
         kd, kl = self.keyframe_dict, self.keyframe_list
+        if self.timing is not None:
+            import time
+            torch.cuda.synchronize(); self._t_mark = time.perf_counter()
         if len(kd) == 0:
             optimize_frame = []
         else:
@@ -174,6 +233,7 @@ class Mapper:
         if len(kl) > 1:
             optimize_frame = sorted(optimize_frame + [len(kl) - 1] + [len(kl) - 2])
         optimize_frame += [-1]                                                          # -1 = the current frame
+        self._mark("keyframe selection")
         b = len(optimize_frame)
         pixs_per_image = c["pixels"] // b
         # the window = arena rows: the selected keyframes' (written when they were made), row 0 = the pool of the frame being mapped
@@ -184,17 +244,21 @@ class Mapper:
         has_zero = self.cur_has_zero or any(kd[f]["has_zero"] for f in optimize_frame if f != -1)
         joint = self.joint_opt and b > 1
         extra = (10, 200) if (not s.tracking_back and len(kl) > 20) else None           # extra rays from the newest frames (:381-390)
+        self._mark("pool of the frame + window rows")
         win = self._window(joint, extra is not None, has_zero, lr_factor)
         self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
         win.bind(rows, c2ws, pixs_per_image, extra)
+        self._mark("optimiser reset + bind")
         # the loop of :366-445: pose -> rays, render, loss, backward, pose step and Adam are HIP launches on static buffers, one graph
         step = win.replay if win._graph is not None else win.iterate
         for _ in range(int(iters)):
             step()
+        self._mark("iterations")
         if joint:
             opt = win.c2ws()                                                            # put the updated camera poses back (:447-457)
             self.kf_c2w[torch.as_tensor(rows[1:], device=dev)] = opt[1:]
             cur_c2w = opt[-1]
+        self._mark("pose write-back")
         return cur_c2w
 
     def map_frame(self, idx, color, depth, gt_c2w, rays_d):
@@ -215,6 +279,8 @@ class Mapper:
             hz = self._pool_into(row, color, depth, rays_d)
             self.kf_c2w[row] = cur_c2w
             self.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "row": row, "has_zero": hz})
+            if self.timing is not None:
+                self._mark("new keyframe's pool")
         self.init_phase = False
 
     def keyframe_pose(self, k):

@@ -353,6 +353,15 @@ class KeyframeArena:
     def put(self, row, color, depth, dirs):
         self.color[row].copy_(color.reshape(self.P, 3)); self.depth[row].copy_(depth.reshape(self.P)); self.dirs[row].copy_(dirs.reshape(self.P, 3))
 
+    def cut(self, row, color, depth, dirs, seed):
+        """row <- a random subset of P distinct pixels of the frame (color [H,W,3], depth [H,W], dirs [H,W,3]): Mapper.py:329-337's
+        randperm + gathers as ONE launch (us_pool_cut).  Returns a device int32[1]: 1 if the pool holds a pixel without a depth."""
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        c, d, r = L.f32(color), L.f32(depth), L.f32(dirs)
+        L.check(L.lib().us_pool_cut(L.ptr(c), L.ptr(d), L.ptr(r), d.numel(), self.P, int(seed) & (2 ** 64 - 1), L.ptr(self.color[row]), L.ptr(self.depth[row]),
+                                    L.ptr(self.dirs[row]), L.ptr(flag), L.stream()), "us_pool_cut")
+        return flag
+
 
 class ArenaWindow(MapWindow):
     """
