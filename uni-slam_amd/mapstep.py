@@ -195,6 +195,8 @@ class MapStep:
 
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self, R):
+        # generation: bumped whenever buffers a captured graph may hold change their addresses (MapWindow compares it before a replay)
+        self.generation = getattr(self, "generation", 0) + 1
         self._join_side_streams()
         self._step_advanced = False
         dev, S = self.device, self.S

@@ -299,7 +299,7 @@ class Tracker:
                               c["w"], mask_mode=slam.cfg["t_mask_mode"], perturb=r["perturb"], max_rays=c["pixels"])
         self.num_cam_iters = c["iters"]
         self.rendered_weight = {}
-        self._graphs = {}
+        self._graphs, self._graphs_gen = {}, 0
         self.params_stale = True                                                        # set by SLAM.run after every mapping pass
 
     def track_frame(self, idx, color, depth):
@@ -326,6 +326,8 @@ class Tracker:
                 for _ in range(k):
                     out = self.step.iterate_fused(n_pix)
                 return out
+            if self._graphs and self._graphs_gen != self.step.generation:
+                self._graphs.clear()                                                    # TrackStep reallocated: the graphs hold old addresses
             if k not in self._graphs:
                 self._capture(k, begin)
             return self._graphs[k].replay()
@@ -362,6 +364,7 @@ class Tracker:
                 out = self.step.iterate_fused(n_pix)
             return out
         self._graphs[k] = CapturedIteration(body, warmup=0)
+        self._graphs_gen = self.step.generation
 
     def prewarm(self, color, depth, c2w):
         """capture the run lengths a sequence meets (iters - 1 up to the loop's host decision, 1 behind it, and their doubled forms while

@@ -42,6 +42,8 @@ class TrackStep:
         self._alloc(max_rays)
 
     def _alloc(self, R):
+        # generation: bumped whenever a buffer a captured graph may hold changes its address (holders compare it before a replay)
+        self.generation = getattr(self, "generation", 0) + 1
         dev, S = self.device, self.S
         N = R * S
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -73,6 +75,8 @@ class TrackStep:
             if old is not None and old.shape == new.shape and old.data_ptr() != new.data_ptr():
                 old.copy_(new)
             else:
+                if old is not None and old.data_ptr() != new.data_ptr():
+                    self.generation = getattr(self, "generation", 0) + 1        # a captured graph holds the old address
                 setattr(self, name, new)
         ps, pc = self._decoder_params()
         keep("_ps", ps); keep("_pc", pc)

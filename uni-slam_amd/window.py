@@ -245,11 +245,15 @@ class MapWindow:
         finally:
             restore()                                            # (the capture pass does not execute; its host-side counters are undone)
             s.probe = keep[11]
-        self._graph = graph
+        self._graph, self._graph_gen = graph, s.generation
 
     def replay(self, indices=None, indices_extra=None):
         if self._graph is None:
             raise L.UniSlamHipError("MapWindow.replay: call capture() first")
+        if self.step.generation != self._graph_gen:              # e.g. a later, larger window on the same MapStep made it reallocate
+            self._graph = None
+            raise L.UniSlamHipError("MapWindow.replay: the MapStep's buffers were reallocated after this graph was captured (it holds the "
+                                    "old addresses); capture() again")
         if self._device_draw:
             if indices is not None:
                 raise L.UniSlamHipError("MapWindow.replay: this graph draws its pixels itself; capture(device_draw=False) to pass indices")
