@@ -183,16 +183,18 @@ int us_hashgrid_bwd_input(const float* dL_dy, const float* dy_dx, int64_t n, uin
 int us_hashgrid_bwd_input_gather(const us_grid_desc* desc_host, const float* params, const float* x, const float* dL_dy,
                                  int64_t n, float* dL_dx, int flags, void* stream);
 
-/* us_hashgrid_fwd_joint that also leaves d(features)/d(position) of both grids: dy_dxA / dy_dxB = planes [L][3][N][2]
- * (level l, dimension gd, point i: the two features' derivatives; tcnn's dy_dx with the clamp's zero gradient folded in), 24 B per
- * (point, level, grid), written in whole lines by the threads that hold the 8 vertices anyway.  us_hashgrid_dydx_rays contracts them with
- * dL/dy and reduces to the rays: dL_do, dL_dd (and the per-point dL_dx, nullable) are bit-identical to us_hashgrid_bwd_input_rays, at
- * the price of a stream instead of a second gather pass over the tables (MI355X, 2000 x 40 points: 20 against 65 us).  For the
- * iterations that differentiate with respect to the camera: src/Tracker.py:170-174,241 and src/Mapper.py:372-376,444. */
+/* us_hashgrid_fwd_joint that also leaves d(features)/d(position) of both grids: dy_dxA / dy_dxB = planes [L][3][N][2] of IEEE HALF
+ * values (level l, dimension gd, point i: the two features' derivatives; tcnn's dy_dx with the clamp's zero gradient folded in), 12 B
+ * per (point, level, grid), written in whole lines by the threads that hold the 8 vertices anyway.  us_hashgrid_dydx_rays contracts them
+ * with dL/dy and reduces to the rays: dL_do, dL_dd (and the per-point dL_dx, nullable) equal us_hashgrid_bwd_input_rays to the rounding
+ * of the stored halves (2^-11 per value; a scratch tensor between two kernels of one iteration, never a result), at the price of a stream
+ * instead of a second gather pass over the tables (MI355X, 2000 x 40 points: 20 against 65 us).  For the iterations that differentiate with respect to
+ * the camera: src/Tracker.py:170-174,241 and src/Mapper.py:372-376,444. */
+typedef uint16_t us_half_t;              /* the bits of an IEEE binary16 value (torch.float16) */
 int us_hashgrid_fwd_joint_dydx(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB, const float* x,
-                               int64_t n, float* outA, float* outB, float* dy_dxA, float* dy_dxB, int flags, void* workspace,
+                               int64_t n, float* outA, float* outB, us_half_t* dy_dxA, us_half_t* dy_dxB, int flags, void* workspace,
                                size_t workspace_bytes, void* stream);
-int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, const float* dL_dyB, const float* dy_dxA, const float* dy_dxB,
+int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, const float* dL_dyB, const us_half_t* dy_dxA, const us_half_t* dy_dxB,
                           int64_t n_rays, int n_samples, const float* z_vals, const float* bound_host, float* dL_do, float* dL_dd,
                           float* dL_dx, void* stream);
 
@@ -275,7 +277,7 @@ int us_mlp_bwd_pair_dydx(const us_mlp_desc* da, const us_mlp_desc* db, const flo
                          const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
                          const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
                          float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
-                         void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dL_dpts_a,
+                         void* workspace_b, size_t workspace_bytes, const us_half_t* dy_dx_a, const us_half_t* dy_dx_b, float* dL_dpts_a,
                          float* dL_dpts_b, void* stream);
 /* us_mlp_reduce_pair with torch.optim.Adam of the decoder param group folded in (src/Mapper.py:118,443-445; single process): the
  * gradients are the fixed-order sums of the partial rows us_mlp_bwd_pair(US_MLP_DEFER_REDUCE) left (WRITTEN to grad_params_*, no cleared

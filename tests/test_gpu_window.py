@@ -98,7 +98,7 @@ def test_window_rays_and_pose_step_against_autograd():
 @pytest.mark.parametrize("S,pair", [(64, (16, 19)), (40, (14, 15)), (96, (16, 16)), (7, (12, 12))])
 def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
     """us_hashgrid_bwd_input_rays: per-point dL/dx bit-identical to two us_hashgrid_bwd_input_gather launches, dL/do and dL/dd equal to
-    us_ray_points_bwd of it (summation order differs: 1e-5)"""
+    us_ray_points_bwd of it (summation order differs: 1e-5); the stored-derivative path (half-precision dy/dx planes) against both"""
     import ctypes
     import unislam_amd as us
     from unislam_amd import _lib as L
@@ -133,7 +133,7 @@ def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
     assert lib.us_hashgrid_bwd_input_rays_supported(ds, dc, 129) == 0
     # the stored-derivative path: the joint encoder leaves dy/dx (planes [L][3][N][2]), one streaming launch contracts it
     fa, fb, fa0, fb0 = f(16, N, 2), f(16, N, 2), f(16, N, 2), f(16, N, 2)
-    dda, ddb = f(16, 3, N, 2), f(16, 3, N, 2)                                   # planes [L][3][N][2]
+    dda, ddb = (torch.empty((16, 3, N, 2), dtype=torch.float16, device=DEV) for _ in range(2))      # planes [L][3][N][2] of halves
     L.check(lib.us_hashgrid_fwd_joint(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), N, P_(fa0), P_(fb0), 3, None, 0, L.stream()), "fwd")
     L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P_(es.params.detach()), P_(ec.params.detach()), P_(x), N, P_(fa), P_(fb), P_(dda), P_(ddb), 3,
                                            None, 0, L.stream()), "us_hashgrid_fwd_joint_dydx")
@@ -141,10 +141,13 @@ def test_input_gradient_of_both_grids_reduced_to_rays(S, pair):
     # dy/dx against the one-grid encoder's stored tensor [N][C][3]
     ref_dd = f(N, 32, 3); tmp = f(N, 32)
     L.check(lib.us_hashgrid_fwd(dc, P_(ec.params.detach()), P_(x), N, P_(tmp), P_(ref_dd), 1, L.stream()), "us_hashgrid_fwd")
-    assert torch.equal(ddb.permute(2, 0, 3, 1).reshape(N, 32, 3), ref_dd)
+    assert torch.equal(ddb.permute(2, 0, 3, 1).reshape(N, 32, 3), ref_dd.half())   # the one-grid encoder's values, rounded once to half
     d3, go3, gd3 = f(N, 3), f(R, 3), f(R, 3)
     L.check(lib.us_hashgrid_dydx_rays(16, P_(dya), P_(dyb), P_(dda), P_(ddb), R, S, P_(z), bh, P_(go3), P_(gd3), P_(d3), L.stream()), "us_hashgrid_dydx_rays")
-    assert torch.equal(d3, d_ref) and torch.equal(go3, go) and torch.equal(gd3, gd)
+    # the stored halves carry 2^-11 per value: the 96 products of a point's gradient agree with the re-gathering path to ~1e-3 of its size
+    assert float((d3 - d_ref).norm() / d_ref.norm()) < 5e-4
+    for a, b in ((go3, go), (gd3, gd)):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()))
 
 
 def _g14_scene(us, g):
@@ -418,7 +421,7 @@ def test_decoder_backward_contracts_dydx_in_registers(S, n_rays):
     A, B = ctypes.byref(ds_), ctypes.byref(dc_)
     ps = (torch.randn(us.network.mlp_n_params(ds_), generator=g) * 0.3).to(DEV); pc = (torch.randn(us.network.mlp_n_params(dc_), generator=g) * 0.3).to(DEV)
     fa, fb = torch.randn(16, N, 2, generator=g).to(DEV), torch.randn(16, N, 2, generator=g).to(DEV)
-    dda, ddb = torch.randn(16, 3, N, 2, generator=g).to(DEV), torch.randn(16, 3, N, 2, generator=g).to(DEV)
+    dda, ddb = torch.randn(16, 3, N, 2, generator=g).half().to(DEV), torch.randn(16, 3, N, 2, generator=g).half().to(DEV)
     d_raw = torch.randn(N, 4, generator=g).to(DEV); z = (torch.rand(n_rays, S, generator=g) * 3).to(DEV)
     raw = torch.empty(N, 4, device=DEV)
     off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
@@ -490,8 +493,8 @@ def test_mapwindow_with_pixels_without_depth():
         outs.append((float(loss), step.stats.clone(), step.z[:R].clone(), g_o, g_d))
     a, c = outs
     assert np.isfinite(a[0]) and a[0] == c[0] and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
-    for k in (3, 4):
-        assert torch.allclose(a[k], c[k], rtol=1e-4, atol=1e-5 * float(c[k].abs().max()))
+    for k in (3, 4):                                               # (the window contracts stored half-precision dy/dx, the step re-gathers in fp32)
+        assert torch.allclose(a[k], c[k], rtol=2e-3, atol=2e-4 * float(c[k].abs().max()))
 
 
 def test_a_captured_iteration_does_not_keep_its_owner_in_a_cycle():

@@ -154,7 +154,7 @@ template <bool GATHER, bool COUNT, bool DYDX = false>
 __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
                                                         int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
-                                                        float* __restrict__ dydxA = nullptr, float* __restrict__ dydxB = nullptr) {
+                                                        us_half_t* __restrict__ dydxA = nullptr, us_half_t* __restrict__ dydxB = nullptr) {
     constexpr int HALVES = J_FWD_THREADS / J_ROW_POINTS;
     __shared__ uint32_t lcnt[HALVES][J_LVL_BINS];
     __shared__ uint32_t done;
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
             float* o = (s ? outB : outA) + feat_index(lm, i, n, level, C, 2);
             o[0] = r0; o[1] = r1;
             if (DYDX) {                                          // k_fwd<F, DYDX>'s arithmetic, value for value
-                float* dd_base = (s ? dydxB : dydxA) + (int64_t)level * 3 * n * 2 + i * 2;      // planes [L][3][N][2]: a store instruction covers whole lines
+                // planes [L][3][N][2] of IEEE half values: a store instruction covers whole lines.  (dy/dx = scale * feature differences: |.| < 65504
+                // for any table this path trains, relative error 2^-11 -- against 5e-4 relative per element the pose gradient sums ~10^6 of them)
+                _Float16* dd_base = reinterpret_cast<_Float16*>(s ? dydxB : dydxA) + (int64_t)level * 3 * n * 2 + i * 2;
 #pragma unroll
                 for (int gd = 0; gd < 3; ++gd) {
                     float a0 = 0.0f, a1 = 0.0f;
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
                     }
                     const float xin = x[i * 3 + gd];
                     const bool pass = !clamp || (xin >= 0.0f && xin <= 1.0f);
-                    typedef float f2_t __attribute__((ext_vector_type(2)));
-                    f2_t o2; o2.x = pass ? a0 : 0.0f; o2.y = pass ? a1 : 0.0f;
+                    typedef _Float16 f2_t __attribute__((ext_vector_type(2)));
+                    f2_t o2; o2.x = (_Float16)(pass ? a0 : 0.0f); o2.y = (_Float16)(pass ? a1 : 0.0f);
                     f2_t* dst = reinterpret_cast<f2_t*>(dd_base + (int64_t)gd * n * 2);
 #if J_DYDX_NT
                     __builtin_nontemporal_store(o2, dst);
@@ -865,7 +867,7 @@ static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n)
                "per-level scale, <= %d bins) or the batch is too large", J_MAX_LEVELS, J_MAX_BINS)
 
 static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB, const float* x,
-                     int64_t n, float* outA, float* outB, float* dydxA, float* dydxB, int flags, void* workspace, size_t workspace_bytes,
+                     int64_t n, float* outA, float* outB, us_half_t* dydxA, us_half_t* dydxB, int flags, void* workspace, size_t workspace_bytes,
                      void* stream) {
     if (n < 0) return US_ERR_SHAPE;
     US_REQUIRE(a && b, US_ERR_NULL, "%s: desc is NULL", fn);
@@ -879,7 +881,7 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
     US_REQUIRE(paramsA && paramsB && x && outA && outB, US_ERR_NULL, "%s: NULL pointer", fn);
     US_REQUIRE(((uintptr_t)paramsA & 15u) == 0 && ((uintptr_t)paramsB & 15u) == 0, US_ERR_SHAPE, "%s: params must be 16-byte aligned", fn);
     US_REQUIRE((dydxA != nullptr) == (dydxB != nullptr), US_ERR_NULL, "%s: dy_dx of both grids or of neither", fn);
-    US_REQUIRE(!dydxA || ((((uintptr_t)dydxA | (uintptr_t)dydxB) & 7u) == 0), US_ERR_SHAPE, "%s: dy_dx must be 8-byte aligned", fn);
+    US_REQUIRE(!dydxA || ((((uintptr_t)dydxA | (uintptr_t)dydxB) & 3u) == 0), US_ERR_SHAPE, "%s: dy_dx must be 4-byte aligned", fn);
     const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
     dim3 grid((unsigned)us_cdiv(n, J_FWD_THREADS), a->n_levels), block(J_FWD_THREADS);
     hipStream_t s = (hipStream_t)stream;
@@ -909,7 +911,7 @@ extern "C" int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* 
 }
 
 extern "C" int us_hashgrid_fwd_joint_dydx(const us_grid_desc* a, const us_grid_desc* b, const float* paramsA, const float* paramsB,
-                                          const float* x, int64_t n, float* outA, float* outB, float* dy_dxA, float* dy_dxB, int flags,
+                                          const float* x, int64_t n, float* outA, float* outB, us_half_t* dy_dxA, us_half_t* dy_dxB, int flags,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     US_REQUIRE(n <= 0 || (dy_dxA && dy_dxB), US_ERR_NULL, "us_hashgrid_fwd_joint_dydx: NULL pointer");
     return fwd_joint("us_hashgrid_fwd_joint_dydx", a, b, paramsA, paramsB, x, n, outA, outB, dy_dxA, dy_dxB, flags, workspace, workspace_bytes, stream);
@@ -917,12 +919,11 @@ extern "C" int us_hashgrid_fwd_joint_dydx(const us_grid_desc* a, const us_grid_d
 
 // The input gradient from the stored dy_dx, reduced to the rays: a workgroup = one ray, lanes = 16 samples x 4 level rows, each lane
 // its levels {row, row+4, ...} of grid A, then of grid B -- the summation order of k_bwd_input_rays (hashgrid.hip), so the two paths
-// agree bit for bit -- then the adjoint of us_ray_points.  Pure streaming: 32 B per (point, level, grid), every row of 16 lanes reads
-// 128 + 384 contiguous bytes.
+// agree to the rounding of the stored half values -- then the adjoint of us_ray_points.  Pure streaming: 20 B per (point, level, grid).
 #define JR_MAX_WAVES 8
 struct JRaySpan { float span[3]; };
 __global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_levels, const float* __restrict__ dyA, const float* __restrict__ dyB,
-                                                                 const float* __restrict__ dydxA, const float* __restrict__ dydxB, int64_t n, int S,
+                                                                 const us_half_t* __restrict__ dydxA, const us_half_t* __restrict__ dydxB, int64_t n, int S,
                                                                  const float* __restrict__ z_vals, JRaySpan bd, float* __restrict__ g_o,
                                                                  float* __restrict__ g_d, float* __restrict__ dL_dx) {
     __shared__ float sh[JR_MAX_WAVES][6];
@@ -935,14 +936,17 @@ __global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_leve
     if (in) {
 #pragma unroll
         for (int gsel = 0; gsel < 2; ++gsel) {
-            const float* dy = gsel ? dyB : dyA; const float* dd = gsel ? dydxB : dydxA;
+            const float* dy = gsel ? dyB : dyA; const _Float16* dd = reinterpret_cast<const _Float16*>(gsel ? dydxB : dydxA);
             float* r = gsel ? rB : rA;
             for (uint32_t level = (uint32_t)row; level < n_levels; level += 4) {
                 const int64_t e = (int64_t)level * n + i;
                 typedef float f2_t __attribute__((ext_vector_type(2)));
                 const f2_t y = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(dy + e * 2));
-                const f2_t* d = reinterpret_cast<const f2_t*>(dd + (int64_t)level * 3 * n * 2 + i * 2);
-                const f2_t d0 = __builtin_nontemporal_load(d), d1 = __builtin_nontemporal_load(d + n), d2 = __builtin_nontemporal_load(d + 2 * n);
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                const h2_t* d = reinterpret_cast<const h2_t*>(dd + (int64_t)level * 3 * n * 2 + i * 2);
+                const h2_t e0 = __builtin_nontemporal_load(d), e1 = __builtin_nontemporal_load(d + n), e2 = __builtin_nontemporal_load(d + 2 * n);
+                f2_t d0, d1, d2;
+                d0.x = (float)e0.x; d0.y = (float)e0.y; d1.x = (float)e1.x; d1.y = (float)e1.y; d2.x = (float)e2.x; d2.y = (float)e2.y;
                 float t[3];
                 t[0] = y.x * d0.x; t[1] = y.x * d1.x; t[2] = y.x * d2.x;      // input_grad_level: r[gd] += dy[0] * d[0][gd], then dy[1] * d[1][gd]
                 r[0] += t[0]; r[1] += t[1]; r[2] += t[2];
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(64 * JR_MAX_WAVES) void k_dydx_rays(uint32_t n_leve
     }
 }
 
-extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, const float* dL_dyB, const float* dy_dxA, const float* dy_dxB,
+extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, const float* dL_dyB, const us_half_t* dy_dxA, const us_half_t* dy_dxB,
                                      int64_t n_rays, int n_samples, const float* z_vals, const float* bound_host, float* dL_do, float* dL_dd,
                                      float* dL_dx, void* stream) {
     US_REQUIRE(n_levels >= 1 && n_levels <= US_MAX_LEVELS, US_ERR_CONFIG, "us_hashgrid_dydx_rays: n_levels %u", n_levels);

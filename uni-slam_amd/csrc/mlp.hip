@@ -740,7 +740,7 @@ static int mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const floa
                         const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
                         const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
                         float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
-                        void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dpts_a, float* dpts_b,
+                        void* workspace_b, size_t workspace_bytes, const us_half_t* dy_dx_a, const us_half_t* dy_dx_b, float* dpts_a, float* dpts_b,
                         void* stream) {
     US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_mlp_bwd_pair: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
     US_REQUIRE(out_stride_a >= (int64_t)da->n_out && dout_stride_a >= (int64_t)da->n_out && out_stride_b >= (int64_t)db->n_out &&
@@ -762,7 +762,7 @@ static int mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const floa
     if (dy_dx_a || dy_dx_b || dpts_a || dpts_b) {
         US_REQUIRE(dy_dx_a && dy_dx_b && dpts_a && dpts_b && dpts_a != dpts_b, US_ERR_NULL, "us_mlp_bwd_pair_dydx: dy_dx and dL_dpts of both decoders");
         US_REQUIRE(lm && da->n_in == 32, US_ERR_CONFIG, "us_mlp_bwd_pair_dydx: level-major inputs of 16 levels x 2 features");
-        US_REQUIRE(((((uintptr_t)dy_dx_a) | ((uintptr_t)dy_dx_b)) & 7u) == 0, US_ERR_SHAPE, "us_mlp_bwd_pair_dydx: dy_dx must be 8-byte aligned");
+        US_REQUIRE(((((uintptr_t)dy_dx_a) | ((uintptr_t)dy_dx_b)) & 3u) == 0, US_ERR_SHAPE, "us_mlp_bwd_pair_dydx: dy_dx must be 4-byte aligned");
     }
     hipStream_t s = (hipStream_t)stream;
     const int waves = MLP_BF_BWD_WAVES(da->width);
@@ -804,7 +804,7 @@ extern "C" int us_mlp_bwd_pair_dydx(const us_mlp_desc* da, const us_mlp_desc* db
                                     const float* in_b, const float* out_a, int64_t out_stride_a, const float* out_b, int64_t out_stride_b,
                                     const float* dL_dout_a, int64_t dout_stride_a, const float* dL_dout_b, int64_t dout_stride_b, int64_t n,
                                     float* dL_din_a, float* dL_din_b, float* grad_params_a, float* grad_params_b, int flags, void* workspace_a,
-                                    void* workspace_b, size_t workspace_bytes, const float* dy_dx_a, const float* dy_dx_b, float* dL_dpts_a,
+                                    void* workspace_b, size_t workspace_bytes, const us_half_t* dy_dx_a, const us_half_t* dy_dx_b, float* dL_dpts_a,
                                     float* dL_dpts_b, void* stream) {
     US_REQUIRE(n <= 0 || (dy_dx_a && dy_dx_b && dL_dpts_a && dL_dpts_b), US_ERR_NULL, "us_mlp_bwd_pair_dydx: NULL pointer");
     return mlp_bwd_pair(da, db, params_a, params_b, in_a, in_b, out_a, out_stride_a, out_b, out_stride_b, dL_dout_a, dout_stride_a, dL_dout_b,

@@ -389,7 +389,7 @@ class MapStep:
             if self.store_dydx:
                 L_ = self.es.desc.n_levels
                 if self.dydx_s is None or self.dydx_s.numel() < L_ * self.max_rays * S * 6:
-                    self.dydx_s = torch.empty(L_ * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+                    self.dydx_s = torch.empty(L_ * self.max_rays * S * 6, dtype=torch.float16, device=self.device)
                     self.dydx_c = torch.empty_like(self.dydx_s)
                 self._dydx_valid = True
                 self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint_dydx(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,

@@ -113,7 +113,7 @@ class TrackStep:
         if self._joint:
             # ... and d(features)/d(position) of both, which the pose gradient contracts at the end (no second gather pass over the tables)
             if self.dydx_s is None:
-                self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+                self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float16, device=self.device)
                 self.dydx_c = torch.empty_like(self.dydx_s)
             L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c),
                                                    3, None, 0, st), "us_hashgrid_fwd_joint_dydx")
@@ -284,7 +284,7 @@ class TrackStep:
             P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation), tr, seed,
             P(self.draw_ctr), 1 if self.perturb else 0, None, None, P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st))
         if self.dydx_s is None:
-            self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float32, device=self.device)
+            self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float16, device=self.device)
             self.dydx_c = torch.empty_like(self.dydx_s)
         T("us_hashgrid_fwd_joint_dydx", lambda: lib.us_hashgrid_fwd_joint_dydx(
             ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3, None, 0, st))
