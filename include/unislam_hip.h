@@ -466,6 +466,11 @@ int us_adam_step_segments(float* p, float* g, float* m, float* v, int n_seg, con
 int us_adam_step_segments_dev(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
                               const double* seg_lr, double beta1, double beta2, double eps, float* step_dev,
                               unsigned zero_grad_mask, void* stream);
+/* us_adam_step_segments_dev where the segments flagged in bf16_mask (bit k = segment k) read their gradient from g_bf16 -- a bfloat16
+ * image of the gradient buffer, same indexing: the payload of the data-parallel all-reduce as it came off the wire (no widening pass) */
+int us_adam_step_segments_bf16(float* p, float* g, const uint16_t* g_bf16, unsigned bf16_mask, float* m, float* v, int n_seg,
+                               const int64_t* seg_off, const int64_t* seg_n, const double* seg_lr, double beta1, double beta2,
+                               double eps, float* step_dev, unsigned zero_grad_mask, void* stream);
 
 /* the same with the 1-based step count in device memory (float[1]): nothing step-dependent is baked into the launch, so the
  * call can sit inside a captured hipGraph (torch.optim.Adam(capturable=True) arithmetic: bias corrections in fp32) */

@@ -45,7 +45,7 @@ for jo in (False, True):
     for name, kw in (("local_fast", dict(group=True)), ("colour_first", dict(group=True, dp_mode="colour_first"))):
         win = us.MapWindow(build(**kw), c2ws, pd, pc, pr, 256, joint_opt=jo, has_zero_depth=False)
         out[f"{tag} {name} eager"] = timed(win.iterate)
-        win.capture()
+        win.capture(collectives="between")
         out[f"{tag} {name} segments ({len(win._graph.segments)})"] = timed(win.replay)
         try:
             win.capture(collectives="inside")

@@ -118,6 +118,8 @@ SIGNATURES = {
                                       ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_int, ctypes.c_uint, c_f]),
     "us_adam_step_segments_dev": (c_int, [c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                           ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_f, ctypes.c_uint, c_f]),
+    "us_adam_step_segments_bf16": (c_int, [c_f, c_f, c_f, ctypes.c_uint, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
+                                           ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_f, ctypes.c_uint, c_f]),
     "us_importance_z": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f]),
     "us_zero_depth_rows": (c_int, [c_f, c_i64, c_f, c_f, c_f]),
     "us_uniform_points": (c_int, [c_f, c_f, c_f, c_i64, _HF, c_f, c_int, c_f, ctypes.c_uint64, c_int, c_f, c_f, c_f]),

@@ -965,9 +965,14 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, AdamSegs sg, float one_minus_b1, float b2,
                                                    float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask,
-                                                   const float* __restrict__ step_dev) {
+                                                   const float* __restrict__ step_dev, const uint16_t* __restrict__ g16 = nullptr,
+                                                   unsigned g16_mask = 0u) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    typedef uint16_t h_t __attribute__((ext_vector_type(VEC)));
     const int64_t n = sg.n[blockIdx.y] / VEC, o = sg.off[blockIdx.y];
+    // g16 (us_adam_step_segments_bf16): a bfloat16 image of the gradient buffer (same indexing); the segments flagged in g16_mask read
+    // their gradient THERE -- the payload of a data-parallel all-reduce as it came off the wire, no widening pass in between
+    const bool narrow = g16 != nullptr && ((g16_mask >> blockIdx.y) & 1u);
     const bool zero = (zero_mask >> blockIdx.y) & 1u;            // optimizer.zero_grad() of this segment, folded in
     float step_size = sg.step_size[blockIdx.y];
     if (step_dev) {
@@ -978,7 +983,14 @@ __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float*
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = o + k * VEC;
         // g, m, v are streamed once per step: non-temporal, so that the tables (p), which the next forward gathers from, stay cached
-        const vec_t gv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(g + i));
+        vec_t gv;
+        if (narrow) {
+            const h_t hv = __builtin_nontemporal_load(reinterpret_cast<const h_t*>(g16 + i));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gv[e] = __uint_as_float((uint32_t)hv[e] << 16);
+        } else {
+            gv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(g + i));
+        }
         const vec_t mv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(m + i));
         const vec_t vv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v + i));
         vec_t pv = *reinterpret_cast<const vec_t*>(p + i), mo, vo;
@@ -1697,7 +1709,7 @@ extern "C" int us_adam_step(float* p, const float* g, float* m, float* v, int64_
 #endif
 static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
                          const double* seg_lr, double beta1, double beta2, double eps, int step, float* step_dev,
-                         unsigned zero_grad_mask, void* stream) {
+                         unsigned zero_grad_mask, void* stream, const uint16_t* g16 = nullptr, unsigned g16_mask = 0u) {
     US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr, US_ERR_NULL, "us_adam_step_segments: NULL pointer");
     US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_segments: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
     US_REQUIRE(step_dev || step >= 1, US_ERR_SHAPE, "us_adam_step_segments: step %d (1-based)", step);
@@ -1720,11 +1732,11 @@ static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, cons
     if (vec4)
         hipLaunchKernelGGL(k_adam_segs<4>, dim3(grid_1d(n_max / 4, 256, ADAM_VEC_BLOCKS), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
-                           (const float*)step_dev);
+                           (const float*)step_dev, g16, g16_mask);
     else
         hipLaunchKernelGGL(k_adam_segs<1>, dim3(grid_1d(n_max, 256, 4096), n_seg), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg,
                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
-                           (const float*)step_dev);
+                           (const float*)step_dev, g16, g16_mask);
     US_CHECK_LAUNCH("us_adam_step_segments");
     return US_OK;
 }
@@ -1740,6 +1752,17 @@ extern "C" int us_adam_step_segments_dev(float* p, float* g, float* m, float* v,
                                          float* step_dev, unsigned zero_grad_mask, void* stream) {
     US_REQUIRE(step_dev && ((uintptr_t)step_dev & 7u) == 0, US_ERR_NULL, "us_adam_step_segments_dev: step_dev is NULL or not 8-byte aligned");
     return adam_segments(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, 0, step_dev, zero_grad_mask, stream);
+}
+
+// us_adam_step_segments_dev where the segments flagged in bf16_mask (bit k = segment k) read their gradient from g_bf16, a bfloat16 image
+// of the gradient buffer with the same indexing (the payload of the data-parallel all-reduce, dist.GradComm) instead of from g
+extern "C" int us_adam_step_segments_bf16(float* p, float* g, const uint16_t* g_bf16, unsigned bf16_mask, float* m, float* v, int n_seg,
+                                          const int64_t* seg_off, const int64_t* seg_n, const double* seg_lr, double beta1, double beta2,
+                                          double eps, float* step_dev, unsigned zero_grad_mask, void* stream) {
+    US_REQUIRE(step_dev && ((uintptr_t)step_dev & 7u) == 0, US_ERR_NULL, "us_adam_step_segments_bf16: step_dev is NULL or not 8-byte aligned");
+    US_REQUIRE(g_bf16 || bf16_mask == 0u, US_ERR_NULL, "us_adam_step_segments_bf16: g_bf16 is NULL");
+    US_REQUIRE(((uintptr_t)g_bf16 & 7u) == 0, US_ERR_SHAPE, "us_adam_step_segments_bf16: g_bf16 must be 8-byte aligned");
+    return adam_segments(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, 0, step_dev, zero_grad_mask, stream, g_bf16, bf16_mask);
 }
 
 extern "C" int us_adam_step_inc(float* step_dev, double beta1, double beta2, void* stream) {

@@ -57,6 +57,11 @@ class GradComm:
         self.nccl = dist.get_backend(self.pg) == "nccl"
         self.segments = []                                  # (lo, n) of the announced segments, in announcement order
         self.works = []
+        # direct: the engine's optimiser reads narrow segments from the bfloat16 image itself (engine._grad_bf16_from: the first index that
+        # lives there), so finish() does not widen them back.  Decided when a segment is ANNOUNCED, i.e. also while a step is being captured.
+        self.direct = self.narrow and hasattr(engine, "_grad_bf16_from")
+        if hasattr(engine, "_grad_bf16_from"):
+            engine._grad_bf16_from = None
 
     # -- operations (each one is also a valid `op` of SegmentedGraph.cut)
     def stats(self):
@@ -87,6 +92,8 @@ class GradComm:
             if img is None or img.shape != e.grad.shape or img.device != e.grad.device:
                 img = e._grad_bf16 = torch.empty_like(e.grad, dtype=torch.bfloat16)
             buf = img[lo:lo + n]
+            if self.direct:
+                e._grad_bf16_from = lo if e._grad_bf16_from is None else min(e._grad_bf16_from, lo)
 
         def op():
             if buf is not view:
@@ -95,9 +102,10 @@ class GradComm:
         return op
 
     def finish(self):
+        # (an engine whose optimiser reads the bfloat16 image itself -- self.direct, MapStep: us_adam_step_segments_bf16 -- needs no widening)
         for w, view, buf in self.works:
             w.wait()
-            if buf is not view:
+            if buf is not view and not self.direct:
                 view.copy_(buf)
         self.works = []
 

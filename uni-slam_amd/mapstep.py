@@ -69,6 +69,7 @@ class MapStep:
         self._dec_grad_clean = False
         self._step_advanced = False
         self._scan_pending = self._side_pending = False          # work queued on the scan / side stream since its last join
+        self._grad_bf16_from = None                              # dist.GradComm (bf16 payload): first flat index whose gradient lives in self._grad_bf16
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
         # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
         # window.MapWindow for the iterations that optimise camera poses (src/Mapper.py:372-376); costs 2 x 24 B per point and level.
@@ -731,6 +732,13 @@ class MapStep:
             self._step_advanced = False
         I64, DBL = ctypes.c_int64 * k, ctypes.c_double * k
         # the step count lives on the device (advanced by the launch itself): nothing in the arguments changes between iterations
+        narrow = getattr(self, "_grad_bf16_from", None)          # dist.GradComm: segments from this index on arrived as bfloat16 (engine._grad_bf16)
+        if narrow is not None and ranges is None:
+            mask = sum(1 << i for i, g in enumerate(segs) if g[0] >= narrow)
+            L.check(lib.us_adam_step_segments_bf16(P(self.flat), P(self.grad), P(self._grad_bf16), mask, P(self.m), P(self.v), k,
+                                                   I64(*[g[0] for g in segs]), I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999,
+                                                   1e-8, P(self.step_dev), zero_mask, st), "us_adam_step_segments_bf16")
+            return
         L.check(lib.us_adam_step_segments_dev(P(self.flat), P(self.grad), P(self.m), P(self.v), k, I64(*[g[0] for g in segs]),
                                               I64(*[g[1] for g in segs]), DBL(*[g[2] for g in segs]), 0.9, 0.999, 1e-8, P(self.step_dev),
                                               zero_mask, st), "us_adam_step_segments_dev")
