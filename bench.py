@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--hidden", type=int, default=32, help="MLP width (32 = BASELINE '2x32'; 16 = reference decoders.py default)")
     ap.add_argument("--bwd-mode", type=int, default=-1)
-    ap.add_argument("--mlp-precision", default="bf16", choices=["fp32", "bf16", "bf16_plain"],
+    ap.add_argument("--mlp-precision", default="bf16", choices=["fp32", "bf16", "bf16_plain", "f16"],
                     help="MFMA operand type of the decoders.  bf16 (headline): v_mfma_f32_16x16x32_bf16 with split operands (hi + lo) in the "
                          "forward products -- rendered depth / colour within 4e-5 of the fp32 decoders on identical parameters "
                          "(tools/bf16_deviation.py; bound 1e-3), bf16 operands in the gradient products; fp32: f32-input MFMA throughout")
