@@ -101,13 +101,18 @@ class GradComm:
             self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), view, buf))
         return op
 
-    def finish(self):
-        # (an engine whose optimiser reads the bfloat16 image itself -- self.direct, MapStep: us_adam_step_segments_bf16 -- needs no widening)
-        for w, view, buf in self.works:
+    def finish(self, first=None):
+        """wait for the announced segments (stream-level over RCCL); first = k: only the first k of them (announcement order), the
+        others stay in flight.  (An engine whose optimiser reads the bfloat16 image itself -- self.direct -- needs no widening.)"""
+        n = len(self.works) if first is None else min(int(first), len(self.works))
+        for w, view, buf in self.works[:n]:
             w.wait()
-            if buf is not view and not self.direct:
+            if buf is not None and buf is not view and not self.direct:
                 view.copy_(buf)
-        self.works = []
+        self.works = self.works[n:]
+
+    def finish_first(self):
+        self.finish(first=1)
 
     def ranges(self):
         return [(lo + self.r * (n // self.W), lo + (self.r + 1) * (n // self.W)) for lo, n in self.segments]
@@ -162,11 +167,19 @@ def dp_iterate(engine, batch, group=None, grad_comm=None, ray_grads=False, befor
         run(comm.announce(engine.grad))
     if before_adam is not None:
         before_adam()
-    run(comm.finish)
     if comm.sharded:
+        run(comm.finish)
         engine.adam_step(ranges=comm.ranges())
         run(comm.gather)
+    elif getattr(engine, "adam_in_parts", False) and len(comm.segments) == 2 and comm.segments[0][0] == getattr(engine, "o_tab_c", -1):
+        # the colour table's segment was announced first and is the large one: its optimiser pass (47 of 54 us) starts as soon as it has
+        # arrived and covers the reduction of the small remaining segment, which only the last 7 us of the optimiser need
+        run(comm.finish_first)
+        engine.adam_step(part="colour")
+        run(comm.finish)
+        engine.adam_step(part="rest")
     else:
+        run(comm.finish)
         engine.adam_step()
     return loss
 

@@ -69,6 +69,7 @@ class MapStep:
         self._dec_grad_clean = False
         self._step_advanced = False
         self._scan_pending = self._side_pending = False          # work queued on the scan / side stream since its last join
+        self.adam_in_parts = True                                # data-parallel: the colour table's optimiser pass ahead of the rest (dist.dp_iterate)
         self._grad_bf16_from = None                              # dist.GradComm (bf16 payload): first flat index whose gradient lives in self._grad_bf16
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
         # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
@@ -685,13 +686,16 @@ class MapStep:
         R = self.n_rays
         return self.g_o[:R], self.g_d[:R]
 
-    def adam_step(self, ranges=None):
+    def adam_step(self, ranges=None, part=None):
         """
         torch.optim.Adam over the three param groups (Mapper.py:118-126) in one launch.  ranges: None (everything) or a list of
         (lo, hi) index ranges of the flat buffer -- the shards this rank owns when the optimiser state is sharded over ranks.
+        part: None | "colour" | "rest" -- ONE optimiser step as two launches (the data-parallel step: the colour table's pass, 47 of the
+        54 us, runs as soon as ITS gradient segment has arrived and covers the reduction of the small remaining segment; "colour" first).
         """
         lib, st, P = L.lib(), L.stream(), L.ptr
-        self.opt_step += 1
+        if part != "rest":
+            self.opt_step += 1
         f = self.lr_factor
         groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
                   (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
@@ -713,6 +717,11 @@ class MapStep:
                 P(self.step_dev), st), "us_mlp_reduce_pair_adam")
             segs, zero_mask = list(groups)[1:], 0
             self._dec_grad_clean = False
+        elif ranges is None and part == "colour":
+            segs, zero_mask = [groups[2]], 0
+        elif ranges is None and part == "rest":
+            segs, zero_mask = list(groups[:2]), 0b001 | L.US_ADAM_STEP_ADVANCED      # (the colour part advanced the step count)
+            self._dec_grad_clean = True
         elif ranges is None:
             segs, zero_mask = list(groups), 0b001                # the decoder gradients (which the MLP backward adds to) are
             self._dec_grad_clean = True                          # cleared on the way
