@@ -73,7 +73,7 @@ def test_slam_with_replayed_mapping_windows():
     import unislam_amd as us
     n = 16
     slam, frames = _build(us, n, mlp_precision="bf16")
-    assert slam.cfg["mapping"]["graph_replay"] is True
+    assert slam.cfg["mapping"].get("graph_replay", True) is True          # (an extension key: on unless a config turns it off)
     slam.run()
     assert slam.mapper.joint_opt and slam.ate_rmse() < 0.02, slam.ate_rmse()
     kinds = sorted(slam.mapper._wins)

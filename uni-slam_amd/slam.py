@@ -22,7 +22,7 @@ DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
                      activated_mapping_mode=True, uncertainty_ts=0.001,
                      w=dict(fs=10, center=200, tail=50, depth=1, color=5)),
     "mapping": dict(every_frame=4, keyframe_every=4, joint_opt=True, joint_opt_cam_lr=0.001, mapping_window_size=20,
-                    lr_first_factor=5, lr_factor=1, pixels=4000, iters_first=10, iters=15, LC=True, LC_ts=0.95, graph_replay=True,
+                    lr_first_factor=5, lr_factor=1, pixels=4000, iters_first=10, iters=15, LC=True, LC_ts=0.95,
                     lr=dict(decoders=0.001, sdf_grid=0.05, color_grid=0.05), w=dict(fs=5, center=200, tail=10, depth=0.1, color=5)),
     "rendering": dict(n_stratified=32, n_importance=8, perturb=True), "truncation": 0.06,
     "m_mask_mode": "original", "t_mask_mode": "original",
