@@ -786,22 +786,31 @@ class MapStep:
         keep = (self.flat.clone(), self.m.clone(), self.v.clone(), self.step_dev.clone(), self.opt_step, dict(self.lr), self.rng_calls)
         self.lr = {k: 0.0 for k in self.lr}
         fn = lambda: self.iterate(ins[0], ins[1], ins[2], ins[3], t_rand=tr, has_zero_depth=False)
-        try:
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    fn()
-            torch.cuda.current_stream().wait_stream(s)
-        finally:
+
+        def restore():                  # everything the warm-up iterations and the traced call touched -- also when one of them raises
             self.lr = keep[5]
-        self.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2]); self.step_dev.copy_(keep[3])
-        self.opt_step, self.rng_calls = keep[4], keep[6]
-        self._dec_grad_clean = False    # the captured backward clears the decoder gradient itself: a replay is then valid after any call
-        self._graph = CapturedIteration(fn, warmup=0)
-        # the capture pass itself does not execute: state is as before.  (opt_step was advanced by the traced call: undo.)
-        self.opt_step = keep[4]
-        self.probe = was
+            self.flat.copy_(keep[0]); self.m.copy_(keep[1]); self.v.copy_(keep[2]); self.step_dev.copy_(keep[3])
+            self.opt_step, self.rng_calls = keep[4], keep[6]
+            self._dec_grad_clean = False    # the captured backward clears the decoder gradient itself: a replay is then valid after any call
+            self._step_advanced, self._folded = False, False
+
+        graph, s = None, None
+        try:
+            try:
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        fn()
+            finally:
+                if s is not None:
+                    torch.cuda.current_stream().wait_stream(s)
+                restore()               # the real learning rates are what the capture records
+            graph = CapturedIteration(fn, warmup=0)
+        finally:
+            restore()                   # (the capture pass does not execute; its host-side counters are undone)
+            self.probe = was
+        self._graph = graph
         return tuple(ins) + ((tr,) if t_rand else ())
 
     def replay(self):
