@@ -69,7 +69,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-decoder-pair", action="store_true", help="the two decoders as two launches each way instead of one (MapStep.decoder_pair)")
     ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
                     help="both grids in one encoder launch and one binned table-gradient pass (csrc/hashgrid_joint.hip); auto = MapStep's default")
-    ap.add_argument("--no-graph", action="store_true", help="N = 1: launch every iteration eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch every iteration eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--dp-graph", default="inside", choices=["inside", "between"],
+                    help="N > 1: the step as ONE hipGraph with the RCCL calls captured inside it (default), or hipGraph segments with the "
+                         "collectives eager between them (graph.SegmentedGraph)")
     ap.add_argument("--fixed-batch", action="store_true", help="re-render one fixed batch every step (round 1's bench) instead of a fresh draw")
     ap.add_argument("--probe-steps", type=int, default=10, help="eager iterations with HIP events around the hot kernels, after the timed region")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed iterations before the W warm-up steps (clock ramp)")
@@ -547,7 +550,7 @@ def run_rank(args):
     # US_BENCH_REHEARSE=1: rehearse the N > 1 code path on a one-GPU box -- every rank on cuda:0, gloo as the transport (RCCL refuses
     # two ranks on one device).  The numbers of such a run mean nothing; it shows that the ranks start, step, agree and report.
     rehearse = os.environ.get("US_BENCH_REHEARSE") == "1"
-    rank, local, world = init_from_env("gloo" if rehearse else None)
+    rank, local, world = init_from_env("gloo" if rehearse else None, timeout_s=float(os.environ.get("US_BENCH_PG_TIMEOUT", "180")))
     if rehearse:
         local = 0
     if world != args.gpus:
@@ -608,7 +611,7 @@ def run_rank(args):
             graph = use_graph
             if graph:
                 try:
-                    win.capture()                                # N > 1: hipGraph segments between the collectives (graph.SegmentedGraph)
+                    win.capture(**({"collectives": args.dp_graph} if (world > 1 and not rehearse) else {}))   # N > 1: one graph, RCCL calls inside
                 except Exception as e:                           # a runtime that refuses the capture: the eager step is the same arithmetic
                     print(f"[bench rank {rank}] graph capture failed, running eagerly: {e!r}"[:400], file=sys.stderr, flush=True)
                     graph = False

@@ -184,10 +184,11 @@ def dp_iterate(engine, batch, group=None, grad_comm=None, ray_grads=False, befor
     return loss
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=None):
     """
     torchrun-style initialisation (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment),
-    one process per GPU.  Returns (rank, local_rank, world_size).
+    one process per GPU.  Returns (rank, local_rank, world_size).  timeout_s: the process group's collective timeout (a rank stuck in a
+    collective then ends with an error after that long instead of the default 10 minutes).
     """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -197,7 +198,11 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 
