@@ -1,8 +1,7 @@
 """
 GPU: the two-grid kernels (csrc/hashgrid_joint.hip: us_hashgrid_fwd_joint / us_hashgrid_bwd_joint) against the one-grid kernels
 and the CPU oracle.  Bars: features bit-identical to us_hashgrid_fwd; table gradients equal to us_hashgrid_bwd_binned up to the
-rounding of the joint path's 8-byte records (their two values carry 18 / 19 significant bits, rounded to nearest: 2e-6 relative per
-contribution, summed in double: 4e-6 of the table's largest gradient) and to the oracle at 1e-4.
+rounding of one f64 -> f32 conversion (the sums are formed in double in both; 1e-6 relative) and to the oracle at 1e-4.
 Pairs: room0 (log2T 16 / 19: dense-dense, hashed-dense and hashed-hashed levels), ScanNet / TUM (16 / 16) and the default 19 / 19.
 """
 import ctypes
@@ -98,7 +97,7 @@ def test_joint_backward_equals_the_single_grid_backward(us, l2a, l2b, res, n):
     nbytes = int(lib.us_hashgrid_joint_workspace_bytes(da, db, n))
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    tol = lambda a, b: torch.allclose(a, b, rtol=2e-5, atol=4e-6 * float(b.abs().max()))
+    tol = lambda a, b: torch.allclose(a, b, rtol=1e-6, atol=1e-7 * float(b.abs().max()))
     # uncounted, OVERWRITE on garbage
     ga, gb = torch.full_like(ga_ref, 9.0), torch.full_like(gb_ref, -4.0)
     L.check(lib.us_hashgrid_bwd_joint(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), 3 | L.US_GRID_BWD_OVERWRITE, P(ws), nbytes, st), "bwd joint")
@@ -110,8 +109,8 @@ def test_joint_backward_equals_the_single_grid_backward(us, l2a, l2b, res, n):
     base_a, base_b = torch.randn_like(ga_ref), torch.randn_like(gb_ref)
     ga, gb = base_a.clone(), base_b.clone()
     L.check(lib.us_hashgrid_bwd_joint(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), 3 | L.US_GRID_BWD_COUNTED, P(ws), nbytes, st), "bwd joint counted")
-    assert torch.allclose(ga - base_a, ga_ref, rtol=2e-5, atol=4e-6 * float(ga_ref.abs().max()) + 1e-6)
-    assert torch.allclose(gb - base_b, gb_ref, rtol=2e-5, atol=4e-6 * float(gb_ref.abs().max()) + 1e-6)
+    assert torch.allclose(ga - base_a, ga_ref, rtol=1e-5, atol=1e-6 * float(ga_ref.abs().max()) + 1e-6)
+    assert torch.allclose(gb - base_b, gb_ref, rtol=1e-5, atol=1e-6 * float(gb_ref.abs().max()) + 1e-6)
     if n <= 70001:                                                # and against the CPU oracle
         for enc, dy, gg in ((ea, dya, ga_ref), (eb, dyb, gb_ref)):
             d = O.make_grid_desc(16, 2, enc.desc.log2_hashmap_size, 16, O.per_level_scale(res))

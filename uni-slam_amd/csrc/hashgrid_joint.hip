@@ -10,7 +10,7 @@
 //                 and one stage position per record pair; the bin's record region holds its A records, then its B records.
 //   SPLIT levels  one grid dense, the other hashed (room0: levels 4-6): unrelated entries, each grid has its own bins.
 // Everything per (point, level) that does not depend on the table -- cell, keys, run masks, weights, the run scan's bookkeeping -- is
-// computed once for both grids; records are 8 bytes (two rounded values with the 11-bit bin-local entry in their low mantissa bits, below).
+// computed once for both grids; records are 10 bytes (16-bit local entry, d0, d1) in two planes per (bin, grid) region (below).
 //   k_jfwd<gather,count>  encoder for both tables (one thread per point and level, blockIdx.y = level) that also leaves the binning
 //                         counts, one row of records-per-bin per 512 points;
 //   k_jcolscan, k_jscan   column scan over the rows, exclusive scan of the bin totals;
@@ -52,19 +52,18 @@
 
 enum { J_HASHED_A = 1, J_HASHED_B = 2, J_PACKABLE = 4, J_SPLIT = 8 };
 
-// RECORDS: 8 bytes each -- two 32-bit words {d0', d1'}: the two gradient values rounded to 18 / 19 significant bits (relative 2^-19 /
-// 2^-20, unbiased; the f64 sums of the ~25 records of an entry then carry ~1e-6 relative, far inside the 1e-4 the table gradient is held
-// to) with the record's bin-local entry (< 2^11: J_ACC_DOUBLES / 2 entries per bin) in the 6 + 5 mantissa bits that freed.  Every (bin,
-// grid) region starts at a multiple of 8 records, so the accumulate pass reads a PAIR of records as ONE aligned 16-byte load, consecutive
-// lanes consecutive pairs, and the record pass writes ONE 8-byte store per record.  History of the layout (MI355X, timing builds of the
-// accumulate pass with one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us): 12-byte {entry, d0,
-// d1} records 102.5 us; 10 bytes in two planes (16-bit entries | value pairs) 88.7, with ONE copy of the entries per joint bin 85.7 and
-// the record pass 126 -> 114 (its 2-byte entry stores were the expensive part of the copy-out); r4: 8 bytes, no entry plane at all.
-// A region of c records takes j_region(c) record indices; a joint bin holds its A region, then its B region.
+// RECORDS: 10 bytes each, in TWO PLANES over one record index R -- the local entries as 16-bit numbers (< 2^11: J_ACC_DOUBLES / 2 entries
+// per bin) in E[R], the value pairs in V[R].  Every (bin, grid) region starts at a multiple of 8 records, so the accumulate pass reads a
+// PAIR of records as one aligned 4-byte load (two entries) + one aligned 16-byte load (four values), consecutive lanes consecutive pairs,
+// and the record pass derives both addresses of a record from ONE per-bin number.  The accumulate pass is bound by its record stream
+// (timing builds, MI355X, one contiguous aligned load per record: 8 / 12 / 16 bytes per record 79.9 / 103.1 / 121.3 us): 12-byte
+// {entry, d0, d1} records 102.5 us, two planes 88.7 (same box); the same 10 bytes as 5-dword units of two records -- one unaligned 16-byte
+// load + a 4-byte load over the same lines -- took 104: the shape of the loads counts, not only their bytes.
+// A region of c records takes j_region(c) record indices; a joint bin holds its A region, then its B region -- and only the B region's
+// entries are written: table A's local entry is table B's masked, so the A items of the accumulate pass read E of the B region (the
+// 2-byte stores are the expensive part of the record pass's copy-out: without the A pass's, 126 -> 114 us and 132 -> 118 on two boxes;
+// pairing the remaining ones into 4-byte stores costs more than it saves, with row shifts as well as with two positions per lane).
 __host__ __device__ __forceinline__ uint32_t j_region(uint32_t c) { return (c + 7u) & ~7u; }
-__device__ __forceinline__ uint2 j_pack(uint32_t loc, uint32_t d0_bits, uint32_t d1_bits) {
-    return make_uint2(((d0_bits + 0x20u) & ~0x3Fu) | (loc >> 5), ((d1_bits + 0x10u) & ~0x1Fu) | (loc & 31u));
-}
 static_assert(J_ACC_DOUBLES / 2 <= 65536 && J_LVL_BINS <= 65536, "local entry and bin of the level in 16 bits each");
 
 struct JLevel {
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const float* __restrict__ dyA, const float* __restrict__ dyB, int64_t n, int clamp,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
-                                                            uint32_t row_stride, uint2* __restrict__ rec_v,
+                                                            uint32_t row_stride, uint16_t* __restrict__ rec_e, uint2* __restrict__ rec_v,
                                                             uint32_t rec_cap, int64_t plane_stride) {
     __shared__ uint2 stxy[J_STAGE];                              // stage: {local entry | bin of the level << 16, d0}
     __shared__ uint32_t stz[J_STAGE];                            //        d1                                       (48 KiB together)
@@ -532,14 +531,17 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             }
         };
         // stage entry: {local entry | bin of the level << 16, d0, d1}; its position k in the stage is its cursor value (minus `sb`); at
-        // copy-out it becomes record R = gr[bin] + k + sb: one 8-byte store of the packed pair (j_pack)
+        // copy-out it becomes record R = gr[bin] + k + sb: a 2-byte store into the entry plane and an 8-byte store into the value plane
         auto stage_put = [&](uint32_t k, uint32_t loc, float d0, float d1, uint32_t bin) {
             stxy[k] = make_uint2(loc | (bin << 16), __float_as_uint(d0)); stz[k] = __float_as_uint(d1);
         };
-        auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, uint32_t emask) {
+        auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, auto with_entries) {
             auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
                 const uint32_t R = gr[a.x >> 16] + k + sb;
-                if (R < rec_cap) rec_v[R] = j_pack(a.x & emask, a.y, z);
+                if (R < rec_cap) {
+                    if (decltype(with_entries)::value) rec_e[R] = (uint16_t)a.x;
+                    rec_v[R] = make_uint2(a.y, z);
+                }
             };
             uint32_t k = tid;
             for (; k + J_ROW_POINTS < cnt; k += 2 * J_ROW_POINTS) {
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t cnt = min(ttot[par], (uint32_t)J_STAGE);
-            copy_out(cnt, gra[par], 0u, q.maskA & 0xFFFFu);      // table A's local entry is table B's (the stage holds that), masked
+            copy_out(cnt, gra[par], 0u, JBufTag<0>{});           // values only: table A reads the B region's entries, masked
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 if (k8[c] < J_STAGE) { stxy[k8[c]].y = __float_as_uint(val[c][0]); stz[k8[c]] = __float_as_uint(val[c][1]); }
             }
             lds_barrier();
-            copy_out(cnt, grb[par], 0u, 0xFFFFu);
+            copy_out(cnt, grb[par], 0u, JBufTag<1>{});
         } else {
             const uint32_t nbA = 1u << q.lgA, mA = nbA - 1u, mB = (1u << q.lgB) - 1u;
             {                                                    // table A: bins [0, nbA) of the level, stage index = cursor
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             consume_next();
             lds_barrier();
             const uint32_t na = min(atot[par], (uint32_t)J_STAGE);
-            copy_out(na, gra[par], 0u, 0xFFFFu);
+            copy_out(na, gra[par], 0u, JBufTag<1>{});
             if (has_next) setup_fin(par ^ 1, level + 1, c1, p1, o1, t1, incl1);
             products(1);
             slot_scan_apply_pairs(val, take_all, steps);
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                 }
             }
             lds_barrier();
-            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, 0xFFFFu);
+            copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, JBufTag<1>{});
         }
     }
 }
@@ -644,12 +646,13 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
-enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_EBASE, JI_EMASK, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
 
 __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
                                                             const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
                                                             const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
-                                                            const uint2* __restrict__ rec_v, float* __restrict__ gradA,
+                                                            const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
+                                                            float* __restrict__ gradA,
                                                             float* __restrict__ gradB, int overwrite, int side_sel) {
     // side_sel: -1 both grids' items; 0 / 1: the items of grid A / B only (the data-parallel step finishes the colour table first, so
     // that its all-reduce travels while the sdf table is summed)
@@ -673,18 +676,22 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
         }
         const JBin jb = j_bin_of(lv, n_levels, b);
         if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) ok = false;        // a single-grid bin has no records of the other grid
-        uint32_t hs = 1u, lg = 0u, goff = 0u;
+        uint32_t hs = 1u, lg = 0u, goff = 0u, emask = 0xFFFFu;
 #pragma unroll
         for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
             const JLevel& q = lv.l[l];
-            if (l < n_levels && jb.level == l) { hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA; }
+            if (l < n_levels && jb.level == l) {
+                hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA;
+                if (jb.kind == 0u && side == 0u) emask = q.maskA & 0xFFFFu;      // joint bin, table A: the B region's entries, masked
+            }
         }
         uint32_t cnt = 0, dwo = 0;
         if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
         const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
         const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
         const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
-                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff};
+                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff,
+                                            dwo + (jb.kind == 0u ? j_region(cnt) : 0u), emask};
         const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
         if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
 #pragma unroll
@@ -700,28 +707,32 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
     constexpr uint32_t STEP = J_ACC_THREADS * J_ACC_UNROLL * 2;  // records per batch: every thread takes J_ACC_UNROLL pairs
     constexpr int EPT = J_ACC_DOUBLES / 2 / J_ACC_THREADS;       // entries per thread in the sweep
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(16)));
+    const uint32_t* rec_e2 = reinterpret_cast<const uint32_t*>(rec_e);
     const u32x4* rec_v2 = reinterpret_cast<const u32x4*>(rec_v);
-    u32x4 wv[2][J_ACC_UNROLL];                                   // a pair of packed records: {d0', d1'} x 2
+    uint32_t we[2][J_ACC_UNROLL];                                // a pair's two local entries
+    u32x4 wv[2][J_ACC_UNROLL];                                   // ... and its four values
     // ---- the request side of the pipeline: item fk, records from fa on (fa is even: chunks of hot bins start at multiples of hdr[1])
-    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0;
-    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); } };
+    uint32_t fk = 0, fa = 0, f_c1 = 0, f_base = 0, f_ebase = 0;
+    auto f_load = [&]() { if (fk < n) { fa = field(JI_C0, fk); f_c1 = field(JI_C1, fk); f_base = field(JI_BASE, fk); f_ebase = field(JI_EBASE, fk); } };
     auto fetch = [&](auto tag) {                                 // every load unconditional (the compiler closes a conditional block with
         constexpr int buf = decltype(tag)::value;                // s_waitcnt vmcnt(0): ONE record in flight per thread): past the end of an
                                                                  // item, and past the last item of the workgroup, it re-reads the last pair
-        const size_t pair0 = (size_t)(f_base >> 1);              // (regions start at multiples of 8 records)
+        const size_t pair0 = (size_t)(f_base >> 1), epair0 = (size_t)(f_ebase >> 1);     // (regions start at multiples of 8 records)
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
             const uint32_t q = min((fa >> 1) + u * J_ACC_THREADS + tid, (f_c1 - 1u) >> 1);
-            wv[buf][u] = __builtin_nontemporal_load(rec_v2 + pair0 + q);
+            we[buf][u] = __builtin_nontemporal_load(rec_e2 + epair0 + q);                                        // two 16-bit entries
+            wv[buf][u] = __builtin_nontemporal_load(rec_v2 + pair0 + q);                                         // their four values
         }
         fa += STEP;
         if (fa >= f_c1) { ++fk; f_load(); }
     };
     // ---- the adding side: item k, records from a on
-    uint32_t k = 0, a = 0, c1 = 0, nl = 0, misc = 0, hs = 0, goff = 0, REP = 1, rstride = 0;
+    uint32_t k = 0, a = 0, c1 = 0, nl = 0, misc = 0, hs = 0, goff = 0, REP = 1, rstride = 0, emask = 0xFFFFu;
     double* my = acc;
     auto a_load = [&]() {
         a = field(JI_C0, k); c1 = field(JI_C1, k); nl = field(JI_NL, k); misc = field(JI_MISC, k); hs = field(JI_HS, k); goff = field(JI_GOFF, k);
+        emask = field(JI_EMASK, k);
         // slices of few entries (the sdf table: 256 per bin, 25 records per entry) are kept in 4 copies, which thins out same-address
         // collisions of the LDS atomics; the copies sit 2 nl + 8 doubles apart (bank spread)
         REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;
@@ -763,15 +774,14 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
 #pragma unroll
         for (int u = 0; u < J_ACC_UNROLL; ++u) {
             const uint32_t r0 = a + 2u * (u * J_ACC_THREADS + tid);
-            const u32x4 w = wv[buf][u];                          // j_pack: the local entry sits in the low 6 + 5 bits of the two words
-            const uint32_t l0 = ((w.x & 0x3Fu) << 5) | (w.y & 0x1Fu), l1 = ((w.z & 0x3Fu) << 5) | (w.w & 0x1Fu);
+            const uint32_t l0 = we[buf][u] & emask, l1 = (we[buf][u] >> 16) & emask;
             if (r0 < c1 && l0 < nl) {
-                atomicAdd(&my[l0], (double)__uint_as_float(w.x & ~0x3Fu));                        // ds_add_f64
-                atomicAdd(&my[nl + l0], (double)__uint_as_float(w.y & ~0x1Fu));
+                atomicAdd(&my[l0], (double)__uint_as_float(wv[buf][u].x));                        // ds_add_f64
+                atomicAdd(&my[nl + l0], (double)__uint_as_float(wv[buf][u].y));
             }
             if (r0 + 1u < c1 && l1 < nl) {
-                atomicAdd(&my[l1], (double)__uint_as_float(w.z & ~0x3Fu));
-                atomicAdd(&my[nl + l1], (double)__uint_as_float(w.w & ~0x1Fu));
+                atomicAdd(&my[l1], (double)__uint_as_float(wv[buf][u].z));
+                atomicAdd(&my[nl + l1], (double)__uint_as_float(wv[buf][u].w));
             }
         }
         a += STEP;
@@ -814,7 +824,7 @@ static size_t j_header_bytes(int TB, int64_t n) {
 }
 // record indices of both grids (every (bin, grid) region padded to 8) and the bytes of the two planes over them
 static uint64_t j_record_cap(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 2ull + 16ull * J_MAX_BINS; }
-static size_t j_record_bytes(uint32_t n_levels, int64_t n) { return (size_t)j_record_cap(n_levels, n) * 8u; }
+static size_t j_record_bytes(uint32_t n_levels, int64_t n) { return (size_t)j_record_cap(n_levels, n) * 10u; }    // (cap is a multiple of 8: both planes 16-byte aligned)
 
 extern "C" int us_hashgrid_joint_supported(const us_grid_desc* a, const us_grid_desc* b, int64_t n) {
     JLevels lv;
@@ -831,7 +841,7 @@ extern "C" size_t us_hashgrid_joint_workspace_bytes(const us_grid_desc* a, const
     return j_header_bytes(TB, n) + j_record_bytes(a->n_levels, n);
 }
 
-struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *counts, *prefix; uint2* rec_v; uint32_t n_rows, stride, rec_cap; };
+struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *counts, *prefix; uint16_t* rec_e; uint2* rec_v; uint32_t n_rows, stride, rec_cap; };
 static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n) {
     JWorkspace w;
     w.totals = (uint32_t*)workspace;
@@ -843,7 +853,8 @@ static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n)
     w.n_rows = (uint32_t)us_cdiv(n, J_ROW_POINTS); w.stride = j_row_stride(TB);
     w.prefix = w.counts + (size_t)w.n_rows * w.stride;
     w.rec_cap = (uint32_t)j_record_cap(n_levels, n);
-    w.rec_v = (uint2*)((char*)workspace + j_header_bytes(TB, n));
+    w.rec_e = (uint16_t*)((char*)workspace + j_header_bytes(TB, n));
+    w.rec_v = (uint2*)((char*)w.rec_e + (size_t)w.rec_cap * 2u);
     return w;
 }
 
@@ -1032,10 +1043,10 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
                "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
     if (!(flags & US_GRID_BWD_RECORDS_READY))
         hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                           w.stride, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n);
+                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n);
     const uint32_t n_acc_items = (side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB);
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec_v, gradA, gradB, overwrite, side_sel);
+                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel);
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
 }
