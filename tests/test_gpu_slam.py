@@ -82,6 +82,68 @@ def test_slam_with_replayed_mapping_windows():
     assert len(kinds) == 4 and len(slam.mapper.keyframe_list) >= 7, kinds
 
 
+def test_slam_survives_a_growing_keyframe_arena():
+    """an arena sized for 2 keyframes in a run that makes 6: KeyframeArena.grow() doubles the store (new addresses), the mapper drops
+    the graphs that hold the old ones and captures again -- the trajectory is as good as with a big enough arena"""
+    import unislam_amd as us
+    from unislam_amd.synthetic import SyntheticRoom
+    from unislam_amd.slam import SLAM
+    n = 12
+    slam, frames = _build(us, n, mlp_precision="bf16")
+    slam.cfg["mapping"]["arena_keyframes"] = 2
+    slam.mapper = type(slam.mapper)(slam)                                    # (the arena is sized when the mapper is built)
+    assert slam.mapper.arena.K == 3
+    slam.run()
+    assert slam.mapper.arena.generation >= 1 and slam.mapper.arena.K >= 6 and len(slam.mapper.keyframe_list) >= 5
+    assert slam.mapper.kf_c2w.shape[0] == slam.mapper.arena.K
+    assert slam.ate_rmse() < 0.02, slam.ate_rmse()
+
+
+def test_arena_window_with_extra_rays_and_depth_holes():
+    """ArenaWindow with the extra block of the newest frames (src/Mapper.py:385-393) and pools that hold pixels without a depth, against
+    MapWindow on the same frames, pixel indices, jitter and zero-depth draws: one joint_opt iteration, replayed from the graph"""
+    import unislam_amd as us
+    from test_gpu_window import _window, _cfg, _ecfg, BOUND, W, LR
+    P, rows_a, rows_b = 300, 300, 80
+    g = torch.Generator().manual_seed(9)
+    arena = us.KeyframeArena(8, P, DEV)
+    c2ws, depths, colors, dirs = _window(6, P, 23)
+    depths[:, ::9] = 0.0
+    for k in range(6):
+        arena.put(arena.alloc(), colors[k].to(DEV), depths[k].to(DEV), dirs[k].to(DEV))
+
+    def scene():
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        return us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=rows_a + rows_b)
+
+    step_a, step_p = scene(), scene()
+    awin = us.ArenaWindow(step_a, arena, rows_a, rows_b, joint_opt=True, cam_lr=1e-3, has_zero_depth=None)
+    awin.capture(t_rand=True, device_draw=False)
+    b, n_per, extra = 5, 60, (4, 20)
+    frames = [0, 1, 2, 4, 5]
+    sel = torch.tensor(frames)
+    pwin = us.MapWindow(step_p, c2ws[sel], depths[sel], colors[sel], dirs[sel], n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=None)
+    awin.bind([f + 1 for f in frames], c2ws[sel].to(DEV), n_per, extra)
+    R = b * n_per + extra[0] * extra[1]
+    idx, idx2 = torch.randint(P, (b, n_per), generator=g), torch.randint(P, extra, generator=g)
+    tr = torch.rand(R, 40, generator=g)
+    zd = (torch.rand(rows_a + rows_b, 32, generator=g).to(DEV), torch.rand(rows_a + rows_b, 8, generator=g).to(DEV))
+    la = pwin.iterate(idx.to(DEV), idx2.to(DEV), t_rand=tr.to(DEV), zero_depth_draws=zd)
+    # the arena window's fixed layout: rows [0, rows_a) for the frames' shares, [rows_a, rows_a + rows_b) for the extra block
+    awin.t_rand.zero_(); awin.t_rand[:b * n_per].copy_(tr[:b * n_per].to(DEV)); awin.t_rand[rows_a:rows_a + extra[0] * extra[1]].copy_(tr[b * n_per:].to(DEV))
+    # (the zero-depth draws are indexed by the compacted row: both windows meet their zero-depth rays in the same order)
+    awin.zd_draws[0].copy_(zd[0]); awin.zd_draws[1].copy_(zd[1])
+    lb = awin.replay(idx.to(DEV), idx2.to(DEV))
+    assert int(step_a.zd_count) == int(step_p.zd_count) > 5
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-5)
+    assert torch.allclose(step_a.flat, step_p.flat, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(awin.c2ws(), pwin.c2ws(), rtol=0, atol=1e-6)
+
+
 def test_arena_window_equals_a_plain_window():
     """ArenaWindow (window shape on the device, pools in a KeyframeArena, padded rows) against MapWindow on the same frames, pixel indices
     and jitter: windows of 3 and of 7 frames through ONE captured graph, 4 joint_opt iterations each -- losses, model and poses agree;
