@@ -47,7 +47,9 @@
 #ifndef J_ACC_UNROLL
 #define J_ACC_UNROLL 3                   // pairs of records per thread and batch (2 / 3 / 4: 86.6 / 85.8 / 87.9 us on one box)
 #endif
-#define J_TARGET_RECORDS 8192
+#ifndef J_TARGET_RECORDS
+#define J_TARGET_RECORDS 16384           // records per bin aimed at where capacity leaves a choice (the coarse / split levels).  Same box, both grids,
+#endif                                   // scans included (us): 8192: 233.7-238.6, 16384: 222.2-227.4, 32768: as 16384; 4096: 233.6-234.3
 #define J_WANT_MAX 8
 
 enum { J_HASHED_A = 1, J_HASHED_B = 2, J_PACKABLE = 4, J_SPLIT = 8 };
