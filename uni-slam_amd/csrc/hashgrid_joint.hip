@@ -45,7 +45,8 @@
 #define J_ACC_THREADS 512
 #endif
 #ifndef J_ACC_UNROLL
-#define J_ACC_UNROLL 3                   // pairs of records per thread and batch (2 / 3 / 4: 86.6 / 85.8 / 87.9 us on one box)
+#define J_ACC_UNROLL 2                   // pairs of records per thread and batch (r3, 8192 records per bin: 2 / 3 / 4: 86.6 / 85.8 / 87.9 us;
+                                         // r4, 16384 per bin and 2048 workgroups: 2 against 3: 219 against 222 us for the whole table gradient)
 #endif
 #ifndef J_TARGET_RECORDS
 #define J_TARGET_RECORDS 16384           // records per bin aimed at where capacity leaves a choice (the coarse / split levels).  Same box, both grids,
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 // so no clear pass and no third barrier per item.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef J_ACCP_GROUPS
-#define J_ACCP_GROUPS 1024
+#define J_ACCP_GROUPS 2048              // (four are resident per CU: the second thousand takes over as the first finishes its items)
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
