@@ -14,10 +14,11 @@ from .common import get_camera_rays
 
 class SyntheticRoom:
     def __init__(self, n_frames=40, H=120, W=160, fov_deg=80.0, device="cuda:0", room=((0.0, 6.0), (-0.6, 3.0), (-1.2, 1.0)),
-                 step_m=0.02, turn_deg=0.8, seed=0):
+                 step_m=0.02, turn_deg=0.8, seed=0, tex_freq=1.0):
         self.n_img, self.H, self.W, self.device = n_frames, H, W, torch.device(device)
         self.fx = self.fy = 0.5 * W / math.tan(math.radians(fov_deg) / 2)
         self.cx, self.cy = (W - 1) / 2.0, (H - 1) / 2.0
+        self.tex_freq = float(tex_freq)                                          # > 1: finer colour pattern (long runs along bare walls need it)
         self.room = torch.tensor(room, dtype=torch.float32, device=self.device)
         self.sphere_c = torch.tensor([3.6, 0.9, -0.5], device=self.device); self.sphere_r = 0.55
         self.block_c = torch.tensor([2.2, 2.1, -0.7], device=self.device)
@@ -36,7 +37,7 @@ class SyntheticRoom:
         return torch.minimum(inside, torch.minimum(sph, blk))
 
     def color(self, p):
-        k = torch.tensor([2.1, 1.7, 2.9], device=p.device)
+        k = torch.tensor([2.1, 1.7, 2.9], device=p.device) * self.tex_freq
         base = 0.5 + 0.5 * torch.sin(p * k + torch.tensor([0.3, 1.1, 2.0], device=p.device))
         tint = 0.5 + 0.5 * torch.sin((p[..., :1] + p[..., 1:2] * 0.7 - p[..., 2:3] * 0.4) * 1.3)
         return (0.75 * base + 0.25 * tint).clamp(0, 1)
