@@ -636,27 +636,103 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// accumulate, persistent form: J_ACCP_GROUPS workgroups (four per CU), each takes the items t = blockIdx.x + k * gridDim.x
-// (item = (bin or extra chunk of a hot bin, grid), the extra chunks -- the largest items -- first).  One workgroup per item spends most
-// of its life outside the record stream: arguments, offsets, first records, clear, two barriers, sweep -- ~12 us for ~50 KB of
-// records.  Here wave 0 decodes ALL items of the workgroup up front (one round trip, descriptors in LDS), and the record stream runs
-// as ONE software pipeline over the items: the first records of item k + 1 are requested before the last batch of item k is added and
-// are in flight across its barriers and its sweep (the barriers order LDS only).  The sweep returns the accumulators it read to zero,
-// so no clear pass and no third barrier per item.
+// accumulate, persistent form: J_ACCP_GROUPS workgroups (four per CU, all resident), each with a list of items (item = (bin or extra
+// chunk of a hot bin, grid)).  One workgroup per item spends most of its life outside the record stream: arguments, offsets, first
+// records, clear, two barriers, sweep -- ~12 us for ~50 KB of records.  Here wave 0 reads the descriptors of ALL items of the workgroup
+// up front (k_jitems' table: one round trip), and the record stream runs as ONE software pipeline over the items: the first records of
+// item k + 1 are requested before the last batch of item k is added and are in flight across its barriers and its sweep (the
+// barriers order LDS only).  The sweep returns the accumulators it read to zero, so no clear pass and no third barrier per item.
+// r4, with tools/acc_balance.py (per-workgroup and per-item clocks of a timing build, bench batch):
+//  * the kernel used to decode its items itself -- header, extra list, a walk over the levels, offsets: 22 KiB of straight-line code that
+//    one wave runs once -- and every workgroup spent its first 9-10 us on instruction fetch; with the table the list stands after 1.7 us;
+//  * with the numbering 2 x (extra slot or bin) | grid, 18 % of the indices were empty (unused extra slots, the other grid's side of
+//    single-grid bins) and the workgroups drew 2 to 4 items: the table numbers the items densely;
+//  * 2048 workgroups in two rounds paid the start-up twice: 1024, one round;
+//  * what is left: the four workgroups of a CU do not run at one rate (the wave scheduler prefers the older waves: first-placed ones end
+//    at 45 us, last-placed at 70-80 us) -- but the CU's rate is what the memory system gives it, 341 MB of records + 45 MB of
+//    gradients in ~75 us; longer lists for the early workgroups moved their ends, not the kernel's, and drawing items from a counter
+//    evened the ends out at the price of a counter and a descriptor round trip per item (or a look-ahead as long as the lists): slower;
+//  * runs of records on ONE entry (every ray of a keyframe starts at its camera: the bins that own the vertices of those cells) serialise
+//    a wave's ds_add_f64; summing such runs in registers first (segmented DPP scan) took the items of levels 2-5 from 12-28 us to
+//    8-19 us -- and left the kernel where it was: the time went to their neighbours on the CU.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef J_ACCP_GROUPS
-#define J_ACCP_GROUPS 2048              // (four are resident per CU: the second thousand takes over as the first finishes its items)
+#define J_ACCP_GROUPS 1024
 #endif
 #define J_ACCP_MAXI 32                   // items per workgroup: 2 * (ACC_EXTRA_MAX + J_MAX_BINS) / J_ACCP_GROUPS = 16.5
 static_assert(2 * (ACC_EXTRA_MAX + J_MAX_BINS) <= J_ACCP_GROUPS * J_ACCP_MAXI, "k_jaccum_p: items per workgroup");
-enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_EBASE, JI_EMASK, JI_FIELDS };     // JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25
+static_assert(J_MAX_LEVELS <= 16, "JI_MISC holds the level in four bits");
+enum { JI_BASE, JI_C0, JI_C1, JI_NL, JI_MISC, JI_HS, JI_GOFF, JI_EBASE, JI_EMASK, JI_FIELDS };
+// JI_MISC: bin of the level | lg << 16 | side << 24 | hot << 25 | empty bin << 26 | nothing behind this index << 27 | level << 28
+#define JT_CAP (2 * (ACC_EXTRA_MAX + J_MAX_BINS))        // item descriptors: [JI_FIELDS][JT_CAP] in the workspace header
 
-__global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t TB,
-                                                            const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
-                                                            const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
+// ---------------------------------------------------------------------------------------------------------------
+// item descriptors of the accumulate pass (one thread per item, behind k_jscan on its stream).  Items are numbered densely, grid A's
+// first: [extra chunks of hot bins | bins with a side in A, level by level] then the same for grid B -- every index stands for work
+// except the extra chunks of single-grid bins in the other grid's list.  (With the numbering 2 x (extra slot or bin) | grid that the
+// accumulate kernel used to decode itself, 18 % of the indices of the bench batch were empty and its workgroups drew 2 to 4 items.)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jitems(JLevels lv, uint32_t n_levels, uint32_t e_max, uint32_t SA, uint32_t SB,
+                                               const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ dw_off,
+                                               const uint32_t* __restrict__ extra, const uint32_t* __restrict__ hdr,
+                                               uint32_t* __restrict__ items_tab) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_x = min(hdr[0], e_max), CH = hdr[1];
+    const uint32_t nA = n_x + SA, nB = n_x + SB;
+    if (u >= nA + nB) return;
+    const uint32_t side = u < nA ? 0u : 1u, v = side ? u - nA : u;
+    const bool is_extra = v < n_x;
+    uint32_t b = 0, chunk = 0;
+    if (is_extra) { const uint32_t pk = extra[v]; b = pk & 0xFFFFu; chunk = pk >> 16; }
+    // ONE walk over the levels finds the bin (by its number: an extra chunk; by its place in this grid's list otherwise) and what the
+    // accumulate pass needs to know about it
+    JBin jb; jb.level = 0; jb.kind = 0; jb.bl = 0;
+    uint32_t hs = 1u, lg = 0u, goff = 0u, emask = 0xFFFFu, r = v - n_x;
+    bool found = false;
+#pragma unroll
+    for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
+        const JLevel& q = lv.l[l];
+        if (l < n_levels && !found) {
+            const bool split = (q.flags & J_SPLIT) != 0u;
+            const uint32_t nbA = 1u << q.lgA, nbB = 1u << q.lgB, slots = (split && !side) ? nbA : nbB, nlb = split ? nbA + nbB : nbB;
+            const bool hit = is_extra ? (b - q.first < nlb) : (r < slots);
+            if (hit) {
+                found = true;
+                if (!is_extra) b = q.first + ((split && side) ? nbA : 0u) + r;
+                const uint32_t rel = b - q.first;
+                jb.level = l; jb.kind = split ? (rel < nbA ? 1u : 2u) : 0u; jb.bl = (split && rel >= nbA) ? rel - nbA : rel;
+                hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA;
+                if (jb.kind == 0u && side == 0u) emask = q.maskA & 0xFFFFu;                      // joint bin, table A: the B region's entries, masked
+            } else if (!is_extra) r -= slots;
+        }
+    }
+    bool ok = found;
+    if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) ok = false;            // a single-grid bin has no records of the other grid
+    uint32_t cnt = 0, dwo = 0;
+    if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
+    const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
+    const uint32_t f[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region(cnt) : 0u), ok ? c0 : 0u, ok ? c1 : 0u, bin_n_local(hs, jb.bl, lg),
+                                   jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25) | ((ok && cnt == 0u && chunk == 0u ? 1u : 0u) << 26) |
+                                       ((ok ? 0u : 1u) << 27) | (jb.level << 28),
+                                   hs, goff, dwo + (jb.kind == 0u ? j_region(cnt) : 0u), emask};
+#pragma unroll
+    for (int k = 0; k < JI_FIELDS; ++k) items_tab[(size_t)k * JT_CAP + u] = f[k];
+}
+
+
+__global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, uint32_t SA, uint32_t SB,
+                                                            const uint32_t* __restrict__ items_tab, const uint32_t* __restrict__ hdr,
                                                             const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
                                                             float* __restrict__ gradA,
-                                                            float* __restrict__ gradB, int overwrite, int side_sel) {
+                                                            float* __restrict__ gradB, int overwrite, int side_sel
+#ifdef J_ACC_TIMING
+                                                            , unsigned long long* __restrict__ dbg     // timing build (tools/acc_balance.py): per workgroup
+#endif                                                                                                 // start, end (100 MHz ticks), items, records
+                                                            ) {
+#ifdef J_ACC_TIMING
+    const unsigned long long dbg_t0 = wall_clock64();
+    unsigned long long dbg_rec = 0;
+#endif
     // side_sel: -1 both grids' items; 0 / 1: the items of grid A / B only (the data-parallel step finishes the colour table first, so
     // that its all-reduce travels while the sdf table is summed)
     __shared__ double acc[J_ACC_DOUBLES + 4 * 8];
@@ -665,36 +741,22 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
     __shared__ uint32_t n_items, n_zitems;
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < J_ACC_DOUBLES + 4 * 8; k += J_ACC_THREADS) acc[k] = 0.0;
-    if (tid < 64) {                                              // wave 0, lane i: the workgroup's i-th item
-        const uint32_t T = (side_sel < 0 ? 2u : 1u) * (e_max + TB), t = blockIdx.x + tid * gridDim.x;
-        const uint32_t side = side_sel < 0 ? (t & 1u) : (uint32_t)side_sel, slot = side_sel < 0 ? (t >> 1) : t;
-        const uint32_t CH = hdr[1];                              // records per item (k_jscan)
-        bool ok = t < T && tid < J_ACCP_MAXI;
-        uint32_t b = 0, chunk = 0;
-        if (ok) {
-            if (slot < e_max) {
-                ok = slot < hdr[0];
-                if (ok) { const uint32_t pk = extra[slot]; b = pk & 0xFFFFu; chunk = pk >> 16; }
-            } else b = slot - e_max;
-        }
-        const JBin jb = j_bin_of(lv, n_levels, b);
-        if ((jb.kind == 1u && side == 1u) || (jb.kind == 2u && side == 0u)) ok = false;        // a single-grid bin has no records of the other grid
-        uint32_t hs = 1u, lg = 0u, goff = 0u, emask = 0xFFFFu;
+    // ---- which items: workgroup b takes the table's indices i G + b on even turns i and i G + (G - 1 - b) on odd ones -- within a turn
+    // the items grow with the index (finer levels: more records per bin), and the alternation cancels that trend over a list
+    const uint32_t G = gridDim.x;
+    const uint32_t n_x = min(hdr[0], e_max);
+    const uint32_t nA = n_x + SA, nB = n_x + SB;                 // items of grid A / B: extra chunks + bins with a side in that grid
+    const uint32_t lo = side_sel == 1 ? nA : 0u, cnt_u = side_sel < 0 ? nA + nB : (side_sel ? nB : nA);
+    if (tid < 64) {                                              // wave 0, lane i: the workgroup's i-th turn
+        const uint32_t turn = tid;
+        const uint32_t v = turn * G + ((turn & 1u) ? G - 1u - blockIdx.x : blockIdx.x);
+        const bool in = turn < (uint32_t)J_ACCP_MAXI && v < cnt_u;
+        const uint32_t u = in ? lo + v : 0u;
+        uint32_t fields[JI_FIELDS];
 #pragma unroll
-        for (uint32_t l = 0; l < J_MAX_LEVELS; ++l) {
-            const JLevel& q = lv.l[l];
-            if (l < n_levels && jb.level == l) {
-                hs = side ? q.hsB : q.hsA; lg = side ? q.lgB : q.lgA; goff = side ? q.offB : q.offA;
-                if (jb.kind == 0u && side == 0u) emask = q.maskA & 0xFFFFu;      // joint bin, table A: the B region's entries, masked
-            }
-        }
-        uint32_t cnt = 0, dwo = 0;
-        if (ok) { const uint32_t b0 = rec_off[b]; cnt = rec_off[b + 1] - b0; dwo = dw_off[b]; }
-        const uint32_t c0 = chunk * CH, c1 = (cnt > c0 && cnt - c0 > CH) ? c0 + CH : cnt;
-        const bool has = ok && c1 > c0, zero = ok && cnt == 0u && overwrite;
-        const uint32_t fields[JI_FIELDS] = {dwo + ((jb.kind == 0u && side == 1u) ? j_region(cnt) : 0u), c0, c1, bin_n_local(hs, jb.bl, lg),
-                                            jb.bl | (lg << 16) | (side << 24) | ((cnt > CH ? 1u : 0u) << 25), hs, goff,
-                                            dwo + (jb.kind == 0u ? j_region(cnt) : 0u), emask};
+        for (int f = 0; f < JI_FIELDS; ++f) fields[f] = items_tab[(size_t)f * JT_CAP + u];
+        const bool valid = in && !((fields[JI_MISC] >> 27) & 1u);
+        const bool has = valid && fields[JI_C1] > fields[JI_C0], zero = valid && ((fields[JI_MISC] >> 26) & 1u) && overwrite;
         const uint64_t mh = __ballot(has), mz = __ballot(zero), below = (1ull << tid) - 1ull;
         if (has) { const uint32_t p = (uint32_t)__popcll(mh & below);
 #pragma unroll
@@ -740,6 +802,9 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
         // collisions of the LDS atomics; the copies sit 2 nl + 8 doubles apart (bank spread)
         REP = (8u * nl <= J_ACC_DOUBLES) ? 4u : 1u; rstride = 2u * nl + 8u;
         my = acc + (tid & (REP - 1u)) * rstride;
+#ifdef J_ACC_TIMING
+        dbg_rec += c1 - a;
+#endif
     };
     auto sweep = [&]() {                                         // sums of the item -> gradient table; the accumulators return to zero
         const uint32_t bl = misc & 0xFFFFu, lg = (misc >> 16) & 0xFFu, side = (misc >> 24) & 1u;
@@ -813,17 +878,20 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(JLevels lv, uint3
             if (e < zhs) *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
         }
     }
+#ifdef J_ACC_TIMING
+    if (tid == 0) { dbg[4 * blockIdx.x] = dbg_t0; dbg[4 * blockIdx.x + 1] = wall_clock64(); dbg[4 * blockIdx.x + 2] = n; dbg[4 * blockIdx.x + 3] = dbg_rec << 32; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
-// workspace: totals | rec_off | dw_off (3 x (J_MAX_BINS + 64) u32) | hdr (16 u32) | extra (ACC_EXTRA_MAX u32) | count rows
+// workspace: totals | rec_off | dw_off (3 x (J_MAX_BINS + 64) u32) | hdr (16 u32) | extra (ACC_EXTRA_MAX u32) | item descriptors | count rows
 // [rows][row_stride] | their column prefixes | records
 static uint32_t j_row_stride(int TB) { return ((uint32_t)TB + 63u) & ~63u; }
 static size_t j_header_bytes(int TB, int64_t n) {
     const size_t rows = (size_t)us_cdiv(n, J_ROW_POINTS);
-    return (size_t)(3 * (J_MAX_BINS + 64) + 16 + ACC_EXTRA_MAX) * sizeof(uint32_t) + 2 * rows * j_row_stride(TB) * sizeof(uint32_t);
+    return (size_t)(3 * (J_MAX_BINS + 64) + 16 + ACC_EXTRA_MAX + JI_FIELDS * JT_CAP) * sizeof(uint32_t) + 2 * rows * j_row_stride(TB) * sizeof(uint32_t);
 }
 // record indices of both grids (every (bin, grid) region padded to 8) and the bytes of the two planes over them
 static uint64_t j_record_cap(uint32_t n_levels, int64_t n) { return (uint64_t)n * 8ull * n_levels * 2ull + 16ull * J_MAX_BINS; }
@@ -844,7 +912,7 @@ extern "C" size_t us_hashgrid_joint_workspace_bytes(const us_grid_desc* a, const
     return j_header_bytes(TB, n) + j_record_bytes(a->n_levels, n);
 }
 
-struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *counts, *prefix; uint16_t* rec_e; uint2* rec_v; uint32_t n_rows, stride, rec_cap; };
+struct JWorkspace { uint32_t *totals, *rec_off, *dw_off, *hdr, *extra, *items, *counts, *prefix; uint16_t* rec_e; uint2* rec_v; uint32_t n_rows, stride, rec_cap; };
 static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n) {
     JWorkspace w;
     w.totals = (uint32_t*)workspace;
@@ -852,7 +920,8 @@ static JWorkspace j_carve(void* workspace, uint32_t n_levels, int TB, int64_t n)
     w.dw_off = w.rec_off + (J_MAX_BINS + 64);
     w.hdr = w.dw_off + (J_MAX_BINS + 64);
     w.extra = w.hdr + 16;
-    w.counts = w.extra + ACC_EXTRA_MAX;
+    w.items = w.extra + ACC_EXTRA_MAX;
+    w.counts = w.items + (size_t)JI_FIELDS * JT_CAP;
     w.n_rows = (uint32_t)us_cdiv(n, J_ROW_POINTS); w.stride = j_row_stride(TB);
     w.prefix = w.counts + (size_t)w.n_rows * w.stride;
     w.rec_cap = (uint32_t)j_record_cap(n_levels, n);
@@ -1027,6 +1096,8 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     const JWorkspace w = j_carve(workspace, a->n_levels, TB, n);
     const int clamp = flags & US_GRID_CLAMP01;
     const uint32_t L = a->n_levels;
+    uint32_t SA = 0, SB = 0;                                     // bins with a side in grid A / B (a joint bin: both)
+    for (uint32_t l = 0; l < L; ++l) { SA += (lv.l[l].flags & J_SPLIT) ? 1u << lv.l[l].lgA : 1u << lv.l[l].lgB; SB += 1u << lv.l[l].lgB; }
     if (!counted)
         hipLaunchKernelGGL((k_jfwd<false, true, false>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
                            (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
@@ -1038,6 +1109,8 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
         for (uint32_t l = 0; l < L; ++l)
             if (lv.l[l].flags & J_SPLIT) { sg.lo[l] = lv.l[l].first; sg.len[l] = j_level_bins(lv.l[l]); }
         hipLaunchKernelGGL(k_jscan, dim3(1), dim3(1024), 0, s, sg, w.totals, (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, chunk0);
+        hipLaunchKernelGGL(k_jitems, dim3((2u * ACC_EXTRA_MAX + SA + SB + 255u) / 256u), dim3(256), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX, SA, SB, w.rec_off,
+                           w.dw_off, w.extra, w.hdr, w.items);
     }
     if (scan_only) { US_CHECK_LAUNCH("us_hashgrid_joint_scan"); return US_OK; }
     const int side_sel = (flags & US_GRID_BWD_ONLY_A) ? 0 : ((flags & US_GRID_BWD_ONLY_B) ? 1 : -1);
@@ -1047,9 +1120,13 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     if (!(flags & US_GRID_BWD_RECORDS_READY))
         hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
                            w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n);
-    const uint32_t n_acc_items = (side_sel < 0 ? 2u : 1u) * (ACC_EXTRA_MAX + (uint32_t)TB);
-    hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, lv, L, (uint32_t)ACC_EXTRA_MAX,
-                       (uint32_t)TB, w.rec_off, w.dw_off, w.extra, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel);
+    const uint32_t n_acc_items = side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA);
+    hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, (uint32_t)ACC_EXTRA_MAX,
+                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel
+#ifdef J_ACC_TIMING
+                       , (unsigned long long*)((char*)workspace + us_hashgrid_joint_workspace_bytes(a, b, n) - (size_t)J_ACCP_GROUPS * 32u)   // the last 64 KiB of the
+#endif                                                                                                                                          // record planes: never reached
+                       );
     US_CHECK_LAUNCH("us_hashgrid_bwd_joint");
     return US_OK;
 }

@@ -421,10 +421,12 @@ class MapStep:
                     self.scan_stream.wait_stream(torch.cuda.current_stream())
                 self._scan_pending = True
                 with torch.cuda.stream(self.scan_stream):
-                    L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
+                    # (the increment first: a one-thread launch behind the scans would be issued while the decoders' backward pass fills
+                    #  every CU's LDS, and sit there until one of its workgroups leaves -- 47 us, profiles/r04_timeline.txt's forerunner)
                     if not self._step_advanced:                  # Adam's step count for this iteration (the sampler has read the old one)
                         L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, L.stream()), "us_adam_step_inc")
                         self._step_advanced = True
+                    L.check(scan_call(L.stream()), "us_hashgrid_joint_scan")
             if self._probing or not self.overlap:
                 self._timed("hashgrid_scan_joint", lambda: scan_call(st))
             elif not main_first:
