@@ -437,7 +437,14 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
                                                             uint32_t row_stride, uint16_t* __restrict__ rec_e, uint2* __restrict__ rec_v,
-                                                            uint32_t rec_cap, int64_t plane_stride) {
+                                                            uint32_t rec_cap, int64_t plane_stride
+#ifdef J_WR_TIMING
+                                                            , unsigned long long* __restrict__ dbg     // timing build (tools/wr_levels.py): [workgroup][24] clocks
+#endif
+                                                            ) {
+#ifdef J_WR_TIMING
+    if (threadIdx.x == 0) dbg[24 * blockIdx.x] = wall_clock64();
+#endif
     __shared__ uint2 stxy[J_STAGE];                              // stage: {local entry | bin of the level << 16, d0}
     __shared__ uint32_t stz[J_STAGE];                            //        d1                                       (48 KiB together)
     __shared__ uint32_t cur[2][J_LVL_BINS];                      // [level parity][bin of the level]: stage cursor
@@ -499,6 +506,9 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
     setup_fin(0, 0, c1, p1, o1, t1, incl1);
 
     for (uint32_t level = 0; level < n_levels; ++level) {
+#ifdef J_WR_TIMING
+        if (threadIdx.x == 0) dbg[24 * blockIdx.x + 1 + level] = wall_clock64();
+#endif
         const int par = level & 1;
         const JLevel q = lv.l[level];
         const bool split = (q.flags & J_SPLIT) != 0u, has_next = level + 1 < n_levels;
@@ -633,6 +643,9 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
             copy_out(min(ttot[par] - sb, (uint32_t)J_STAGE), gra[par], sb, JBufTag<1>{});
         }
     }
+#ifdef J_WR_TIMING
+    if (threadIdx.x == 0) dbg[24 * blockIdx.x + 17] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -654,7 +667,10 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 //    evened the ends out at the price of a counter and a descriptor round trip per item (or a look-ahead as long as the lists): slower;
 //  * runs of records on ONE entry (every ray of a keyframe starts at its camera: the bins that own the vertices of those cells) serialise
 //    a wave's ds_add_f64; summing such runs in registers first (segmented DPP scan) took the items of levels 2-5 from 12-28 us to
-//    8-19 us -- and left the kernel where it was: the time went to their neighbours on the CU.
+//    8-19 us -- and left the kernel where it was: the time went to their neighbours on the CU;
+//  * s_setprio handed round the four workgroups of a CU item by item: ends 49-74 us by placement instead of 45-69, kernel 87 us: slower.
+//    (The same in the record pass, whose two workgroups per CU end at 99 and 124 us -- tools/wr_levels.py: priority changing hands
+//    level by level moved the first to 113 us and the second nowhere: that kernel is bound by what a CU issues, not by who issues it.)
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef J_ACCP_GROUPS
 #define J_ACCP_GROUPS 1024
@@ -1119,7 +1135,11 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
                "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
     if (!(flags & US_GRID_BWD_RECORDS_READY))
         hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n);
+                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n
+#ifdef J_WR_TIMING
+                           , (unsigned long long*)((char*)workspace + ((us_hashgrid_joint_workspace_bytes(a, b, n) & ~(size_t)7) - (size_t)393216))   // the planes' unused end
+#endif
+                           );
     const uint32_t n_acc_items = side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA);
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, (uint32_t)ACC_EXTRA_MAX,
                        SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel
