@@ -70,10 +70,10 @@ def traffic(names):
             if any(n in k for n in names):
                 tot += corr * med(a[k][c]) * 1024
     return tot
-out = {"hashgrid_bwd_joint": traffic(("k_jcolscan", "k_jscan", "k_jwrite", "k_jaccum")), "hashgrid_fwd_joint": traffic(("k_jfwd<true, true, false>",))}
+out = {"hashgrid_bwd_joint": traffic(("k_jcolscan", "k_jscan", "k_jitems", "k_jwrite", "k_jaccum")), "hashgrid_fwd_joint": traffic(("k_jfwd<true, true, false>",))}
 for k, v in out.items():
     print(k, round(v / 1e6, 1), "MB")
 json.dump({**out, "_note": f"bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per-kernel medians summed over the kernels of the entry point (hashgrid_bwd_joint: "
-                           f"k_jcolscan, k_jscan, k_jwrite, k_jaccum; the counting runs in the encoder), rocprofv3 --pmc in separate passes, {T}; FETCH_SIZE doubled per "
+                           f"k_jcolscan, k_jscan, k_jitems, k_jwrite, k_jaccum; the counting runs in the encoder), rocprofv3 --pmc in separate passes, {T}; FETCH_SIZE doubled per "
                            "MI355X_MICROARCH.md (gfx950 reports half of a wide streaming read)"},
           open(os.path.join(R, "profiles/traffic.json"), "w"), indent=1)
