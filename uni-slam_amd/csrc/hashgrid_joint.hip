@@ -157,7 +157,15 @@ template <bool GATHER, bool COUNT, bool DYDX = false>
 __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
                                                         int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
-                                                        us_half_t* __restrict__ dydxA = nullptr, us_half_t* __restrict__ dydxB = nullptr) {
+                                                        us_half_t* __restrict__ dydxA = nullptr, us_half_t* __restrict__ dydxB = nullptr
+#ifdef J_FWD_TIMING
+                                                        , unsigned long long* __restrict__ dbg = nullptr      // timing build (tools/fwd_clocks.py)
+#endif
+                                                        ) {
+#ifdef J_FWD_TIMING
+    const unsigned long long dbg_t0 = wall_clock64();
+    unsigned long long dbg_t1 = 0;
+#endif
     constexpr int HALVES = J_FWD_THREADS / J_ROW_POINTS;
     __shared__ uint32_t lcnt[HALVES][J_LVL_BINS];
     __shared__ uint32_t done;
@@ -224,6 +232,9 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
             }
         }
     }
+#ifdef J_FWD_TIMING
+    dbg_t1 = wall_clock64();                                     // (the features of this thread are on their way out)
+#endif
     if (!COUNT) return;
     // ---- the records k_jwrite will emit for these points, per bin (every point counts: no gradient exists yet)
     uint32_t key[8];
@@ -259,6 +270,15 @@ __global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_l
             uint32_t* row = counts + (size_t)r * row_stride + q.first;
             for (uint32_t t = (uint32_t)lane; t < nlb; t += 64) row[t] = lcnt[h][t];
         }
+#ifdef J_FWD_TIMING
+        if (dbg && lane == 0) {
+            unsigned long long* d = dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            d[0] = dbg_t0; d[1] = dbg_t1; d[2] = wall_clock64();
+            unsigned int xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            d[3] = ((unsigned long long)xcc << 32) | hw;
+        }
+#endif
     }
 }
 
@@ -979,7 +999,11 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
                    "%s: workspace %zu B < %zu B", fn, workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
         const JWorkspace w = j_carve(workspace, a->n_levels, TB, n);
         if (dydxA) hipLaunchKernelGGL((k_jfwd<true, true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
-        else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
+        else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB
+#ifdef J_FWD_TIMING
+                                , (unsigned long long*)((char*)workspace + ((us_hashgrid_joint_workspace_bytes(a, b, n) & ~(size_t)7) - (size_t)393216))
+#endif
+                                );
     } else {
         // small batches (a tracking iteration: 80 000 points = 79 workgroups of 1024 per level) leave a ragged last round over the chip's
         // 256 CUs: 256-thread workgroups there
