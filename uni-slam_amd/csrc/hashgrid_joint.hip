@@ -28,6 +28,11 @@
 #ifndef J_FWD_THREADS
 #define J_FWD_THREADS 1024               // encoder workgroup: 1024 points x one level (two count rows)
 #endif
+#ifndef J_FWD_WAVES_PER_EU
+#define J_FWD_WAVES_PER_EU 4               // register budget of the encoder: 4 waves per SIMD = ONE 1024-thread workgroup per CU (it takes 70 registers);
+                                         // 8 = two per CU (64 registers, no spill in the counting form): encoder 132 -> 140 us, same box (r4) -- the
+                                         // gathers are served at the memory system's rate, more waves only spread each level's slab thinner
+#endif
 #ifndef J_DYDX_NT
 #define J_DYDX_NT 1                      // dy/dx is written once and read once: non-temporal stores.  Measured (MI355X, 4096 x 64): with the
 #endif                                   // planes [L][3][N][2] a store instruction covers whole 128-byte lines and the encoder takes 169 us (plain
@@ -154,7 +159,7 @@ static int make_jlevels(const us_grid_desc* a, const us_grid_desc* b, int64_t n,
 // contracts with dL/dy: us_hashgrid_dydx_rays) -- the 8 vertices are in registers here, and 24 contiguous bytes per thread and grid
 // stream out coalesced, where a second gather pass over the tables (us_hashgrid_bwd_input_rays) costs as much as the encoder itself.
 template <bool GATHER, bool COUNT, bool DYDX = false>
-__global__ __launch_bounds__(J_FWD_THREADS) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
+__global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
                                                         int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
                                                         us_half_t* __restrict__ dydxA = nullptr, us_half_t* __restrict__ dydxB = nullptr
