@@ -1019,7 +1019,7 @@ def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
     g = torch.Generator().manual_seed(2)
     trs = [torch.rand(R, S, generator=g).to(DEV) for _ in range(5)]
     outs = []
-    for folded in (True, False):
+    for folded in (True, "two launches", False):                # (True: the whole optimiser step in one launch, us_adam_step_model)
         torch.manual_seed(7)
         dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
         es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
@@ -1027,6 +1027,7 @@ def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
             es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
         step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, deterministic=True)    # (no float atomics in hot bins)
         assert step.joint and step._decoder_pair() and step.overlap
+        step.one_launch_adam = folded is True
         losses = []
         for tr in trs:
             if folded:
@@ -1037,13 +1038,14 @@ def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
                 step.adam_step()
         torch.cuda.synchronize()
         outs.append((losses, step.flat.clone(), step.m.clone(), step.v.clone(), step.grad[:step.o_tab_s].clone()))
-    a, b = outs
-    assert a[0] == b[0]
+    a, a2, b = outs
+    assert a[0] == b[0] and a2[0] == b[0]
     nd = step.o_tab_s
     for k in range(1, 4):
-        assert torch.equal(a[k][:nd], b[k][:nd]), k                  # decoders + beta: parameters and moments bit for bit
+        assert torch.equal(a[k][:nd], b[k][:nd]) and torch.equal(a2[k][:nd], b[k][:nd]), k      # decoders + beta: parameters and moments bit for bit
         # (the tables do not take part in the change; their f64 sums are order-free up to rare last-bit flips of entries of 1e-20)
-        assert torch.allclose(a[k][nd:], b[k][nd:], rtol=1e-6, atol=1e-12), k
+        assert torch.allclose(a[k][nd:], b[k][nd:], rtol=1e-6, atol=1e-12) and torch.allclose(a2[k][nd:], b[k][nd:], rtol=1e-6, atol=1e-12), k
+    assert torch.equal(a[4], a2[4])
     # the decoder gradients of the last iteration are in the gradient buffer either way (the unfolded optimiser pass clears them: compare
     # against a recomputation)
     assert float(a[4].abs().max()) > 0

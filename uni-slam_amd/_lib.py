@@ -88,6 +88,9 @@ SIGNATURES = {
     "us_ray_points_bwd2": (c_int, [c_f, c_f, c_f, _HF, c_i64, c_int, c_f, c_f, c_f]),
     "us_mlp_reduce_pair_adam": (c_int, [_MP, _MP, c_f, c_f, ctypes.c_size_t, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f,
                                         c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
+    "us_adam_step_model": (c_int, [_MP, _MP, c_f, c_f, ctypes.c_size_t, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f,
+                                   c_dbl, c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl),
+                                   c_dbl, c_dbl, c_dbl, c_f, ctypes.c_uint, c_f]),
     "us_mlp_fwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_bwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_int,
                                 c_f, c_f, ctypes.c_size_t, c_f]),

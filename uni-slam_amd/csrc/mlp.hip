@@ -543,6 +543,7 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
 }
 
 #include "mlp_bf16.inc"
+#include "dec_adam_dev.h"
 
 // -------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -832,17 +833,6 @@ extern "C" int us_mlp_reduce_pair(const us_mlp_desc* da, const us_mlp_desc* db, 
 // needed), beta's gradient = f64 sum of the per-ray partials, then torch.optim.Adam on exactly those parameters -- one launch on the
 // MAIN stream in front of the tables' Adam pass instead of a fill, two reductions and a fork / join around the table gradient
 // (src/Mapper.py:443-445: zero_grad, backward, step for the param group of :118).
-struct DecAdam { float lr, one_minus_b1, b2, one_minus_b2, eps; const float* step_dev; };
-__device__ __forceinline__ void dec_adam_apply(float g, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const DecAdam& ad) {
-    const double* aux = reinterpret_cast<const double*>(ad.step_dev + 2);          // as k_adam_segs (render.hip) reads them
-    const float step_size = (float)((double)ad.lr / aux[0]), bc2_sqrt = (float)aux[1];
-    const float m0 = *m, v0 = *v;
-    const float mi = m0 + ad.one_minus_b1 * (g - m0);
-    const float vi = v0 * ad.b2 + (ad.one_minus_b2 * g) * g;
-    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
-    *p = *p + (-step_size) * (mi / denom);
-    *m = mi; *v = vi;
-}
 __global__ __launch_bounds__(1024) void k_mlp_reduce_pair_adam(const float* __restrict__ pa, const float* __restrict__ pb, int n_rows, int npa, int npb,
                                                                float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ Pa,
                                                                float* __restrict__ Pb, float* __restrict__ ma, float* __restrict__ mb,
@@ -901,6 +891,33 @@ extern "C" int us_mlp_reduce_pair_adam(const us_mlp_desc* da, const us_mlp_desc*
                        grad_params_b, params_a, params_b, m_a, m_b, v_a, v_b, beta_partials, n_rays, beta, grad_beta, m_beta, v_beta, ad);
     US_CHECK_LAUNCH("us_mlp_reduce_pair_adam");
     return US_OK;
+}
+
+// The same, and the optimiser pass of the tables, in ONE launch: the decoder group's reductions are three extra slices of the tables' Adam
+// launch (render.hip: k_adam_segs_model) -- 50 small workgroups beside thousands, instead of a 7.5 us launch in front of them.
+extern "C" int us_adam_step_model(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b,
+                                  size_t workspace_bytes, int64_t n, float* params_a, float* params_b, float* grad_params_a,
+                                  float* grad_params_b, float* m_a, float* m_b, float* v_a, float* v_b, const float* beta_partials,
+                                  int64_t n_rays, float* beta, float* grad_beta, float* m_beta, float* v_beta, double lr_decoders,
+                                  float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
+                                  const double* seg_lr, double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask,
+                                  void* stream) {
+    US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_adam_step_model: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
+    if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
+    US_REQUIRE(workspace_a && workspace_b && params_a && params_b && grad_params_a && grad_params_b && m_a && m_b && v_a && v_b && step_dev, US_ERR_NULL,
+               "us_adam_step_model: NULL pointer");
+    US_REQUIRE(!beta_partials || (beta && grad_beta && m_beta && v_beta && n_rays >= 1), US_ERR_NULL, "us_adam_step_model: beta needs p, g, m, v and n_rays");
+    US_REQUIRE(((uintptr_t)step_dev & 7u) == 0, US_ERR_SHAPE, "us_adam_step_model: step_dev (float[8]) must be 8-byte aligned");
+    US_REQUIRE(workspace_bytes >= us_mlp_bwd_workspace_bytes(da) && workspace_bytes >= us_mlp_bwd_workspace_bytes(db), US_ERR_WORKSPACE,
+               "us_adam_step_model: workspace %zu B too small", workspace_bytes);
+    DecGroup dg;
+    dg.pa = (const float*)workspace_a; dg.pb = (const float*)workspace_b; dg.n_rows = (int)mlp_pair_rows(da, n);
+    dg.npa = (int)us_mlp_n_params(da); dg.npb = (int)us_mlp_n_params(db);
+    dg.ga = grad_params_a; dg.gb = grad_params_b; dg.Pa = params_a; dg.Pb = params_b; dg.ma = m_a; dg.mb = m_b; dg.va = v_a; dg.vb = v_b;
+    dg.beta_part = beta_partials; dg.n_rays = n_rays; dg.p_beta = beta; dg.g_beta = grad_beta; dg.m_beta = m_beta; dg.v_beta = v_beta;
+    dg.ad.lr = (float)lr_decoders; dg.ad.one_minus_b1 = (float)(1.0 - beta1); dg.ad.b2 = (float)beta2; dg.ad.one_minus_b2 = (float)(1.0 - beta2);
+    dg.ad.eps = (float)eps; dg.ad.step_dev = step_dev;
+    return us_adam_segments_model(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, step_dev, zero_grad_mask, stream, dg);
 }
 
 #include <string.h>

@@ -7,6 +7,7 @@
 // The file is compiled with -ffp-contract=off: the reference evaluates these expressions as separate fp32 ops,
 // and z_vals is required to match it bit for bit.
 #include "us_common.h"
+#include "dec_adam_dev.h"
 #include <math.h>
 #include <string.h>
 
@@ -962,25 +963,25 @@ __global__ void k_step_inc(float* step_dev, double beta1, double beta2) {
 // VEC = 4: segments whose offset and length are multiples of 4 floats (16-byte aligned base pointers): one 16-byte access per array and
 // thread instead of four 4-byte ones.  Same arithmetic per element.
 template <int VEC>
-__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+__device__ __forceinline__ void adam_segs_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, AdamSegs sg, float one_minus_b1, float b2,
                                                    float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask,
-                                                   const float* __restrict__ step_dev, const uint16_t* __restrict__ g16 = nullptr,
-                                                   unsigned g16_mask = 0u) {
+                                                   const float* __restrict__ step_dev, const uint16_t* __restrict__ g16,
+                                                   unsigned g16_mask, unsigned bx, unsigned by, unsigned gx) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     typedef uint16_t h_t __attribute__((ext_vector_type(VEC)));
-    const int64_t n = sg.n[blockIdx.y] / VEC, o = sg.off[blockIdx.y];
+    const int64_t n = sg.n[by] / VEC, o = sg.off[by];
     // g16 (us_adam_step_segments_bf16): a bfloat16 image of the gradient buffer (same indexing); the segments flagged in g16_mask read
     // their gradient THERE -- the payload of a data-parallel all-reduce as it came off the wire, no widening pass in between
-    const bool narrow = g16 != nullptr && ((g16_mask >> blockIdx.y) & 1u);
-    const bool zero = (zero_mask >> blockIdx.y) & 1u;            // optimizer.zero_grad() of this segment, folded in
-    float step_size = sg.step_size[blockIdx.y];
+    const bool narrow = g16 != nullptr && ((g16_mask >> by) & 1u);
+    const bool zero = (zero_mask >> by) & 1u;                    // optimizer.zero_grad() of this segment, folded in
+    float step_size = sg.step_size[by];
     if (step_dev) {
         const double* aux = reinterpret_cast<const double*>(step_dev + 2);
         step_size = (float)((double)step_size / aux[0]);
         bc2_sqrt = (float)aux[1];
     }
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = (int64_t)bx * blockDim.x + threadIdx.x; k < n; k += (int64_t)gx * blockDim.x) {
         const int64_t i = o + k * VEC;
         // g, m, v are streamed once per step: non-temporal, so that the tables (p), which the next forward gathers from, stay cached
         vec_t gv;
@@ -1006,6 +1007,72 @@ __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float*
         *reinterpret_cast<vec_t*>(p + i) = pv;
         __builtin_nontemporal_store(mo, reinterpret_cast<vec_t*>(m + i)); __builtin_nontemporal_store(vo, reinterpret_cast<vec_t*>(v + i));
         if (zero) { vec_t z; for (int e = 0; e < VEC; ++e) z[e] = 0.0f; *reinterpret_cast<vec_t*>(g + i) = z; }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamSegs sg,
+                                                   float one_minus_b1, float b2, float one_minus_b2, float bc2_sqrt, float eps, unsigned zero_mask,
+                                                   const float* __restrict__ step_dev, const uint16_t* __restrict__ g16 = nullptr,
+                                                   unsigned g16_mask = 0u) {
+    adam_segs_body<VEC>(p, g, m, v, sg, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, zero_mask, step_dev, g16, g16_mask, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// ... with the decoder param group riding along (us_adam_step_model).  A one-dimensional launch: the FIRST workgroups are the decoder
+// group's -- gd per decoder (fixed-order sums of their partial rows, then Adam), one for beta (f64 sum of the per-ray partials) -- so they
+// are placed first and finish under the tables' stream; the rest are the table segments', each with workgroups in proportion to its size.  (As trailing slices of a
+// two-dimensional grid they were placed last, behind 3 x gt workgroups that had nothing to do: 5-10 us SLOWER than two launches.)
+// 256 threads walk through what k_mlp_reduce_pair_adam's 1024 do, in the same order: the results are the same bits.
+struct SegBlocks { unsigned n[ADAM_MAX_SEG]; };
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adam_segs_model(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                         AdamSegs sg, unsigned gd, SegBlocks sb, float one_minus_b1, float b2, float one_minus_b2,
+                                                         float bc2_sqrt, float eps, unsigned zero_mask, const float* __restrict__ step_dev, DecGroup dg) {
+    const unsigned nd = 2u * gd + 1u;
+    if (blockIdx.x >= nd) {                                      // a table segment's workgroup: segment k has blocks[k] of them (in proportion to its size)
+        unsigned t = blockIdx.x - nd, k = 0;
+        while (k + 1u < (unsigned)ADAM_MAX_SEG && t >= sb.n[k]) { t -= sb.n[k]; ++k; }
+        adam_segs_body<VEC>(p, g, m, v, sg, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, zero_mask, step_dev, nullptr, 0u, t, k, sb.n[k]);
+        return;
+    }
+    const int which = blockIdx.x == nd - 1u ? 2 : (int)(blockIdx.x / gd);
+    const unsigned bx = blockIdx.x % gd;
+    if (which == 2) {                                            // beta: one workgroup
+        if (!dg.beta_part) return;
+        __shared__ double shd[1024];
+        for (int vt = threadIdx.x; vt < 1024; vt += 256) {
+            double acc = 0.0;
+            for (long long r = vt; r < dg.n_rays; r += 1024) acc += (double)dg.beta_part[r];
+            shd[vt] = acc;
+        }
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            for (int vt = threadIdx.x; vt < o; vt += 256) shd[vt] += shd[vt + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { const float gb = (float)shd[0]; *dg.g_beta = gb; dec_adam_apply(gb, dg.p_beta, dg.m_beta, dg.v_beta, dg.ad); }
+        return;
+    }
+    __shared__ float sh[16][64];
+    const float* partials = which ? dg.pb : dg.pa;
+    const int np = which ? dg.npb : dg.npa;
+    const int kl = threadIdx.x & 63, s4 = threadIdx.x >> 6;
+    const int k = (int)bx * 64 + kl;
+    if ((int)bx * 64 >= np) return;                              // (workgroup-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = s4 + 4 * q;
+        float s = 0.0f;
+        if (k < np)
+            for (int r = sl; r < dg.n_rows; r += 16) s += partials[(size_t)r * np + k];
+        sh[sl][kl] = s;
+    }
+    __syncthreads();
+    if (s4 == 0 && k < np) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][kl];
+        (which ? dg.gb : dg.ga)[k] = t;
+        dec_adam_apply(t, (which ? dg.Pb : dg.Pa) + k, (which ? dg.mb : dg.ma) + k, (which ? dg.vb : dg.va) + k, dg.ad);
     }
 }
 
@@ -1738,6 +1805,48 @@ static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, cons
                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
                            (const float*)step_dev, g16, g16_mask);
     US_CHECK_LAUNCH("us_adam_step_segments");
+    return US_OK;
+}
+
+int us_adam_segments_model(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n, const double* seg_lr,
+                           double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask, void* stream, const DecGroup& dg) {
+    US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr && step_dev, US_ERR_NULL, "us_adam_step_model: NULL pointer");
+    US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_model: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
+    AdamSegs sg;
+    memset(&sg, 0, sizeof(sg));
+    int64_t n_max = 0;
+    bool vec4 = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0;
+    for (int k = 0; k < n_seg; ++k) {
+        US_REQUIRE(seg_off[k] >= 0 && seg_n[k] >= 0, US_ERR_SHAPE, "us_adam_step_model: segment %d: offset %lld n %lld", k, (long long)seg_off[k], (long long)seg_n[k]);
+        sg.off[k] = seg_off[k]; sg.n[k] = seg_n[k]; sg.step_size[k] = (float)seg_lr[k];
+        if (seg_n[k] > n_max) n_max = seg_n[k];
+        vec4 = vec4 && (seg_off[k] % 4 == 0) && (seg_n[k] % 4 == 0);
+    }
+    const bool advanced = (zero_grad_mask & US_ADAM_STEP_ADVANCED) != 0;
+    zero_grad_mask &= ~US_ADAM_STEP_ADVANCED;
+    if (!advanced) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, beta1, beta2);
+    const int np = dg.npa > dg.npb ? dg.npa : dg.npb;
+    const unsigned gd = (unsigned)us_cdiv(np, 64);               // workgroups per decoder
+    const int vec = vec4 ? 4 : 1;
+    const unsigned cap = vec4 ? ADAM_VEC_BLOCKS : 4096;
+    int64_t n_sum = 0;
+    for (int k = 0; k < n_seg; ++k) n_sum += seg_n[k];
+    SegBlocks sb;
+    memset(&sb, 0, sizeof(sb));
+    unsigned total = 0;
+    for (int k = 0; k < n_seg; ++k) {                            // <= cap workgroups in all, none with less than one turn of 256 elements if avoidable
+        const int64_t want = us_cdiv(seg_n[k] / vec, 256), share = n_sum > 0 ? (int64_t)((double)cap * (double)seg_n[k] / (double)n_sum) : 1;
+        int64_t nb = want < share ? want : share;
+        if (nb < 1) nb = 1;
+        sb.n[k] = (unsigned)nb; total += (unsigned)nb;
+    }
+    if (vec4)
+        hipLaunchKernelGGL(k_adam_segs_model<4>, dim3(2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg);
+    else
+        hipLaunchKernelGGL(k_adam_segs_model<1>, dim3(2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg);
+    US_CHECK_LAUNCH("us_adam_step_model");
     return US_OK;
 }
 

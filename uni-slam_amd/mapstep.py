@@ -69,6 +69,7 @@ class MapStep:
         self._dec_grad_clean = False
         self._step_advanced = False
         self._scan_pending = self._side_pending = False          # work queued on the scan / side stream since its last join
+        self.one_launch_adam = True                               # single process: decoder group + tables in ONE optimiser launch (us_adam_step_model)
         self.adam_in_parts = True                                # data-parallel: the colour table's optimiser pass ahead of the rest (dist.dp_iterate)
         self._grad_bf16_from = None                              # dist.GradComm (bf16 payload): first flat index whose gradient lives in self._grad_bf16
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
@@ -710,15 +711,24 @@ class MapStep:
                 self._step_advanced = True
             off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
             hb = self.has_beta
-            L.check(lib.us_mlp_reduce_pair_adam(
-                ctypes.byref(self.desc_s), ctypes.byref(self.desc_c), P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, self.n_rays * self.S,
-                off(self.flat, self.o_dec_s), off(self.flat, self.o_dec_c), off(self.grad, self.o_dec_s), off(self.grad, self.o_dec_c),
-                off(self.m, self.o_dec_s), off(self.m, self.o_dec_c), off(self.v, self.o_dec_s), off(self.v, self.o_dec_c),
-                P(self.beta_part) if hb else None, self.n_rays, off(self.flat, self.o_beta) if hb else None, off(self.grad, self.o_beta) if hb else None,
-                off(self.m, self.o_beta) if hb else None, off(self.v, self.o_beta) if hb else None, self.lr["decoders"] * f, 0.9, 0.999, 1e-8,
-                P(self.step_dev), st), "us_mlp_reduce_pair_adam")
-            segs, zero_mask = list(groups)[1:], 0
+            dec_args = (ctypes.byref(self.desc_s), ctypes.byref(self.desc_c), P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, self.n_rays * self.S,
+                        off(self.flat, self.o_dec_s), off(self.flat, self.o_dec_c), off(self.grad, self.o_dec_s), off(self.grad, self.o_dec_c),
+                        off(self.m, self.o_dec_s), off(self.m, self.o_dec_c), off(self.v, self.o_dec_s), off(self.v, self.o_dec_c),
+                        P(self.beta_part) if hb else None, self.n_rays, off(self.flat, self.o_beta) if hb else None,
+                        off(self.grad, self.o_beta) if hb else None, off(self.m, self.o_beta) if hb else None, off(self.v, self.o_beta) if hb else None,
+                        self.lr["decoders"] * f)
             self._dec_grad_clean = False
+            if self.one_launch_adam:
+                # the whole optimiser step in ONE launch: the decoder group's reductions + Adam ride as three slices of the tables' launch
+                tabs = list(groups)[1:]
+                I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
+                L.check(lib.us_adam_step_model(*dec_args, P(self.flat), P(self.grad), P(self.m), P(self.v), 2, I64(*[g[0] for g in tabs]),
+                                               I64(*[g[1] for g in tabs]), DBL(*[g[2] for g in tabs]), 0.9, 0.999, 1e-8, P(self.step_dev),
+                                               L.US_ADAM_STEP_ADVANCED, st), "us_adam_step_model")
+                self._step_advanced = False
+                return
+            L.check(lib.us_mlp_reduce_pair_adam(*dec_args, 0.9, 0.999, 1e-8, P(self.step_dev), st), "us_mlp_reduce_pair_adam")
+            segs, zero_mask = list(groups)[1:], 0
         elif ranges is None and part == "colour":
             segs, zero_mask = [groups[2]], 0
         elif ranges is None and part == "rest":
