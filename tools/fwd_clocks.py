@@ -35,6 +35,11 @@ for l in range(16):
     print(f"  level {l:2d}: starts {s[l].min():6.1f} .. {s[l].max():6.1f}   ends {e[l].min():6.1f} .. {e[l].max():6.1f}   workgroup: median {np.median(e[l] - s[l]):5.1f} us, "
           f"features out after {np.median(f[l] - s[l]):5.1f}, counting {np.median(e[l] - f[l]):4.1f}")
 dur = e - s
+xcc = (d[..., 3] >> 32) & 0xF
+print("levels by XCC id of their workgroups:", " ".join(f"{l}:{sorted(set(xcc[l].tolist()))}" for l in range(16)))
+for x in sorted(set(xcc.ravel().tolist())):
+    m = xcc == x
+    print(f"  XCC {x}: workgroups {int(m.sum())}, last end {e[m].max():.1f} us")
 print(f"workgroup time: median {np.median(dur):.1f} us; sum / 512 resident = {dur.sum() / 512:.1f} us")
 # how many workgroups run at a time
 ev = sorted([(x, 1) for x in s.ravel()] + [(x, -1) for x in e.ravel()])

@@ -28,6 +28,16 @@
 #ifndef J_FWD_THREADS
 #define J_FWD_THREADS 1024               // encoder workgroup: 1024 points x one level (two count rows)
 #endif
+#ifndef J_PLAN_SLOPE
+#define J_PLAN_SLOPE 0.29                 // make_jplan: estimated work of a workgroup of level l = 1 + slope * max(0, l - 3)
+#endif
+#ifndef J_FWD_FINE_FIRST
+#define J_FWD_FINE_FIRST 0               // two-dimensional launch with blockIdx.y = 0 the FINEST level: render-only call 168 -> 159 us, but the dy/dx
+                                         // encoder +4 us and BASELINE configs[2] +3 %: off (the XCD plan below has the order built in)
+#endif
+#ifndef J_FWD_XCD
+#define J_FWD_XCD 1                     // the counting encoder's workgroups placed by XCD (make_jplan); 0: blockIdx.y = level
+#endif
 #ifndef J_FWD_WAVES_PER_EU
 #define J_FWD_WAVES_PER_EU 4               // register budget of the encoder: 4 waves per SIMD = ONE 1024-thread workgroup per CU (it takes 70 registers);
                                          // 8 = two per CU (64 registers, no spill in the counting form): encoder 132 -> 140 us, same box (r4) -- the
@@ -158,8 +168,74 @@ static int make_jlevels(const us_grid_desc* a, const us_grid_desc* b, int64_t n,
 // DYDX: also leave d(features)/d(position) of both grids, planes [L][3][N][2] (= tcnn's dy_dx, which the input gradient
 // contracts with dL/dy: us_hashgrid_dydx_rays) -- the 8 vertices are in registers here, and 24 contiguous bytes per thread and grid
 // stream out coalesced, where a second gather pass over the tables (us_hashgrid_bwd_input_rays) costs as much as the encoder itself.
+#define J_PLAN_SEGS 6
+struct JPlan { uint32_t n; uint16_t level[8][J_PLAN_SEGS], first[8][J_PLAN_SEGS], count[8][J_PLAN_SEGS]; };
+// host: who takes which (level, block) units.  Units in the order finest level first; XCD x takes a run from the front (heavy) and a run
+// from the back (light) of what is left, 1/8 of the units in all, the split chosen so that its estimated work is 1/8 of the total.
+// Work per unit of level l: 1 on the first four levels, + 0.29 per level beyond (the encoder's workgroup clocks: 4.4 us on levels 0-3,
+// 19.5 us on level 15 -- the finer the level, the fewer lines the lanes of a wave share).
+// the placement pays where a level's slab is a large part of an L2 (4 MiB): a table of 2^18 entries and more
+static bool j_big_slab(const us_grid_desc* a, const us_grid_desc* b) {
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < a->n_levels; ++l) { const uint32_t ha = a->offset[l + 1] - a->offset[l], hb = b->offset[l + 1] - b->offset[l]; m = ha > m ? ha : m; m = hb > m ? hb : m; }
+    return m >= (1u << 18);
+}
+static bool make_jplan_uncached(uint32_t n_levels, uint32_t nb, double slope, JPlan* out);
+static bool make_jplan(uint32_t n_levels, uint32_t nb, double slope, JPlan* out) {      // (the last plans are kept: an iteration asks for the same ones every time)
+    struct Slot { uint32_t levels = 0, nb = 0; double slope = 0.0; bool ok = false; JPlan plan; };
+    static thread_local Slot slots[4];
+    static thread_local int next = 0;
+    for (const Slot& c : slots) if (c.levels == n_levels && c.nb == nb && c.slope == slope) { *out = c.plan; return c.ok; }
+    Slot& c = slots[next]; next = (next + 1) & 3;
+    c.ok = make_jplan_uncached(n_levels, nb, slope, &c.plan); c.levels = n_levels; c.nb = nb; c.slope = slope;
+    *out = c.plan;
+    return c.ok;
+}
+static bool make_jplan_uncached(uint32_t n_levels, uint32_t nb, double slope, JPlan* out) {
+    memset(out, 0, sizeof(*out));
+    if (n_levels < 8u || nb == 0u || nb > 65535u) return false;
+    const uint32_t total = n_levels * nb, per = (total + 7u) / 8u;
+    auto w = [&](uint32_t l) { return 1.0 + slope * (l > 3u ? (double)(l - 3u) : 0.0); };
+    double wsum = 0.0;
+    for (uint32_t l = 0; l < n_levels; ++l) wsum += w(l) * nb;
+    // front: unit index f counts from the finest level's block 0; back: from level 0's block 0 upwards
+    uint32_t fl = n_levels - 1u, fo = 0u, bl = 0u, bo = 0u, left = total;      // (level, offset) of the next front / back unit; units left
+    for (uint32_t x = 0; x < 8u; ++x) {
+        const uint32_t cnt = left < per ? left : per;
+        const double target = wsum / 8.0;
+        // take nf units from the front so that the estimate comes closest to the target
+        uint32_t best_nf = 0; double best_err = 1e300;
+        for (uint32_t nf = 0; nf <= cnt; ++nf) {
+            double acc = 0.0; uint32_t l = fl, o = fo, k = nf;
+            while (k) { const uint32_t t = (nb - o) < k ? (nb - o) : k; acc += t * w(l); k -= t; o += t; if (o == nb) { o = 0; if (l == 0u) break; --l; } }
+            l = bl; o = bo; k = cnt - nf;
+            while (k) { const uint32_t t = (nb - o) < k ? (nb - o) : k; acc += t * w(l); k -= t; o += t; if (o == nb) { o = 0; ++l; } }
+            const double err = acc > target ? acc - target : target - acc;
+            if (err < best_err) { best_err = err; best_nf = nf; }
+        }
+        int q = 0;
+        uint32_t k = best_nf;
+        while (k) {
+            const uint32_t t = (nb - fo) < k ? (nb - fo) : k;
+            if (q >= J_PLAN_SEGS) return false;
+            out->level[x][q] = (uint16_t)fl; out->first[x][q] = (uint16_t)fo; out->count[x][q] = (uint16_t)t; ++q;
+            k -= t; fo += t; if (fo == nb) { fo = 0; if (fl > 0u) --fl; }
+        }
+        k = cnt - best_nf;
+        while (k) {
+            const uint32_t t = (nb - bo) < k ? (nb - bo) : k;
+            if (q >= J_PLAN_SEGS) return false;
+            out->level[x][q] = (uint16_t)bl; out->first[x][q] = (uint16_t)(nb - bo - t); out->count[x][q] = (uint16_t)t; ++q;     // (from the level's end: where
+                                                                                                                      //  the two runs meet in one level they do not overlap)
+            k -= t; bo += t; if (bo == nb) { bo = 0; ++bl; }
+        }
+        left -= cnt;
+    }
+    out->n = per;                                                // workgroups per XCD: the launch has 8 * per
+    return true;
+}
 template <bool GATHER, bool COUNT, bool DYDX = false>
-__global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void k_jfwd(JLevels lv, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
+__global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void k_jfwd(JLevels lv, JPlan plan, uint32_t n_levels, const float* __restrict__ pA, const float* __restrict__ pB,
                                                         const float* __restrict__ x, int64_t n, float* __restrict__ outA, float* __restrict__ outB,
                                                         int clamp, int lm, uint32_t* __restrict__ counts, uint32_t row_stride, uint32_t n_rows,
                                                         us_half_t* __restrict__ dydxA = nullptr, us_half_t* __restrict__ dydxB = nullptr
@@ -174,7 +250,24 @@ __global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void 
     constexpr int HALVES = J_FWD_THREADS / J_ROW_POINTS;
     __shared__ uint32_t lcnt[HALVES][J_LVL_BINS];
     __shared__ uint32_t done;
-    const uint32_t level = blockIdx.y;
+    // XCD-AWARE PLACEMENT (plan.n != 0: a one-dimensional launch).  Workgroup i runs on XCD i & 7 (round-robin placement; checked with
+    // HW_REG_XCC_ID in the timing build), and an XCD's workgroups take the plan's segments (level, first block, blocks) in order: the finest
+    // levels whole, the coarse ones cut where the estimated work of the eight XCDs evens out -- a level's slab is then pulled into ONE L2
+    // (two for a cut level) instead of all eight.
+    uint32_t level = J_FWD_FINE_FIRST ? n_levels - 1u - blockIdx.y : blockIdx.y, bx_ = blockIdx.x;
+    if (plan.n != 0u) {
+        const uint32_t xcd = blockIdx.x & 7u;
+        uint32_t j = blockIdx.x >> 3;
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < J_PLAN_SEGS; ++q) {
+            const uint32_t c = plan.count[xcd][q];
+            if (!found && j < c) { found = true; level = plan.level[xcd][q]; bx_ = plan.first[xcd][q] + j; }
+            else if (!found) j -= c;
+        }
+        if (!found) return;                                      // (padding of the launch to a multiple of eight)
+    }
+#define J_BX bx_
     const JLevel q = lv.l[level];
     const uint32_t nlb = j_level_bins(q);
     if (COUNT) {
@@ -183,7 +276,7 @@ __global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void 
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, lg16 = lane & (RUN_GROUP - 1);
-    const int64_t i = (int64_t)blockIdx.x * (COUNT ? J_FWD_THREADS : (int)blockDim.x) + threadIdx.x;   // (the counting side needs its 1024-point rows)
+    const int64_t i = (int64_t)J_BX * (COUNT ? J_FWD_THREADS : (int)blockDim.x) + threadIdx.x;   // (the counting side needs its 1024-point rows)
     const bool in = i < n;
     float pos[3]; uint32_t cell[3];
 #pragma unroll
@@ -270,14 +363,14 @@ __global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void 
     if (ticket == J_FWD_THREADS / 64 - 1) {
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
-            const uint32_t r = HALVES * blockIdx.x + h;
+            const uint32_t r = HALVES * J_BX + h;
             if (r >= n_rows) break;
             uint32_t* row = counts + (size_t)r * row_stride + q.first;
             for (uint32_t t = (uint32_t)lane; t < nlb; t += 64) row[t] = lcnt[h][t];
         }
 #ifdef J_FWD_TIMING
         if (dbg && lane == 0) {
-            unsigned long long* d = dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            unsigned long long* d = dbg + 4 * ((size_t)level * n_rows / HALVES + J_BX);
             d[0] = dbg_t0; d[1] = dbg_t1; d[2] = wall_clock64();
             unsigned int xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1003,8 +1096,13 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
         US_REQUIRE(workspace_bytes >= us_hashgrid_joint_workspace_bytes(a, b, n), US_ERR_WORKSPACE,
                    "%s: workspace %zu B < %zu B", fn, workspace_bytes, us_hashgrid_joint_workspace_bytes(a, b, n));
         const JWorkspace w = j_carve(workspace, a->n_levels, TB, n);
-        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, true, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
-        else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB
+        JPlan plan;
+        memset(&plan, 0, sizeof(plan));
+#if J_FWD_XCD
+        if (!dydxA && j_big_slab(a, b) && make_jplan(a->n_levels, grid.x, J_PLAN_SLOPE, &plan)) grid = dim3(8u * plan.n, 1u);
+#endif
+        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, true, true>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB);
+        else hipLaunchKernelGGL((k_jfwd<true, true, false>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, w.counts, w.stride, w.n_rows, dydxA, dydxB
 #ifdef J_FWD_TIMING
                                 , (unsigned long long*)((char*)workspace + ((us_hashgrid_joint_workspace_bytes(a, b, n) & ~(size_t)7) - (size_t)393216))
 #endif
@@ -1014,8 +1112,13 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
         // 256 CUs: 256-thread workgroups there
         const int threads = n >= J_SMALL_BATCH ? J_FWD_THREADS : 256;
         grid = dim3((unsigned)us_cdiv(n, threads), a->n_levels); block = dim3(threads);
-        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, false, true>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
-        else hipLaunchKernelGGL((k_jfwd<true, false, false>), grid, block, 0, s, lv, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
+        JPlan plan;
+        memset(&plan, 0, sizeof(plan));
+#if J_FWD_XCD
+        if (!dydxA && j_big_slab(a, b) && make_jplan(a->n_levels, grid.x, J_PLAN_SLOPE, &plan)) grid = dim3(8u * plan.n, 1u);
+#endif
+        if (dydxA) hipLaunchKernelGGL((k_jfwd<true, false, true>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
+        else hipLaunchKernelGGL((k_jfwd<true, false, false>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
     }
     US_CHECK_LAUNCH(fn);
     return US_OK;
@@ -1144,7 +1247,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     uint32_t SA = 0, SB = 0;                                     // bins with a side in grid A / B (a joint bin: both)
     for (uint32_t l = 0; l < L; ++l) { SA += (lv.l[l].flags & J_SPLIT) ? 1u << lv.l[l].lgA : 1u << lv.l[l].lgB; SB += 1u << lv.l[l].lgB; }
     if (!counted)
-        hipLaunchKernelGGL((k_jfwd<false, true, false>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, L, (const float*)nullptr,
+        hipLaunchKernelGGL((k_jfwd<false, true, false>), dim3((unsigned)us_cdiv(n, J_FWD_THREADS), L), dim3(J_FWD_THREADS), 0, s, lv, JPlan{}, L, (const float*)nullptr,
                            (const float*)nullptr, x, n, (float*)nullptr, (float*)nullptr, clamp, 1, w.counts, w.stride, w.n_rows);
     if (!scanned) {
         hipLaunchKernelGGL(k_jcolscan, dim3((unsigned)us_cdiv(TB, JCS_BINS)), dim3(JCS_THREADS), 0, s, lv, L, w.counts, w.prefix, w.n_rows, w.stride,
