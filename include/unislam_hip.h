@@ -289,16 +289,28 @@ int us_mlp_reduce_pair_adam(const us_mlp_desc* da, const us_mlp_desc* db, const 
                             float* m_a, float* m_b, float* v_a, float* v_b, const float* beta_partials, int64_t n_rays, float* beta,
                             float* grad_beta, float* m_beta, float* v_beta, double lr, double beta1, double beta2, double eps,
                             const float* step_dev, void* stream);
+/* A joint_opt window's pose group for us_adam_step_model: the arguments of us_pose_window_step (row_a .. n_b: the rows of the optimised
+ * frames) or, shape_dev != NULL, of us_arena_pose_step (the window's shape on the device; n_poses = the arena's pose capacity). */
+typedef struct us_pose_step_desc {
+    float* poses7; int n_poses;
+    const float *g_rays_o, *g_rays_d, *dirs;
+    int64_t row_a, n_a; int first_pose_b; int64_t row_b, n_b;
+    float *m7, *v7, *g7_out;
+    double lr_q, lr_t;
+    const int32_t* shape_dev; int64_t rows_a;
+} us_pose_step_desc;
 /* us_mlp_reduce_pair_adam and us_adam_step_segments_dev in ONE launch: the whole optimiser step of a model (src/Mapper.py:111-139,443-445: one
- * torch.optim.Adam over the decoder group and the two tables) -- the decoder group's reductions + Adam are three extra slices of the tables'
- * launch instead of a launch of their own in front of it.  Arguments: those of us_mlp_reduce_pair_adam (lr_decoders: its lr), then those of
- * us_adam_step_segments_dev for the table segments.  Same arithmetic, same bits as the two calls. */
+ * torch.optim.Adam over the decoder group and the two tables) -- the decoder group's reductions + Adam are the first workgroups of the tables'
+ * launch instead of a launch of their own in front of it; with poses != NULL the camera poses' group of a joint_opt window (Mapper.py:359-364)
+ * as well: the work of us_pose_window_step / us_arena_pose_step, one workgroup per frame, ahead of both.  Arguments: those of
+ * us_mlp_reduce_pair_adam (lr_decoders: its lr), then those of us_adam_step_segments_dev for the table segments.  Same arithmetic, same bits
+ * as the separate calls. */
 int us_adam_step_model(const us_mlp_desc* da, const us_mlp_desc* db, const void* workspace_a, const void* workspace_b, size_t workspace_bytes,
                        int64_t n, float* params_a, float* params_b, float* grad_params_a, float* grad_params_b, float* m_a, float* m_b,
                        float* v_a, float* v_b, const float* beta_partials, int64_t n_rays, float* beta, float* grad_beta, float* m_beta,
                        float* v_beta, double lr_decoders, float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off,
                        const int64_t* seg_n, const double* seg_lr, double beta1, double beta2, double eps, float* step_dev,
-                       unsigned zero_grad_mask, void* stream);
+                       unsigned zero_grad_mask, const us_pose_step_desc* poses, void* stream);
 int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,
                     const float* in_b, int64_t n, float* out_a, int64_t out_stride_a, float* out_b, int64_t out_stride_b, int flags, void* stream);
 int us_mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const float* params_a, const float* params_b, const float* in_a,

@@ -55,6 +55,15 @@ class MlpDesc(ctypes.Structure):
 
 _GP = ctypes.POINTER(GridDesc)
 _MP = ctypes.POINTER(MlpDesc)
+
+class PoseStepDesc(ctypes.Structure):
+    """include/unislam_hip.h: us_pose_step_desc -- a joint_opt window's pose group riding in us_adam_step_model's launch"""
+    _fields_ = [("poses7", ctypes.c_void_p), ("n_poses", ctypes.c_int), ("g_rays_o", ctypes.c_void_p), ("g_rays_d", ctypes.c_void_p),
+                ("dirs", ctypes.c_void_p), ("row_a", ctypes.c_int64), ("n_a", ctypes.c_int64), ("first_pose_b", ctypes.c_int),
+                ("row_b", ctypes.c_int64), ("n_b", ctypes.c_int64), ("m7", ctypes.c_void_p), ("v7", ctypes.c_void_p), ("g7_out", ctypes.c_void_p),
+                ("lr_q", ctypes.c_double), ("lr_t", ctypes.c_double), ("shape_dev", ctypes.c_void_p), ("rows_a", ctypes.c_int64)]
+
+
 _HF = ctypes.POINTER(c_flt)     # host float array
 
 # name -> (restype, argtypes): exactly the declarations of include/unislam_hip.h
@@ -90,7 +99,7 @@ SIGNATURES = {
                                         c_dbl, c_dbl, c_dbl, c_dbl, c_f, c_f]),
     "us_adam_step_model": (c_int, [_MP, _MP, c_f, c_f, ctypes.c_size_t, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f,
                                    c_dbl, c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl),
-                                   c_dbl, c_dbl, c_dbl, c_f, ctypes.c_uint, c_f]),
+                                   c_dbl, c_dbl, c_dbl, c_f, ctypes.c_uint, ctypes.POINTER(PoseStepDesc), c_f]),
     "us_mlp_fwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
     "us_mlp_bwd_pair": (c_int, [_MP, _MP, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_int,
                                 c_f, c_f, ctypes.c_size_t, c_f]),

@@ -22,6 +22,7 @@ struct DecGroup {
     const float* beta_part; long long n_rays; float *p_beta, *g_beta, *m_beta, *v_beta;
     DecAdam ad;
 };
-// the tables' optimiser launch with the decoder group riding along (render.hip); dg.pa == nullptr: tables only
+// the tables' optimiser launch with the decoder group (and, poses != NULL, a joint_opt window's pose group) riding along (render.hip)
 int us_adam_segments_model(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n, const double* seg_lr,
-                           double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask, void* stream, const DecGroup& dg);
+                           double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask, void* stream, const DecGroup& dg,
+                           const us_pose_step_desc* poses);

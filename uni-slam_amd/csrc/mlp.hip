@@ -901,7 +901,7 @@ extern "C" int us_adam_step_model(const us_mlp_desc* da, const us_mlp_desc* db, 
                                   int64_t n_rays, float* beta, float* grad_beta, float* m_beta, float* v_beta, double lr_decoders,
                                   float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n,
                                   const double* seg_lr, double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask,
-                                  void* stream) {
+                                  const us_pose_step_desc* poses, void* stream) {
     US_REQUIRE(mlp_pair_ok(da, db), US_ERR_CONFIG, "us_adam_step_model: needs two bf16 decoders (32 inputs) of equal width, depth and precision");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(workspace_a && workspace_b && params_a && params_b && grad_params_a && grad_params_b && m_a && m_b && v_a && v_b && step_dev, US_ERR_NULL,
@@ -917,7 +917,7 @@ extern "C" int us_adam_step_model(const us_mlp_desc* da, const us_mlp_desc* db, 
     dg.beta_part = beta_partials; dg.n_rays = n_rays; dg.p_beta = beta; dg.g_beta = grad_beta; dg.m_beta = m_beta; dg.v_beta = v_beta;
     dg.ad.lr = (float)lr_decoders; dg.ad.one_minus_b1 = (float)(1.0 - beta1); dg.ad.b2 = (float)beta2; dg.ad.one_minus_b2 = (float)(1.0 - beta2);
     dg.ad.eps = (float)eps; dg.ad.step_dev = step_dev;
-    return us_adam_segments_model(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, step_dev, zero_grad_mask, stream, dg);
+    return us_adam_segments_model(p, g, m, v, n_seg, seg_off, seg_n, seg_lr, beta1, beta2, eps, step_dev, zero_grad_mask, stream, dg, poses);
 }
 
 #include <string.h>

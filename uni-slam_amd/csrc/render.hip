@@ -8,6 +8,7 @@
 // and z_vals is required to match it bit for bit.
 #include "us_common.h"
 #include "dec_adam_dev.h"
+#include "pose_step_dev.h"
 #include <math.h>
 #include <string.h>
 
@@ -1017,25 +1018,35 @@ __global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ p, float*
                                                    unsigned g16_mask = 0u) {
     adam_segs_body<VEC>(p, g, m, v, sg, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, zero_mask, step_dev, g16, g16_mask, blockIdx.x, blockIdx.y, gridDim.x);
 }
-// ... with the decoder param group riding along (us_adam_step_model).  A one-dimensional launch: the FIRST workgroups are the decoder
+// ... with the decoder param group (and the pose group of a joint_opt window) riding along (us_adam_step_model).  A one-dimensional launch:
+// the FIRST workgroups are the poses' (one per optimised frame: k_pose_window_step's work), then the decoder
 // group's -- gd per decoder (fixed-order sums of their partial rows, then Adam), one for beta (f64 sum of the per-ray partials) -- so they
 // are placed first and finish under the tables' stream; the rest are the table segments', each with workgroups in proportion to its size.  (As trailing slices of a
 // two-dimensional grid they were placed last, behind 3 x gt workgroups that had nothing to do: 5-10 us SLOWER than two launches.)
 // 256 threads walk through what k_mlp_reduce_pair_adam's 1024 do, in the same order: the results are the same bits.
 struct SegBlocks { unsigned n[ADAM_MAX_SEG]; };
+// the pose group of a joint_opt window riding along (us_adam_step_model with a us_pose_step_desc): n workgroups, the arguments of k_pose_window_step
+struct PoseGroup { unsigned n; float* poses7; const float *g_o, *g_d, *dirs; float *m7, *v7, *g7_out, *step_dev; PoseStep ps; const int32_t* shape_dev; int64_t rows_a; };
 template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_segs_model(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                          AdamSegs sg, unsigned gd, SegBlocks sb, float one_minus_b1, float b2, float one_minus_b2,
-                                                         float bc2_sqrt, float eps, unsigned zero_mask, const float* __restrict__ step_dev, DecGroup dg) {
+                                                         float bc2_sqrt, float eps, unsigned zero_mask, const float* __restrict__ step_dev, DecGroup dg,
+                                                         PoseGroup pg) {
+    if (blockIdx.x < pg.n) {                                     // the joint_opt window's poses: one workgroup per optimised frame, first of all
+        pose_window_step_body<256>((int)blockIdx.x, pg.poses7, pg.g_o, pg.g_d, pg.dirs, pg.m7, pg.v7, pg.g7_out, pg.step_dev, pg.ps, nullptr, nullptr,
+                                   nullptr, nullptr, pg.shape_dev, pg.rows_a);
+        return;
+    }
+    const unsigned bid = blockIdx.x - pg.n;
     const unsigned nd = 2u * gd + 1u;
-    if (blockIdx.x >= nd) {                                      // a table segment's workgroup: segment k has blocks[k] of them (in proportion to its size)
-        unsigned t = blockIdx.x - nd, k = 0;
+    if (bid >= nd) {                                             // a table segment's workgroup: segment k has blocks[k] of them (in proportion to its size)
+        unsigned t = bid - nd, k = 0;
         while (k + 1u < (unsigned)ADAM_MAX_SEG && t >= sb.n[k]) { t -= sb.n[k]; ++k; }
         adam_segs_body<VEC>(p, g, m, v, sg, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, zero_mask, step_dev, nullptr, 0u, t, k, sb.n[k]);
         return;
     }
-    const int which = blockIdx.x == nd - 1u ? 2 : (int)(blockIdx.x / gd);
-    const unsigned bx = blockIdx.x % gd;
+    const int which = bid == nd - 1u ? 2 : (int)(bid / gd);
+    const unsigned bx = bid % gd;
     if (which == 2) {                                            // beta: one workgroup
         if (!dg.beta_part) return;
         __shared__ double shd[1024];
@@ -1809,8 +1820,23 @@ static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, cons
 }
 
 int us_adam_segments_model(float* p, float* g, float* m, float* v, int n_seg, const int64_t* seg_off, const int64_t* seg_n, const double* seg_lr,
-                           double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask, void* stream, const DecGroup& dg) {
+                           double beta1, double beta2, double eps, float* step_dev, unsigned zero_grad_mask, void* stream, const DecGroup& dg,
+                           const us_pose_step_desc* poses) {
     US_REQUIRE(p && g && m && v && seg_off && seg_n && seg_lr && step_dev, US_ERR_NULL, "us_adam_step_model: NULL pointer");
+    PoseGroup pg;
+    memset(&pg, 0, sizeof(pg));
+    if (poses) {
+        US_REQUIRE(poses->poses7 && poses->g_rays_o && poses->g_rays_d && poses->dirs && poses->m7 && poses->v7, US_ERR_NULL, "us_adam_step_model: pose step: NULL pointer");
+        US_REQUIRE(poses->n_poses >= 1 && poses->n_poses <= 4096, US_ERR_SHAPE, "us_adam_step_model: pose step: n_poses %d", poses->n_poses);
+        US_REQUIRE(poses->shape_dev || (poses->n_a >= 0 && poses->n_b >= 0 && poses->row_a >= 0 && poses->row_b >= 0 && poses->first_pose_b >= 0), US_ERR_SHAPE,
+                   "us_adam_step_model: pose step: bad shape");
+        pg.n = (unsigned)poses->n_poses; pg.poses7 = poses->poses7; pg.g_o = poses->g_rays_o; pg.g_d = poses->g_rays_d; pg.dirs = poses->dirs;
+        pg.m7 = poses->m7; pg.v7 = poses->v7; pg.g7_out = poses->g7_out; pg.step_dev = step_dev;
+        pg.ps.nA = poses->n_a; pg.ps.rowA = poses->row_a; pg.ps.nB = poses->n_b; pg.ps.rowB = poses->row_b; pg.ps.jB = poses->first_pose_b;
+        pg.ps.lr_q = (float)poses->lr_q; pg.ps.lr_t = (float)poses->lr_t; pg.ps.b1 = (float)beta1; pg.ps.b2 = (float)beta2; pg.ps.eps = (float)eps;
+        pg.ps.own_step = 0; pg.ps.apply = 1;
+        pg.shape_dev = poses->shape_dev; pg.rows_a = poses->rows_a;
+    }
     US_REQUIRE(n_seg >= 1 && n_seg <= ADAM_MAX_SEG, US_ERR_SHAPE, "us_adam_step_model: n_seg %d not in 1..%d", n_seg, ADAM_MAX_SEG);
     AdamSegs sg;
     memset(&sg, 0, sizeof(sg));
@@ -1841,11 +1867,11 @@ int us_adam_segments_model(float* p, float* g, float* m, float* v, int n_seg, co
         sb.n[k] = (unsigned)nb; total += (unsigned)nb;
     }
     if (vec4)
-        hipLaunchKernelGGL(k_adam_segs_model<4>, dim3(2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg);
+        hipLaunchKernelGGL(k_adam_segs_model<4>, dim3(pg.n + 2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg, pg);
     else
-        hipLaunchKernelGGL(k_adam_segs_model<1>, dim3(2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg);
+        hipLaunchKernelGGL(k_adam_segs_model<1>, dim3(pg.n + 2u * gd + 1u + total), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sg, gd, sb,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.0f, (float)eps, zero_grad_mask, (const float*)step_dev, dg, pg);
     US_CHECK_LAUNCH("us_adam_step_model");
     return US_OK;
 }

@@ -689,7 +689,7 @@ class MapStep:
         R = self.n_rays
         return self.g_o[:R], self.g_d[:R]
 
-    def adam_step(self, ranges=None, part=None):
+    def adam_step(self, ranges=None, part=None, poses=None):
         """
         torch.optim.Adam over the three param groups (Mapper.py:118-126) in one launch.  ranges: None (everything) or a list of
         (lo, hi) index ranges of the flat buffer -- the shards this rank owns when the optimiser state is sharded over ranks.
@@ -724,7 +724,7 @@ class MapStep:
                 I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
                 L.check(lib.us_adam_step_model(*dec_args, P(self.flat), P(self.grad), P(self.m), P(self.v), 2, I64(*[g[0] for g in tabs]),
                                                I64(*[g[1] for g in tabs]), DBL(*[g[2] for g in tabs]), 0.9, 0.999, 1e-8, P(self.step_dev),
-                                               L.US_ADAM_STEP_ADVANCED, st), "us_adam_step_model")
+                                               L.US_ADAM_STEP_ADVANCED, ctypes.byref(poses) if poses is not None else None, st), "us_adam_step_model")
                 self._step_advanced = False
                 return
             L.check(lib.us_mlp_reduce_pair_adam(*dec_args, 0.9, 0.999, 1e-8, P(self.step_dev), st), "us_mlp_reduce_pair_adam")

@@ -139,8 +139,13 @@ class MapWindow:
         finally:
             s.store_dydx = False
         loss = s.backward(ray_grads=True, fold=True)              # (adam_step() below sums the decoder-gradient partials itself)
-        self._pose_step()
-        s.adam_step()
+        if s.one_launch_adam and getattr(s, "_folded", False):
+            # the poses' group rides in the model's optimiser launch (us_adam_step_model): one workgroup per frame ahead of the tables' pass
+            # instead of a launch of its own (us_pose_window_step / us_arena_pose_step: same arithmetic)
+            s.adam_step(poses=self._pose_desc())
+        else:
+            self._pose_step()
+            s.adam_step()
         return loss
 
     def _sample(self, tr, device_draw):
@@ -153,6 +158,16 @@ class MapWindow:
                                      s.bhost, P(s.t_uni), s.n_strat, P(s.t_surf), s.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation),
                                      ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
                                      P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
+
+    def _pose_desc(self):
+        """_pose_step()'s arguments as the descriptor us_adam_step_model takes"""
+        P, s = (lambda t: ctypes.c_void_p(t.data_ptr())), self.step
+        b, first = self.b, self.first
+        nf, ne = self.extra if self.extra else (0, 0)
+        f_b = max(b - nf, first)
+        return L.PoseStepDesc(P(self.poses), b - first, P(s.g_o), P(s.g_d), P(self.dirs), first * self.n_per, self.n_per, f_b - first,
+                              self.R_a + (f_b - (b - nf)) * ne, ne if nf else 0, P(self.pm), P(self.pv), P(self.g_pose), self.cam_lr, self.cam_lr,
+                              None, 0)
 
     def _pose_step(self):
         """gradient + Adam of the poses this window optimises (one workgroup per pose), from the ray gradients the backward pass left"""
@@ -451,6 +466,11 @@ class ArenaWindow(MapWindow):
                                            ctypes.c_float(1.2), ctypes.c_float(1.5 * s.truncation), ctypes.c_float(3 * s.truncation), tr, s._seed(0),
                                            P(s.step_dev), 1 if s.perturb else 0, P(self.ro), P(self.rd), P(self.dirs), P(self.gd), P(self.gc),
                                            P(s.valid), P(s.z), P(s.pts), st), "us_arena_window_sample")
+
+    def _pose_desc(self):
+        P, s = (lambda t: ctypes.c_void_p(t.data_ptr())), self.step
+        return L.PoseStepDesc(P(self.poses), self.cap, P(s.g_o), P(s.g_d), P(self.dirs), 0, 0, 0, 0, 0, P(self.pm), P(self.pv), P(self.g_pose),
+                              self.cam_lr, self.cam_lr, P(self.shape_dev), self.rows_a)
 
     def _pose_step(self):
         lib, st, P, s = L.lib(), L.stream(), L.ptr, self.step
