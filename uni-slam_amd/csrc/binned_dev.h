@@ -32,9 +32,6 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
     return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
 }
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
-    return __hiloint2double((int)dpp_u32<CTRL>((uint32_t)__double2hiint(v)), (int)dpp_u32<CTRL>((uint32_t)__double2loint(v)));
-}
 #define DPP_ROW_SHL1 0x101
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
