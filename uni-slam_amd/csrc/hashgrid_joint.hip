@@ -203,16 +203,19 @@ static bool make_jplan_uncached(uint32_t n_levels, uint32_t nb, double slope, JP
     for (uint32_t x = 0; x < 8u; ++x) {
         const uint32_t cnt = left < per ? left : per;
         const double target = wsum / 8.0;
-        // take nf units from the front so that the estimate comes closest to the target
-        uint32_t best_nf = 0; double best_err = 1e300;
-        for (uint32_t nf = 0; nf <= cnt; ++nf) {
+        // take nf units from the front so that the estimate comes closest to the target: the estimate grows with nf (a front unit is at
+        // least as heavy as the back unit it displaces), so the crossing is found by bisection
+        auto estimate = [&](uint32_t nf) {
             double acc = 0.0; uint32_t l = fl, o = fo, k = nf;
             while (k) { const uint32_t t = (nb - o) < k ? (nb - o) : k; acc += t * w(l); k -= t; o += t; if (o == nb) { o = 0; if (l == 0u) break; --l; } }
             l = bl; o = bo; k = cnt - nf;
             while (k) { const uint32_t t = (nb - o) < k ? (nb - o) : k; acc += t * w(l); k -= t; o += t; if (o == nb) { o = 0; ++l; } }
-            const double err = acc > target ? acc - target : target - acc;
-            if (err < best_err) { best_err = err; best_nf = nf; }
-        }
+            return acc;
+        };
+        uint32_t lo_n = 0, hi_n = cnt;                             // estimate(lo_n) <= target < estimate(hi_n), where such a crossing exists
+        while (hi_n - lo_n > 1u) { const uint32_t mid = (lo_n + hi_n) / 2u; if (estimate(mid) <= target) lo_n = mid; else hi_n = mid; }
+        const double e_lo = estimate(lo_n), e_hi = estimate(hi_n);
+        const uint32_t best_nf = ((e_lo > target ? e_lo - target : target - e_lo) <= (e_hi > target ? e_hi - target : target - e_hi)) ? lo_n : hi_n;
         int q = 0;
         uint32_t k = best_nf;
         while (k) {
@@ -1115,7 +1118,7 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
         JPlan plan;
         memset(&plan, 0, sizeof(plan));
 #if J_FWD_XCD
-        if (!dydxA && j_big_slab(a, b) && make_jplan(a->n_levels, grid.x, J_PLAN_SLOPE, &plan)) grid = dim3(8u * plan.n, 1u);
+        if (j_big_slab(a, b) && make_jplan(a->n_levels, grid.x, J_PLAN_SLOPE, &plan)) grid = dim3(8u * plan.n, 1u);   // (also with dy/dx: the tracking encoder, -2.5 us)
 #endif
         if (dydxA) hipLaunchKernelGGL((k_jfwd<true, false, true>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
         else hipLaunchKernelGGL((k_jfwd<true, false, false>), grid, block, 0, s, lv, plan, a->n_levels, paramsA, paramsB, x, n, outA, outB, clamp, lm, (uint32_t*)nullptr, 0u, 0u, dydxA, dydxB);
