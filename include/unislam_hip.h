@@ -155,6 +155,12 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
  * produce zero records), so the counts depend on x only. */
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* us_hashgrid_bwd_joint that ALSO leaves grid B's gradient as a bfloat16 image (gradB_bf16: uint16 [n_params of b], same indexing, rounded to
+ * nearest even as a tensor copy rounds): the payload of a data-parallel all-reduce comes out of the accumulate pass's sweep instead of a
+ * narrowing pass over the table (44.7 MB read + 22 MB written per step at room0's sizes).  Needs US_GRID_BWD_OVERWRITE and
+ * US_GRID_BWD_DETERMINISTIC (in the scan call too): every entry is written once, by the workgroup that owns it. */
+int us_hashgrid_bwd_joint_img(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
+                              float* gradA, float* gradB, uint16_t* gradB_bf16, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The table gradient of a RANGE of the batch: x / dL_dy* point at the range's first point, n = points in the range, plane_stride =
  * points of the whole batch (the distance between the level planes of a level-major dL_dy).  The gradient is additive over points,

@@ -861,7 +861,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
                                                             const uint32_t* __restrict__ items_tab, const uint32_t* __restrict__ hdr,
                                                             const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
                                                             float* __restrict__ gradA,
-                                                            float* __restrict__ gradB, int overwrite, int side_sel
+                                                            float* __restrict__ gradB, uint16_t* __restrict__ gradB16, int overwrite, int side_sel
 #ifdef J_ACC_TIMING
                                                             , unsigned long long* __restrict__ dbg     // timing build (tools/acc_balance.py): per workgroup
 #endif                                                                                                 // start, end (100 MHz ticks), items, records
@@ -966,6 +966,11 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
                 if (v1 != 0.0f) atomicAdd(p + 1, v1);
             } else if (overwrite) {
                 *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
+                if (side && gradB16) {                           // grid B's gradient also as a bfloat16 image (round to nearest even, as a
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));      // tensor copy rounds): the payload of a data-parallel all-reduce
+                    bf2 o; o.x = (__bf16)v0; o.y = (__bf16)v1;
+                    *reinterpret_cast<bf2*>(gradB16 + ((size_t)goff + e) * 2u) = o;
+                }
             } else if (v0 != 0.0f || v1 != 0.0f) {               // this workgroup is the only writer of its entries
                 float2 o = *reinterpret_cast<const float2*>(p);
                 o.x += v0; o.y += v1;
@@ -1012,7 +1017,10 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
         float* gl = (((zm >> 24) & 1u) ? gradB : gradA) + (size_t)zitems[JI_GOFF][z] * 2u;
         for (uint32_t loc = tid; loc < znl; loc += J_ACC_THREADS) {
             const uint32_t e = entry_of(loc, zm & 0xFFFFu, (zm >> 16) & 0xFFu);
-            if (e < zhs) *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
+            if (e < zhs) {
+                *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
+                if (((zm >> 24) & 1u) && gradB16) *reinterpret_cast<uint32_t*>(gradB16 + ((size_t)zitems[JI_GOFF][z] + e) * 2u) = 0u;
+            }
         }
     }
 #ifdef J_ACC_TIMING
@@ -1219,7 +1227,7 @@ extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, con
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
                      float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
-                     int64_t plane_stride = 0) {
+                     int64_t plane_stride = 0, uint16_t* gradB16 = nullptr) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -1277,7 +1285,7 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
                            );
     const uint32_t n_acc_items = side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA);
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, (uint32_t)ACC_EXTRA_MAX,
-                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, overwrite, side_sel
+                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, gradB16, overwrite, side_sel
 #ifdef J_ACC_TIMING
                        , (unsigned long long*)((char*)workspace + us_hashgrid_joint_workspace_bytes(a, b, n) - (size_t)J_ACCP_GROUPS * 32u)   // the last 64 KiB of the
 #endif                                                                                                                                          // record planes: never reached
@@ -1290,6 +1298,17 @@ extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* 
                                      const float* dL_dyB, int64_t n, float* gradA, float* gradB, int flags, void* workspace,
                                      size_t workspace_bytes, void* stream) {
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int us_hashgrid_bwd_joint_img(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
+                                         const float* dL_dyB, int64_t n, float* gradA, float* gradB, uint16_t* gradB_bf16, int flags,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    US_REQUIRE(gradB_bf16 && ((uintptr_t)gradB_bf16 & 3u) == 0, US_ERR_NULL, "us_hashgrid_bwd_joint_img: gradB_bf16 is NULL or not 4-byte aligned");
+    US_REQUIRE((flags & US_GRID_BWD_OVERWRITE) && (flags & US_GRID_BWD_DETERMINISTIC), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint_img: the image is written where the table is (US_GRID_BWD_OVERWRITE) by the one workgroup that owns an entry "
+               "(US_GRID_BWD_DETERMINISTIC: no bin split over several workgroups' float atomics) -- in the scan call as well");
+    US_REQUIRE(!(flags & US_GRID_BWD_ONLY_A), US_ERR_CONFIG, "us_hashgrid_bwd_joint_img: the image belongs to grid B's accumulate pass");
+    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, gradB_bf16);
 }
 
 extern "C" int us_hashgrid_joint_scan(const us_grid_desc* a, const us_grid_desc* b, int64_t n, float* gradA, float* gradB, int flags,

@@ -62,6 +62,16 @@ class GradComm:
         self.direct = self.narrow and hasattr(engine, "_grad_bf16_from")
         if hasattr(engine, "_grad_bf16_from"):
             engine._grad_bf16_from = None
+        # in_kernel: the engine's accumulate pass leaves the colour table's gradient as a bfloat16 image itself (MapStep: us_hashgrid_bwd_joint_img),
+        # so no narrowing pass runs over that segment.  The image is allocated HERE, before any launch (and any capture) takes its address.
+        self.in_kernel = False
+        if self.direct and grad_comm == "bf16_colour" and hasattr(engine, "enable_grad_image"):
+            img = getattr(engine, "_grad_bf16", None)
+            if img is None or img.shape != engine.grad.shape or img.device != engine.grad.device:
+                engine._grad_bf16 = torch.empty_like(engine.grad, dtype=torch.bfloat16)
+            self.in_kernel = bool(engine.enable_grad_image(True))
+        elif hasattr(engine, "enable_grad_image"):
+            engine.enable_grad_image(False)
 
     # -- operations (each one is also a valid `op` of SegmentedGraph.cut)
     def stats(self):
@@ -95,8 +105,10 @@ class GradComm:
             if self.direct:
                 e._grad_bf16_from = lo if e._grad_bf16_from is None else min(e._grad_bf16_from, lo)
 
+        written = self.in_kernel and lo == self.narrow_from and getattr(e, "_grad_image_written", False)      # (the colour table's segment)
+
         def op():
-            if buf is not view:
+            if buf is not view and not written:
                 buf.copy_(view)
             self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), view, buf))
         return op

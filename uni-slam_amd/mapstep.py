@@ -72,6 +72,8 @@ class MapStep:
         self.one_launch_adam = True                               # single process: decoder group + tables in ONE optimiser launch (us_adam_step_model)
         self.adam_in_parts = True                                # data-parallel: the colour table's optimiser pass ahead of the rest (dist.dp_iterate)
         self._grad_bf16_from = None                              # dist.GradComm (bf16 payload): first flat index whose gradient lives in self._grad_bf16
+        self._grad_image = False                                 # ... and the accumulate pass writes the colour table's part of it (enable_grad_image)
+        self._grad_image_written = False
         # store_dydx: the joint encoder of a forward(backward_follows=True) also leaves d(features)/d(position) (us_hashgrid_fwd_joint_dydx),
         # and backward(ray_grads=True) contracts it (us_hashgrid_dydx_rays) instead of gathering the tables a second time.  Set by
         # window.MapWindow for the iterations that optimise camera poses (src/Mapper.py:372-376); costs 2 x 24 B per point and level.
@@ -598,9 +600,18 @@ class MapStep:
             if on_ready is not None:
                 # someone waits for the segments (the data-parallel step): the record pass for both grids, then the accumulate pass per
                 # grid, colour first -- its 44.7 MB all-reduce starts while the sdf table is still being summed
-                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
-                                                                                    off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
-                                                                                    jflags | L.US_GRID_BWD_ONLY_B, P(self.ws), self.ws_bytes, st))
+                self._grad_image_written = False
+                if self._grad_image and (jflags & L.US_GRID_BWD_DETERMINISTIC):
+                    # ... and the colour table's gradient comes out of the sweep as the bfloat16 image the all-reduce carries (no narrowing pass)
+                    img = ctypes.c_void_p(self._grad_bf16.data_ptr() + 2 * self.o_tab_c)
+                    self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint_img(
+                        ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), img,
+                        jflags | L.US_GRID_BWD_ONLY_B, P(self.ws), self.ws_bytes, st))
+                    self._grad_image_written = True
+                else:
+                    self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
+                                                                                        off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                                                        jflags | L.US_GRID_BWD_ONLY_B, P(self.ws), self.ws_bytes, st))
                 on_ready(self.grad[self.o_tab_c:])
                 self._timed("hashgrid_bwd_joint_sdf", lambda: lib.us_hashgrid_bwd_joint(
                     ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
@@ -688,6 +699,16 @@ class MapStep:
         """(dL/d rays_o [R,3], dL/d rays_d [R,3]) of the last backward(ray_grads=True); rays dropped by the pre-filter get 0"""
         R = self.n_rays
         return self.g_o[:R], self.g_d[:R]
+
+    def enable_grad_image(self, on):
+        """dist.GradComm (payload "bf16_colour", this engine's optimiser reads the image itself): have the accumulate pass of the colour table
+        leave its gradient as the bfloat16 image (self._grad_bf16) as well.  That launch writes every entry exactly once: no bin is split
+        over workgroups (US_GRID_BWD_DETERMINISTIC from here on, in the scan passes too).  Returns whether the path is taken."""
+        ok = bool(on) and self.joint and self.dp_mode == "local_fast"
+        self._grad_image = ok
+        if ok:
+            self._det = L.US_GRID_BWD_DETERMINISTIC
+        return ok
 
     def adam_step(self, ranges=None, part=None, poses=None):
         """
