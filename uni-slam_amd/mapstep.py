@@ -580,21 +580,27 @@ class MapStep:
                 defer_side = defer
             # (at THIS fork the side work is recorded first: queueing the record pass ahead of the reductions, as forward() does with the
             #  decoders, made the replayed graph serialise scans and reductions on one queue in front of the record pass: 0.596 ms against 0.546)
-            if defer_side:
+            def side_reductions(st2):                            # the decoder gradients' and beta's sums (+ the step count, if still to come)
+                if clear_later:                                  # the decoder gradients' segment: first touched by the reductions below
+                    self.grad[:self.o_tab_s].zero_()
+                if self._decoder_pair():                         # (the pair launch's partial rows: reduced by its own function)
+                    L.check(lib.us_mlp_reduce_pair(ms, mc, P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s),
+                                                   off(self.grad, self.o_dec_c), st2), "us_mlp_reduce_pair")
+                else:
+                    L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
+                    L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
+                if gbeta is not None:
+                    L.check(lib.us_beta_reduce(P(self.beta_part), R, gbeta, st2), "us_beta_reduce")
+                if not self._step_advanced:
+                    L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st2), "us_adam_step_inc")
+                    self._step_advanced = True
+            # The data-parallel step (on_ready) keeps them on the MAIN stream, between the two accumulate launches: there they run under the
+            # colour segment's all-reduce, which is the long pole anyway, and the record pass follows the decoders on their queue without a
+            # fork (the side branch took the producer's queue in the captured graph and the record pass started 12 us late on the other).
+            inline_side = defer_side and on_ready is not None
+            if defer_side and not inline_side:
                 with self._branch() as st2:                      # side stream, behind both decoders: beside the table gradient
-                    if clear_later:                              # the decoder gradients' segment: first touched by the reductions below
-                        self.grad[:self.o_tab_s].zero_()
-                    if self._decoder_pair():                     # (the pair launch's partial rows: reduced by its own function)
-                        L.check(lib.us_mlp_reduce_pair(ms, mc, P(self.mlp_ws_s), P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s),
-                                                       off(self.grad, self.o_dec_c), st2), "us_mlp_reduce_pair")
-                    else:
-                        L.check(lib.us_mlp_reduce(ms, P(self.mlp_ws_s), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_s), st2), "us_mlp_reduce")
-                        L.check(lib.us_mlp_reduce(mc, P(self.mlp_ws), self.mlp_ws_bytes, N, off(self.grad, self.o_dec_c), st2), "us_mlp_reduce")
-                    if gbeta is not None:
-                        L.check(lib.us_beta_reduce(P(self.beta_part), R, gbeta, st2), "us_beta_reduce")
-                    if not self._step_advanced:
-                        L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st2), "us_adam_step_inc")
-                        self._step_advanced = True
+                    side_reductions(st2)
             self._wait_scans()
             jflags = 3 | L.US_GRID_BWD_OVERWRITE | self._det | ((L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED) if self._jcounted else 0)
             if on_ready is not None:
@@ -613,6 +619,8 @@ class MapStep:
                                                                                         off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                                                                                         jflags | L.US_GRID_BWD_ONLY_B, P(self.ws), self.ws_bytes, st))
                 on_ready(self.grad[self.o_tab_c:])
+                if inline_side:
+                    side_reductions(st)
                 self._timed("hashgrid_bwd_joint_sdf", lambda: lib.us_hashgrid_bwd_joint(
                     ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                     jflags | L.US_GRID_BWD_ONLY_A | L.US_GRID_BWD_RECORDS_READY, P(self.ws), self.ws_bytes, st))
@@ -620,7 +628,7 @@ class MapStep:
                 self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
                                                                                     P(self.ws), self.ws_bytes, st))
-            if defer_side:
+            if defer_side and not inline_side:
                 self._join()                                     # ... and the deferred reductions are in before anything reads the gradients
         elif self.overlap and not self._probing:
             with self._branch() as st2:                          # sdf branch on the side stream, colour branch beside it
