@@ -616,3 +616,53 @@ def test_pose_conversion_kernels_equal_the_torch_chains():
     p = got[:2].clone().requires_grad_(True)
     C.cam_pose_to_matrix(p).sum().backward()
     assert p.grad is not None and float(p.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("arena", [False, True])
+def test_pose_group_rides_in_the_optimiser_launch(arena):
+    """joint_opt window with the bf16 decoder pair: the camera poses' group (and the decoder group) as leading workgroups of the tables'
+    optimiser launch (us_adam_step_model + us_pose_step_desc) == the separate launches (us_pose_window_step / us_arena_pose_step,
+    us_mlp_reduce_pair_adam, us_adam_step_segments_dev): poses, their moments, decoders and beta bit for bit, tables to the rounding of their
+    f64 sums; four iterations on the same draws, with the extra rays of the newest frames"""
+    import unislam_amd as us
+    b, P, n_per, extra = 7, 400, 48, (10, 20)
+    c2ws, depths, colors, dirs = _window(b, P, 11)
+    g = torch.Generator().manual_seed(9)
+    R = b * n_per + min(extra[0], b) * extra[1]
+    draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.randint(P, (min(extra[0], b), extra[1]), generator=g).to(DEV),
+              torch.rand(R, 40, generator=g).to(DEV)) for _ in range(4)]
+    outs = []
+    for one_launch in (True, False):
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=R, deterministic=True)
+        step.one_launch_adam = one_launch
+        if arena:
+            ar = us.KeyframeArena(b + 2, P, DEV)
+            rows = []
+            for f in range(b):
+                r = ar.alloc() if f else 0
+                ar.put(r, colors[f], depths[f], dirs[f])
+                rows.append(r)
+            win = us.ArenaWindow(step, ar, b * n_per, min(extra[0], b) * extra[1], joint_opt=True, cam_lr=1e-3, has_zero_depth=False)
+            win.bind(rows, c2ws, n_per, extra)
+            it = lambda ia, ib, tr: win.iterate(ia, ib, t_rand=tr)
+        else:
+            win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, extra=extra, has_zero_depth=False)
+            it = lambda ia, ib, tr: win.iterate(ia, ib, t_rand=tr)
+        assert step._decoder_pair()
+        losses = [float(it(ia, ib, tr)) for ia, ib, tr in draws]
+        assert float(step.step_dev[0]) == 4.0
+        outs.append((losses, step.flat.clone(), step.m.clone(), step.v.clone(), win.poses.clone(), win.pm.clone(), win.pv.clone()))
+    a, c = outs
+    assert a[0] == c[0]
+    nd = step.o_tab_s
+    for k in (1, 2, 3):
+        assert torch.equal(a[k][:nd], c[k][:nd]), k
+        assert torch.allclose(a[k][nd:], c[k][nd:], rtol=1e-6, atol=1e-12), k
+    for k in (4, 5, 6):
+        assert torch.equal(a[k], c[k]), k
+    assert float(a[5].abs().max()) > 0                                          # the poses' moments did move
