@@ -442,6 +442,82 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
     return out
 
 
+def drop_in_bench(us, dev, prec, hidden, bound, mk, steps, warmup, R, n_strat, n_imp):
+    """
+    BASELINE configs[1] through the REFERENCE'S OWN CALLS ONLY (what a maintainer gets from swapping the imports) --
+    per iteration, eagerly, under torch autograd (src/Mapper.py:372-445):
+        optimizer.zero_grad(); get_samples_all(...) -> bbox pre-filter -> Renderer.render_batch_ray(scene_rep, decoders, rays_d, rays_o, ...)
+        -> mapping_loss(...) -> loss.backward() -> optimizer.step()
+    with the reference's three param groups (src/Mapper.py:111-139).  Decoders.forward is one autograd node on the joint encoder, the
+    decoder pair and the joint table gradient (decoders._DecodersFusedFn); the sampling is one launch.  Variants: the optimiser
+    (torch.optim.Adam as the reference constructs it | unislam_amd.optim.Adam: one launch per step) and the pre-filter (the reference's
+    boolean-mask compaction, a host synchronisation | a validity flag handed to the loss).
+    """
+    import types
+    out = {"workload": f"BASELINE configs[1] through reference-shaped calls only, eager: get_samples_all -> pre-filter -> Renderer.render_batch_ray -> "
+                       f"mapping_loss -> loss.backward() -> Adam([decoders, sdf table, colour table]).step(); {R} rays x {n_strat + n_imp} samples, "
+                       f"{N_KEYFRAMES} keyframe pools, 2 hidden x {hidden} decoders ({prec})"}
+    try:
+        c2ws, pd, pc, pr = keyframe_pools(N_KEYFRAMES, bound, 5000, dev)
+        n_per = R // N_KEYFRAMES
+        cfg = {"rendering": {"perturb": True, "n_stratified": n_strat, "n_importance": n_imp}, "scale": 1, "grid_mode": "hash_grid",
+               "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
+        rend = us.Renderer(cfg, types.SimpleNamespace(bound=bound, device=dev, H=CAM["H"], W=CAM["W"], fx=CAM["fx"], fy=CAM["fy"], cx=CAM["cx"], cy=CAM["cy"]))
+
+        def build(opt_kind):
+            torch.manual_seed(0)
+            dec = us.Decoders(cfg, c_dim=32, hidden_size=hidden, truncation=0.06, n_blocks=2).to(dev)
+            es, ec = mk(16), mk(19)
+            groups = [{"params": list(dec.parameters()), "lr": 0}, {"params": [es.params], "lr": 0}, {"params": [ec.params], "lr": 0}]
+            opt = us.optim.Adam(groups) if opt_kind == "fused" else torch.optim.Adam(groups, **({"fused": True} if opt_kind == "torch_fused_kwarg" else {}))   # src/Mapper.py:118-121
+            opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], opt.param_groups[2]["lr"] = LR["decoders"], LR["sdf_grid"], LR["color_grid"]   # :123-126
+            return dec, es, ec, opt
+
+        def iteration(dec, es, ec, opt, compact):
+            H, Wd = CAM["H"], CAM["W"]
+            opt.zero_grad()
+            ro, rd, gd, gc = us.common.get_samples_all(0, H, 0, Wd, n_per, H, Wd, CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"], c2ws, pd, pc, dev, pr)
+            inside = us.common.bbox_filter(ro, rd, gd, bound)                             # src/Mapper.py:396-402
+            valid = None
+            if compact:
+                ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]          # :403-406
+            else:
+                valid = inside
+            ret = rend.render_batch_ray(([es], [ec]), dec, rd, ro, dev, 0.06, gt_depth=gd)
+            loss = us.mapping_loss(ret, gd, gc, 0.06, W, valid=valid)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            rounds = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    loss = fn()
+                torch.cuda.synchronize()
+                rounds.append(1e3 * (time.perf_counter() - t0) / steps)
+            return sorted(rounds)[1], float(loss)
+
+        for tag, opt_kind, compact in (("torch_adam_compaction", "torch", True), ("torch_adam_valid_flag", "torch", False),
+                                       ("torch_adam_fused_kwarg_compaction", "torch_fused_kwarg", True),
+                                       ("fused_adam_compaction", "fused", True), ("fused_adam_valid_flag", "fused", False)):
+            m = build(opt_kind)
+            ms, loss = timed(lambda: iteration(*m, compact))
+            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": loss}
+            del m
+        out["ms_per_iter"] = out["torch_adam_compaction"]["ms_per_iter"]
+        out["rays_per_s"] = out["torch_adam_compaction"]["rays_per_s"]
+        out["note"] = ("headline of this block = torch_adam_compaction: the reference's lines unchanged except the imports; fused_adam_* swaps "
+                       "torch.optim.Adam for unislam_amd.optim.Adam (same constructor, one launch per step); *_valid_flag hands the pre-filter's mask "
+                       "to the loss instead of compacting four tensors (no host synchronisation)")
+    except Exception as e:                                # report, do not hide
+        out["error"] = repr(e)[:400]
+    return out
+
+
 SCANNET_BOUND = [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]]          # configs/ScanNet/scene0000.yaml:3
 SCANNET_CAM = dict(H=460, W=620, fx=577.590698, fy=578.729797, cx=308.702667, cy=232.809998)   # scannet.yaml:37-44 after crop_edge 10
 
@@ -764,6 +840,8 @@ def run_rank(args):
             rec["trained_like_tables"] = side_run(build_step(args.mlp_precision, table_std=0.1)[0])
         if world == 1 and not args.no_extras:
             rec["joint_opt"] = joint_opt_bench(us, lambda: build_step(args.mlp_precision), bound, dev, args.steps, args.warmup)
+        if world == 1 and not args.no_extras:
+            rec["drop_in_api"] = drop_in_bench(us, dev, args.mlp_precision, args.hidden, bound, mk, max(10, args.steps // 2), args.warmup, R, n_strat, n_imp)
         if world == 1 and not args.no_extras:
             rec["config3"] = config3_bench(us, dev, args.mlp_precision, max(10, args.steps // 2), args.warmup)
         if world == 1 and not args.no_tracking:

@@ -482,6 +482,13 @@ int us_masked_mean(const float* a, const uint8_t* valid, int64_t n, float* out, 
 int us_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, int step, void* stream);
 
+/* torch.optim.Adam's optimizer.step() over up to 40 SEPARATE tensors in ONE launch (each with its own parameter / gradient / moment
+ * allocations, length n[t] and learning rate lr[t]; the pointer and length arrays are HOST arrays of n_tensors entries): the param_groups of
+ * src/Mapper.py:118-126 (the decoders' nn.Linear parameters, beta, the two tables) as src/Mapper.py:445 steps them -- what
+ * unislam_amd.optim.Adam calls.  us_adam_step's arithmetic per element; step is the 1-based count shared by all tensors. */
+int us_adam_step_tensors(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                         const double* lr, double beta1, double beta2, double eps, int step, void* stream);
+
 /* the same over n_seg (<= 8) segments [seg_off[k], seg_off[k] + seg_n[k]) of one flat buffer in ONE launch, each segment with
  * its own learning rate -- the optimizer's param_groups (src/Mapper.py:118-126: decoders, sdf tables, colour tables);
  * seg_off / seg_n / seg_lr are HOST arrays.  Bit k of zero_grad_mask: clear segment k of g once it has been consumed

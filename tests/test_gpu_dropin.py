@@ -1,0 +1,228 @@
+"""
+The reference's OWN call sequence (tcnn.Encoding / Decoders.forward / Renderer.render_batch_ray under torch autograd + an Adam with the
+reference's three param groups: src/networks/decoders.py:91-105,182-205, src/utils/Renderer.py:59-152, src/Mapper.py:111-139,358-364,
+443-445) on the kernels of the straight-line mapping step: Decoders.forward as ONE autograd node (joint encoder, decoder pair, joint
+binned table gradient), one-launch sampling, and unislam_amd.optim.Adam (one launch per optimizer.step()).
+
+Held against the two-module path (encoder and decoder as separate autograd nodes: the round-1 kernels, themselves pinned by fixtures
+g4 / g7 / g9): features' effect on raw within 1e-6, table gradients within 1e-4 of the largest gradient, decoder gradients 1e-4.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import unislam_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BOUND = O.load_bound([[-1.0, 7.0], [-1.3, 3.7], [-1.7, 1.4]])
+
+
+@pytest.fixture(scope="module")
+def us():
+    import unislam_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return unislam_amd
+
+
+def enc_cfg(log2T, res=816):
+    return {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2T,
+            "base_resolution": 16, "per_level_scale": O.per_level_scale(res)}
+
+
+def _cfg(tcnn=False, prec="fp32", n_strat=32, n_imp=8, hidden=16):
+    return {"rendering": {"perturb": True, "n_stratified": n_strat, "n_importance": n_imp, "learnable_beta": True}, "scale": 1,
+            "grid_mode": "hash_grid", "grid": {"tcnn_network": tcnn}, "model": {"c_dim": 32, "truncation": 0.06, "mlp_precision": prec}}
+
+
+def _model(us, tcnn, prec, log2T=(16, 19), hidden=16, n_blocks=2, seed=0):
+    torch.manual_seed(seed)
+    dec = us.Decoders(_cfg(tcnn, prec), c_dim=32, hidden_size=hidden, truncation=0.06, n_blocks=n_blocks).to(DEV)
+    es, ec = us.HashGridEncoding(3, enc_cfg(log2T[0])).to(DEV), us.HashGridEncoding(3, enc_cfg(log2T[1])).to(DEV)
+    with torch.no_grad():
+        es.params.copy_(torch.randn_like(es.params) * 0.1); ec.params.copy_(torch.randn_like(ec.params) * 0.1)
+    return dec, es, ec
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("tcnn,prec,n,with_x", [(False, "fp32", 70001, True), (False, "bf16", 4096 * 8, False), (True, "bf16", 20000, True),
+                                                (True, "fp32", 333, False), (False, "fp32", 1, True)])
+def test_one_node_decoders_forward_equals_two_module_path(us, tcnn, prec, n, with_x):
+    """Decoders.forward through _DecodersFusedFn against the same module with fused = False (us_hashgrid_fwd / us_mlp_fwd per decoder,
+    us_hashgrid_bwd_binned per table): raw, dL/dp, both table gradients, every decoder gradient."""
+    dec, es, ec = _model(us, tcnn, prec, hidden=32 if prec == "bf16" else 16)
+    torch.manual_seed(1)
+    p = (torch.rand(n, 3, device=DEV) * 1.1 - 0.05)             # some coordinates outside [0,1]: the clamp's branch
+    probe = torch.randn(n, 4, device=DEV)
+    res = {}
+    for fused in (True, False):
+        dec.fused = fused
+        for m in (dec, es, ec):
+            m.zero_grad(set_to_none=True)
+        x = p.clone().requires_grad_(with_x)
+        raw = dec(x, ([es], [ec]))
+        assert raw.shape == (n, 4)
+        (raw * probe).sum().backward()
+        res[fused] = dict(raw=raw.detach().clone(), gx=None if not with_x else x.grad.clone(), gs=es.params.grad.clone(), gc=ec.params.grad.clone(),
+                          gd={k: v.grad.clone() for k, v in dec.named_parameters() if v.grad is not None})
+    a, b = res[True], res[False]
+    tol_raw = 1e-6 if prec == "fp32" else 1e-6            # same arithmetic per element in both paths: only the feature layout differs
+    assert _rel(a["raw"], b["raw"]) <= tol_raw
+    assert _rel(a["gs"], b["gs"]) <= 1e-4 and _rel(a["gc"], b["gc"]) <= 1e-4
+    if with_x:
+        assert _rel(a["gx"], b["gx"]) <= 1e-4
+    assert set(a["gd"]) == set(b["gd"]) and len(a["gd"]) >= (2 if tcnn else 12)
+    for k in a["gd"]:
+        assert _rel(a["gd"][k], b["gd"][k]) <= 1e-4, k
+
+
+def test_one_node_forward_without_gradients_and_reshape(us):
+    """under no_grad (render_img, the mesher) the node runs the encoder without the table gradient's bookkeeping; [R,S,3] in, [R,S,4] out"""
+    dec, es, ec = _model(us, False, "fp32")
+    p = torch.rand(37, 40, 3, device=DEV)
+    with torch.no_grad():
+        a = dec(p, ([es], [ec]))
+        dec.fused = False
+        b = dec(p, ([es], [ec]))
+    assert a.shape == (37, 40, 4) and _rel(a, b) <= 1e-6
+    assert dec._fused_ws is None                              # no scratch was made
+
+
+def test_overtaken_forward_pass_counts_again(us):
+    """two forward passes before the first backward pass: the cached binning counts belong to the second; the first must not use them"""
+    dec, es, ec = _model(us, False, "fp32")
+    torch.manual_seed(2)
+    pa, pb = torch.rand(30000, 3, device=DEV), torch.rand(50000, 3, device=DEV)
+    qa, qb = torch.randn(30000, 4, device=DEV), torch.randn(50000, 4, device=DEV)
+    ra = dec(pa, ([es], [ec])); rb = dec(pb, ([es], [ec]))
+    (ra * qa).sum().backward()                                  # overtaken by rb's forward pass
+    ga = es.params.grad.clone(), ec.params.grad.clone()
+    es.zero_grad(); ec.zero_grad()
+    (rb * qb).sum().backward()
+    gb = es.params.grad.clone(), ec.params.grad.clone()
+    dec.fused = False
+    for (p, q, g) in ((pa, qa, ga), (pb, qb, gb)):
+        for m in (dec, es, ec):
+            m.zero_grad(set_to_none=True)
+        (dec(p, ([es], [ec])) * q).sum().backward()
+        assert _rel(g[0], es.params.grad) <= 1e-4 and _rel(g[1], ec.params.grad) <= 1e-4
+
+
+def test_packed_parameters_follow_the_optimiser_state_dict_and_device_moves(us):
+    """the nn.Linear parameters become views of one packed vector: optimizer steps, load_state_dict, deepcopy and .to() keep the
+    kernel's vector and the module's parameters one thing"""
+    dec, es, ec = _model(us, False, "fp32")
+    p = torch.rand(5000, 3, device=DEV)
+    sr = ([es], [ec])
+    r0 = dec(p, sr).detach().clone()
+    base = dec.linears[0].weight.data_ptr()
+    assert dec.c_output_linear.bias.data_ptr() > base and dec._flat is not None
+    # an in-place update through the parameter (what torch.optim does) is seen by the kernels
+    with torch.no_grad():
+        dec.linears[0].weight.mul_(0.5); dec.c_output_linear.bias.add_(0.25)
+    r1 = dec(p, sr).detach().clone()
+    dec.fused = False
+    assert _rel(r1, dec(p, sr)) <= 1e-6 and _rel(r1, r0) > 1e-3
+    dec.fused = True
+    assert dec.linears[0].weight.data_ptr() == base            # no re-packing happened
+    # state_dict round trip (Tracker.py:254: self.decoders.load_state_dict(self.shared_decoders.state_dict()))
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        for q in dec.parameters():
+            q.add_(1.0)
+    dec.load_state_dict(sd)
+    assert _rel(dec(p, sr), r1) <= 1e-6
+    d2 = copy.deepcopy(dec)                                     # Tracker.py:106
+    assert _rel(d2(p, sr), r1) <= 1e-6
+    d3 = dec.cpu().to(DEV)                                      # new storage per parameter: packed again on the next call
+    assert _rel(d3(p, sr), r1) <= 1e-6
+
+
+def test_optim_adam_equals_torch_adam(us):
+    """unislam_amd.optim.Adam against torch.optim.Adam: three param groups with their own learning rates set after construction
+    (src/Mapper.py:118-126), tensors of odd lengths and unaligned views, a parameter without a gradient, five steps"""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(16, 32), (16,), (1, 16), (1,), (100003,), (1 << 20,), (7, 3)]
+    flat = torch.randn(40, generator=g).to(DEV)
+    def make():
+        ps = [torch.randn(*s, generator=torch.Generator().manual_seed(i)).to(DEV).requires_grad_(True) for i, s in enumerate(shapes)]
+        odd = flat.clone()[1:22].view(7, 3)                   # a view at a 4-byte offset: not 16-byte aligned
+        ps[-1] = odd.detach().requires_grad_(True)
+        return ps
+    pa, pb = make(), make()
+    groups = lambda ps: [{"params": ps[:4], "lr": 0}, {"params": [ps[4]], "lr": 0}, {"params": ps[5:] , "lr": 0}]
+    oa, ob = torch.optim.Adam(groups(pa), foreach=False), us.optim.Adam(groups(pb))
+    for o in (oa, ob):
+        o.param_groups[0]["lr"], o.param_groups[1]["lr"], o.param_groups[2]["lr"] = 1e-3, 0.05, 0.02
+    for step in range(5):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 3 and step < 2:
+                a.grad = b.grad = None                          # joins later: its own step count
+                continue
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (0.0 if (step == 2 and k == 4) else 0.1)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert int(ob.state[pb[3]]["step"]) == 3 and int(ob.state[pb[0]]["step"]) == 5
+
+
+def _reference_shaped_iteration(us, rend, dec, es, ec, opt, pools, c2ws, n_per, w, t_rand=None, idx=None):
+    """src/Mapper.py:372-445 in the reference's own calls"""
+    depths, colors, dirs = pools
+    H = W = 0
+    opt.zero_grad()
+    ro, rd, gd, gc = us.common.get_samples_all(0, H, 0, W, n_per, H, W, 0, 0, 0, 0, c2ws, depths, colors, DEV, dirs, indices=idx)
+    inside = us.common.bbox_filter(ro, rd, gd, BOUND)          # Mapper.py:396-406: the pre-filter and its four compactions
+    ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+    if t_rand is not None:
+        t_rand = t_rand[inside]
+    ret = rend.render_batch_ray(([es], [ec]), dec, rd, ro, DEV, 0.06, gt_depth=gd, t_rand=t_rand)
+    loss = us.mapping_loss(ret, gd, gc, 0.06, w)
+    loss.backward()
+    opt.step()
+    return loss, ret, inside
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_reference_shaped_iteration_equals_mapstep(us, prec):
+    """three mapping iterations through get_samples_all -> Renderer.render_batch_ray -> mapping_loss -> backward -> Adam.step() against
+    MapStep.iterate on the same rays, jitter and initial model: losses, rendered depth / colour, and the model after the three steps"""
+    import types
+    torch.manual_seed(0)
+    hidden = 32 if prec == "bf16" else 16
+    dec, es, ec = _model(us, False, prec, hidden=hidden)
+    dec2, es2, ec2 = copy.deepcopy(dec), copy.deepcopy(es), copy.deepcopy(ec)
+    cfg = _cfg(False, prec)
+    rend = us.Renderer(cfg, types.SimpleNamespace(bound=BOUND, device=DEV, H=12, W=16, fx=10., fy=10., cx=7.5, cy=5.5))
+    w = dict(fs=5, center=200, tail=10, color=5, depth=0.1)
+    lr = dict(decoders=1e-3, sdf_grid=0.05, color_grid=0.05)
+    b, P, n_per = 4, 5000, 512
+    g = torch.Generator().manual_seed(3)
+    c2ws = torch.eye(4).repeat(b, 1, 1)
+    c2ws[:, :3, 3] = torch.tensor([3.0, 1.2, 0.0]) + torch.randn(b, 3, generator=g) * 0.1
+    dirs = torch.randn(b, P, 3, generator=g); dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    pools = ((torch.rand(b, P, generator=g) * 2 + 0.4).to(DEV), torch.rand(b, P, 3, generator=g).to(DEV), dirs.to(DEV))
+    c2ws = c2ws.to(DEV)
+    opt = us.optim.Adam([{"params": list(dec.parameters()), "lr": lr["decoders"]}, {"params": [es.params], "lr": lr["sdf_grid"]},
+                         {"params": [ec.params], "lr": lr["color_grid"]}])
+    step = us.MapStep(es2, ec2, dec2, BOUND, 32, 8, 0.06, w, lr, max_rays=b * n_per)
+    for it in range(3):
+        idx = torch.randint(P, (b, n_per), generator=g).to(DEV)
+        t_rand = torch.rand(b * n_per, 40, generator=g).to(DEV)
+        loss, ret, inside = _reference_shaped_iteration(us, rend, dec, es, ec, opt, pools, c2ws, n_per, w, t_rand, idx)
+        ro, rd, gd, gc = us.common.get_samples_all(0, 0, 0, 0, n_per, 0, 0, 0, 0, 0, 0, c2ws, *pools[:2], DEV, pools[2], indices=idx)
+        loss2 = step.iterate(ro, rd, gd, gc, t_rand=t_rand, has_zero_depth=False)
+        r2 = step.rendered()
+        assert abs(float(loss) - float(loss2)) <= 2e-5 * abs(float(loss2)), (it, float(loss), float(loss2))
+        assert 0 < int(inside.sum()) < inside.numel()            # some rays leave the box before their depth: both paths drop them
+        assert _rel(ret[2], r2[2][inside]) <= 1e-4 and _rel(ret[3], r2[3][inside]) <= 1e-4
+    assert _rel(es.params, es2.params) <= 2e-4 and _rel(ec.params, ec2.params) <= 2e-4
+    for (k, a), (_, b_) in zip(dec.named_parameters(), dec2.named_parameters()):
+        assert _rel(a, b_) <= 2e-4, k

@@ -17,7 +17,7 @@ from .trackstep import TrackStep
 from .window import MapWindow, ArenaWindow, KeyframeArena
 from .graph import CapturedIteration
 from .mesher import eval_points
-from . import common, tcnn
+from . import common, tcnn, optim
 
 __all__ = ["HashGridEncoding", "FusedMLP", "Decoders", "Renderer", "sdf_losses", "mapping_loss", "tracking_loss",
            "fused_loss", "common", "tcnn", "UniSlamHipError", "LIB_PATH", "get_model", "make_grid_desc",

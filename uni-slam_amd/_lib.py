@@ -127,6 +127,8 @@ SIGNATURES = {
     "us_masked_median": (c_int, [c_f, c_f, c_f, c_i64, c_f, c_f]),
     "us_masked_mean": (c_int, [c_f, c_f, c_i64, c_f, c_f]),
     "us_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_f]),
+    "us_adam_step_tensors": (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_int, c_f]),
     "us_adam_step_segments": (c_int, [c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                       ctypes.POINTER(c_dbl), c_dbl, c_dbl, c_dbl, c_int, ctypes.c_uint, c_f]),
     "us_adam_step_segments_dev": (c_int, [c_f, c_f, c_f, c_f, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),

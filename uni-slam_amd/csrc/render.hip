@@ -946,6 +946,56 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// the same over up to ADAM_MAX_TENSORS SEPARATE tensors (each with its own p / g / m / v allocation and learning rate) in one launch:
+// the whole optimizer.step() of a torch.optim.Adam whose param_groups hold the decoders' nn.Linear parameters and the two tables
+// (src/Mapper.py:118-126,445) -- the drop-in optimiser unislam_amd.optim.Adam.  One-dimensional grid; tensor t owns workgroups
+// [blk[t], blk[t+1]).  Tensors whose four pointers are 16-byte aligned take 16-byte accesses (+ a scalar tail), the others 4-byte ones.
+#define ADAM_MAX_TENSORS 40
+struct AdamTensors {
+    float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
+    int64_t n[ADAM_MAX_TENSORS]; float step_size[ADAM_MAX_TENSORS]; uint32_t blk[ADAM_MAX_TENSORS + 1]; int n_tensors;
+};
+__device__ __forceinline__ void adam_one(float gi, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float one_minus_b1, float b2,
+                                         float one_minus_b2, float bc2_sqrt, float eps, float step_size) {
+    const float m0 = *m, v0 = *v;
+    const float mi = m0 + one_minus_b1 * (gi - m0);
+    const float vi = v0 * b2 + (one_minus_b2 * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    *p = *p + (-step_size) * (mi / denom);
+    *m = mi; *v = vi;
+}
+__global__ __launch_bounds__(256) void k_adam_tensors(const AdamTensors at, float one_minus_b1, float b2, float one_minus_b2, float bc2_sqrt, float eps) {
+    int t = 0;
+    while (t + 1 < at.n_tensors && blockIdx.x >= at.blk[t + 1]) ++t;
+    float* __restrict__ p = at.p[t]; const float* __restrict__ g = at.g[t]; float* __restrict__ m = at.m[t]; float* __restrict__ v = at.v[t];
+    const int64_t n = at.n[t];
+    const float step_size = at.step_size[t];
+    const unsigned bx = blockIdx.x - at.blk[t], gx = at.blk[t + 1] - at.blk[t];
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0);
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    const int64_t nv = vec ? n / 4 : 0;
+    for (int64_t k = (int64_t)bx * blockDim.x + threadIdx.x; k < nv; k += (int64_t)gx * blockDim.x) {
+        const int64_t i = k * 4;
+        const vec_t gv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(g + i));
+        const vec_t mv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(m + i));
+        const vec_t vv = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v + i));
+        vec_t pv = *reinterpret_cast<const vec_t*>(p + i), mo, vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gv[e], m0 = mv[e], v0 = vv[e];
+            const float mi = m0 + one_minus_b1 * (gi - m0);
+            const float vi = v0 * b2 + (one_minus_b2 * gi) * gi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pv[e] = pv[e] + (-step_size) * (mi / denom);
+            mo[e] = mi; vo[e] = vi;
+        }
+        *reinterpret_cast<vec_t*>(p + i) = pv;
+        __builtin_nontemporal_store(mo, reinterpret_cast<vec_t*>(m + i)); __builtin_nontemporal_store(vo, reinterpret_cast<vec_t*>(v + i));
+    }
+    for (int64_t i = nv * 4 + (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)gx * blockDim.x)
+        adam_one(g[i], p + i, m + i, v + i, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, step_size);
+}
+
 // the same over up to ADAM_MAX_SEG segments of one flat parameter buffer, each with its own learning rate: one launch
 #define ADAM_MAX_SEG 8
 struct AdamSegs { int64_t off[ADAM_MAX_SEG]; int64_t n[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; };
@@ -1816,6 +1866,33 @@ static int adam_segments(float* p, float* g, float* m, float* v, int n_seg, cons
                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, zero_grad_mask,
                            (const float*)step_dev, g16, g16_mask);
     US_CHECK_LAUNCH("us_adam_step_segments");
+    return US_OK;
+}
+
+extern "C" int us_adam_step_tensors(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                    const double* lr, double beta1, double beta2, double eps, int step, void* stream) {
+    US_REQUIRE(p && g && m && v && n && lr, US_ERR_NULL, "us_adam_step_tensors: NULL pointer");
+    US_REQUIRE(n_tensors >= 0 && n_tensors <= ADAM_MAX_TENSORS, US_ERR_SHAPE, "us_adam_step_tensors: n_tensors %d not in 0..%d", n_tensors, ADAM_MAX_TENSORS);
+    US_REQUIRE(step >= 1, US_ERR_SHAPE, "us_adam_step_tensors: step %d (1-based)", step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamTensors at;
+    memset(&at, 0, sizeof(at));
+    uint32_t blocks = 0;
+    int k = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        US_REQUIRE(n[t] >= 0, US_ERR_SHAPE, "us_adam_step_tensors: tensor %d: n %lld", t, (long long)n[t]);
+        if (n[t] == 0) continue;
+        US_REQUIRE(p[t] && g[t] && m[t] && v[t], US_ERR_NULL, "us_adam_step_tensors: tensor %d: NULL pointer", t);
+        at.p[k] = p[t]; at.g[k] = g[t]; at.m[k] = m[t]; at.v[k] = v[t]; at.n[k] = n[t]; at.step_size[k] = (float)(lr[t] / bc1);
+        at.blk[k] = blocks;
+        blocks += (uint32_t)grid_1d((n[t] + 3) / 4, 256, ADAM_VEC_BLOCKS);
+        ++k;
+    }
+    at.blk[k] = blocks; at.n_tensors = k;
+    if (k == 0) return US_OK;
+    hipLaunchKernelGGL(k_adam_tensors, dim3(blocks), dim3(256), 0, (hipStream_t)stream, at, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)sqrt(bc2), (float)eps);
+    US_CHECK_LAUNCH("us_adam_step_tensors");
     return US_OK;
 }
 

@@ -12,8 +12,32 @@ indexing), optimisers constructed with capturable=True and already stepped at le
 capture that contains an optimiser's lazy state initialisation would re-zero the moments on every replay.
 """
 import gc
+import os
 
 import torch
+
+# Every captured graph is kept alive here until release_all().  Reason (r5, reproduced twice each way on the MI355X box with
+# `pytest tests/test_gpu_dropin.py tests/test_gpu_slam.py`; native backtrace in profiles/r05_hipgraph_destroy_segv.txt): with the HIP
+# runtime torch 2.10+rocm7.0 bundles, destroying ONE graph that has parallel branches (hipGraphExecDestroy, reached from the garbage
+# collector when a MapStep / window / SLAM object dies) leaves every OLDER multi-branch graph exec with dangling branch streams: its next
+# hipGraphLaunch dies in hip::Graph::UpdateStreams (SIGSEGV on the host).  All graphs of this package fork side streams, so none may be
+# destroyed while another one may still be replayed.  A graph holds its launch records and the few small allocations made under
+# capture (the iteration's buffers are preallocated): the drivers capture one graph per KIND of window, so the registry stays small;
+# code that captures per mapped frame should call release_all() at a point where no captured graph will be replayed again.
+_KEEP = []
+
+
+def _keep(g):
+    if os.environ.get("US_KEEP_GRAPHS", "1") != "0":     # "0": the old behaviour (for reproducing the runtime fault)
+        _KEEP.append(g)
+
+
+def release_all():
+    """destroy every graph captured so far.  Only safe when none of them will be replayed again (see _KEEP)."""
+    n = len(_KEEP)
+    del _KEEP[:]
+    gc.collect()
+    return n
 
 
 class CapturedIteration:
@@ -26,6 +50,7 @@ class CapturedIteration:
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
+        _keep(self.graph)
         # No cyclic garbage collection while the stream captures: an older graph that is only reachable from a garbage cycle would be
         # destroyed by the collector in the middle of the capture, and hipGraphDestroy is "not permitted when stream is capturing"
         # (seen in a 40-frame SLAM run with one captured MapWindow per mapped frame).  The callable is dropped afterwards: it usually
@@ -69,6 +94,7 @@ class SegmentedGraph:
 
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
+            _keep(cur[0])
             cur[0].capture_begin(capture_error_mode="thread_local")
 
         def end(op):

@@ -38,6 +38,45 @@ class _RayPointsFn(torch.autograd.Function):
         return go, gd, None, None
 
 
+class _SamplePointsFn(torch.autograd.Function):
+    """
+    Renderer.py:81-101 + :132-137 for a batch whose rays all carry a depth, ONE launch (us_sample_points): sorted + jittered z_vals
+    [R,S] (no gradient) and the unit-cube points [R,S,3] (gradient to rays_o / rays_d: us_ray_points_bwd).  t_rand [R,S] replaces the
+    jitter's draw; None: the in-kernel counter-based generator with `seed` (the reference draws torch.rand there, Renderer.py:54).
+    """
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, gt_depth, bhost, t_uni, t_surf, truncation, t_rand, seed, perturb):
+        o, d, gd = L.f32(rays_o.detach()), L.f32(rays_d.detach()), L.f32(gt_depth.detach()).reshape(-1)
+        R, S = o.shape[0], t_uni.shape[0] + t_surf.shape[0]
+        dev = o.device
+        z = torch.empty((R, S), dtype=torch.float32, device=dev)
+        pts = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
+        valid = torch.empty(R, dtype=torch.uint8, device=dev)
+        tr = L.f32(t_rand) if (perturb and t_rand is not None) else None
+        L.check(L.lib().us_sample_points(L.ptr(o), L.ptr(d), L.ptr(gd), bhost, R, L.ptr(t_uni), t_uni.shape[0], L.ptr(t_surf),
+                                         t_surf.shape[0], ctypes.c_float(1.2), ctypes.c_float(1.5 * truncation),
+                                         ctypes.c_float(3 * truncation), L.ptr(tr), int(seed) & (2 ** 64 - 1), None, 1 if perturb else 0, 0,
+                                         L.ptr(valid), L.ptr(z), L.ptr(pts), L.stream()), "us_sample_points")
+        ctx.bhost = bhost
+        ctx.save_for_backward(z)
+        ctx.mark_non_differentiable(z)
+        return z, pts
+
+    @staticmethod
+    def backward(ctx, _gz, g):
+        (z,) = ctx.saved_tensors
+        R, S = z.shape
+        go = gd = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g = L.f32(g)
+            go = torch.empty((R, 3), dtype=torch.float32, device=z.device)
+            gd = torch.empty((R, 3), dtype=torch.float32, device=z.device)
+            L.check(L.lib().us_ray_points_bwd(L.ptr(g), L.ptr(z), ctx.bhost, R, S, L.ptr(go), L.ptr(gd), L.stream()),
+                    "us_ray_points_bwd")
+        return (go if ctx.needs_input_grad[0] else None, gd if ctx.needs_input_grad[1] else None) + (None,) * 8
+
+
 class _CompositeFn(torch.autograd.Function):
     """raw[R,S,4], z[R,S], beta[1] -> term, pixel_unc, depth, rgb, depth_unc   (Renderer.py:140-150)"""
 
@@ -146,6 +185,9 @@ class Renderer(object):
         # on the device: Renderer.py:83-84 rebuilds them every call
         self._t_uni = torch.linspace(0., 1., steps=self.n_stratified).to(self.device)
         self._t_surf = torch.linspace(0., 1., steps=self.n_importance).to(self.device)
+        # the jitter of a batch whose rays all carry a depth is drawn inside the sampling launch (a counter-based generator):
+        # seeded from torch's seed at construction, advanced per call
+        self._rng_seed, self._rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0
 
     def perturbation(self, z_vals):
         """Renderer.py:42-57"""
@@ -170,10 +212,15 @@ class Renderer(object):
         gt_depth = gt_depth.reshape(-1, 1)
         gt_mask = (gt_depth > 0).squeeze(-1)
         all_depth = bool(gt_mask.all())                      # the reference synchronises here too (Renderer.py:104)
+        if all_depth and n_rays > 0:
+            # z sampling + jitter + points in ONE launch (us_sample_points)
+            self._rng_calls += 1
+            seed = (self._rng_seed + 0x9E3779B97F4A7C15 * self._rng_calls) & (2 ** 64 - 1)
+            z_vals, pts = _SamplePointsFn.apply(rays_o, rays_d, gt_depth, self._bhost, self._t_uni, self._t_surf, float(truncation),
+                                                t_rand, seed, bool(self.perturb))
+            return self._decode_composite(scene_rep, decoders, pts, z_vals, device)
         if all_depth:
-            if self.perturb and t_rand is None:
-                t_rand = torch.rand((n_rays, S), device=device)
-            z_vals = sample_z(gt_depth, truncation, self._t_uni, self._t_surf, t_rand if self.perturb else None)
+            z_vals = sample_z(gt_depth, truncation, self._t_uni, self._t_surf, None)
         else:
             z_vals = torch.empty([n_rays, S], device=device)
             gt_nonzero = gt_depth[gt_mask]
@@ -183,6 +230,10 @@ class Renderer(object):
             z_vals[~gt_mask] = self._zero_depth_z(scene_rep, decoders, rays_o[~gt_mask].detach(),
                                                   rays_d[~gt_mask].detach(), device)
         pts = _RayPointsFn.apply(rays_o, rays_d, z_vals, self._bhost)          # normalised to [0,1] (Renderer.py:137)
+        return self._decode_composite(scene_rep, decoders, pts, z_vals, device)
+
+    def _decode_composite(self, scene_rep, decoders, pts, z_vals, device):
+        """Renderer.py:139-152"""
         raw = decoders(pts, scene_rep)
         beta = decoders.beta if torch.is_tensor(decoders.beta) else torch.tensor([float(decoders.beta)], device=device)
         term, unc, depth, rgb, dunc = _CompositeFn.apply(raw, z_vals, beta)
