@@ -391,7 +391,8 @@ def test_composite_golden(us, golden, tag):
     raw = T(g[f"{tag}_raw"]).to(DEV).requires_grad_(True)
     beta = T(g[f"{tag}_beta"]).to(DEV).requires_grad_(True)
     z = T(g[f"{tag}_z"]).to(DEV)
-    term, unc, depth, rgb, dunc = _CompositeFn.apply(raw, z, beta)
+    term, unc, depth, rgb, dunc, sdf = _CompositeFn.apply(raw, z, beta)
+    assert torch.equal(sdf, raw[..., 3].detach())
     outs = dict(term=term, unc=unc, depth=depth, rgb=rgb, dunc=dunc)
     for k, v in outs.items():
         close(v, g[f"{tag}_{k}"], 2e-5, 2e-6)
@@ -412,7 +413,7 @@ def test_composite_96_samples_vs_oracle(us):
     probes = [torch.randn(v.shape, generator=g) for v in (ref[0], ref[1], ref[2], ref[3], ref[6])]
     sum((p * v).sum() for p, v in zip(probes, (ref[0], ref[1], ref[2], ref[3], ref[6]))).backward()
     rg = raw.to(DEV).requires_grad_(True); bg = torch.tensor([10.0], device=DEV, requires_grad=True)
-    out = _CompositeFn.apply(rg, z.to(DEV), bg)
+    out = _CompositeFn.apply(rg, z.to(DEV), bg)[:5]
     for a, b in zip(out, (ref[0], ref[1], ref[2], ref[3], ref[6])):
         close(a, b, 2e-5, 2e-6)
     sum((p.to(DEV) * v).sum() for p, v in zip(probes, out)).backward()

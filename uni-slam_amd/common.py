@@ -246,7 +246,7 @@ def bbox_filter(rays_o, rays_d, gt_depth, bound, require_depth=False):
     valid = torch.empty(o.shape[0], dtype=torch.uint8, device=o.device)
     L.check(L.lib().us_bbox_filter(L.ptr(o), L.ptr(d), L.ptr(g), bound_host(bound), o.shape[0], int(require_depth),
                                    L.ptr(valid), None, L.stream()), "us_bbox_filter")
-    return valid.bool()
+    return valid.view(torch.bool)           # (the kernel writes 0 / 1: one byte per ray either way)
 
 
 def bbox_far(rays_o, rays_d, bound):

@@ -42,28 +42,32 @@ class _LossFn(torch.autograd.Function):
         partials = torch.empty(int(L.lib().us_loss_partials_size(R)), dtype=torch.float32, device=dev)
         stats = torch.empty(10, dtype=torch.float32, device=dev)
         med = None if median is None else L.f32(median.detach()).reshape(1)
-        val = None if valid is None else valid.to(torch.uint8).contiguous()
+        # (a bool mask is one byte per ray: reinterpreted, not converted)
+        val = None if valid is None else (valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous())
         L.check(L.lib().us_loss_stats(mode, sdf_p, sdf_stride, L.ptr(val), L.ptr(z), L.ptr(gd), L.ptr(gc), L.ptr(depth_),
                                       L.ptr(rgb_), L.ptr(unc), L.ptr(med), R, S, float(truncation), L.ptr(partials),
                                       L.ptr(stats), L.stream()), "us_loss_stats")
         if group is not None:
             torch.distributed.all_reduce(stats, group=group if group is not True else None)
-        g_sdf = torch.empty((R, S), dtype=torch.float32, device=dev)
-        g_depth = torch.empty(R, dtype=torch.float32, device=dev)
-        g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        # the three gradients in ONE buffer: the backward pass scales them by the upstream gradient with one multiplication
+        g_all = torch.empty(R * S + 4 * R, dtype=torch.float32, device=dev)
+        g_sdf, g_depth, g_rgb = g_all[:R * S].view(R, S), g_all[R * S:R * S + R], g_all[R * S + R:].view(R, 3)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         L.check(L.lib().us_loss_grad(mode, sdf_p, sdf_stride, L.ptr(val), L.ptr(z), L.ptr(gd), L.ptr(gc), L.ptr(depth_),
                                      L.ptr(rgb_), L.ptr(unc), L.ptr(med), R, S, float(truncation), L.host_floats(w5),
                                      L.ptr(stats), L.ptr(g_sdf), L.ptr(g_depth), L.ptr(g_rgb), L.ptr(loss), L.stream()),
                 "us_loss_grad")
-        ctx.save_for_backward(g_sdf, g_depth, g_rgb)
+        ctx.save_for_backward(g_all)
+        ctx.shape = (R, S)
         ctx.mark_non_differentiable(stats)
         return loss.reshape(()), stats
 
     @staticmethod
     def backward(ctx, g, _gs):
-        g_sdf, g_depth, g_rgb = ctx.saved_tensors
-        return (g_sdf * g, g_depth * g, g_rgb * g) + (None,) * 10
+        (g_all,) = ctx.saved_tensors
+        R, S = ctx.shape
+        ga = g_all * g
+        return (ga[:R * S].view(R, S), ga[R * S:R * S + R], ga[R * S + R:].view(R, 3)) + (None,) * 10
 
 
 def fused_loss(kind, mask_mode, sdf, z_vals, depth, rgb, pixel_unc, gt_depth, gt_color, truncation, w, valid=None,

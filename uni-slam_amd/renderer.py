@@ -78,7 +78,9 @@ class _SamplePointsFn(torch.autograd.Function):
 
 
 class _CompositeFn(torch.autograd.Function):
-    """raw[R,S,4], z[R,S], beta[1] -> term, pixel_unc, depth, rgb, depth_unc   (Renderer.py:140-150)"""
+    """raw[R,S,4], z[R,S], beta[1] -> term, pixel_unc, depth, rgb, depth_unc, sdf   (Renderer.py:140-152).  sdf [R,S] is the 4th channel
+    of raw as render_batch_ray returns it: an output of THIS node (a strided view of raw's storage), so that the gradient the loss sends
+    to it is added to d_raw inside us_composite_bwd instead of through a slice-backward (zeros + copy + add)."""
 
     @staticmethod
     def forward(ctx, raw, z_vals, beta):
@@ -90,19 +92,19 @@ class _CompositeFn(torch.autograd.Function):
         L.check(L.lib().us_composite_fwd(L.ptr(raw), L.ptr(z), L.ptr(b), R, S, L.ptr(term), L.ptr(unc), L.ptr(depth),
                                          L.ptr(rgb), L.ptr(dunc), None, L.stream()), "us_composite_fwd")
         ctx.save_for_backward(raw, z, b)
-        return term, unc, depth, rgb, dunc
+        return term, unc, depth, rgb, dunc, raw.view(R, S, 4)[..., 3]
 
     @staticmethod
-    def backward(ctx, g_term, g_unc, g_depth, g_rgb, g_dunc):
+    def backward(ctx, g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf):
         raw, z, b = ctx.saved_tensors
         R, S = z.shape
         c = lambda t: None if t is None else L.f32(t)
-        g_term, g_unc, g_depth, g_rgb, g_dunc = c(g_term), c(g_unc), c(g_depth), c(g_rgb), c(g_dunc)
+        g_term, g_unc, g_depth, g_rgb, g_dunc, g_sdf = c(g_term), c(g_unc), c(g_depth), c(g_rgb), c(g_dunc), c(g_sdf)
         d_raw = torch.empty_like(raw)
         d_beta = torch.zeros(1, device=z.device) if ctx.needs_input_grad[2] else None
         part = torch.empty(R, device=z.device) if d_beta is not None else None
         L.check(L.lib().us_composite_bwd(L.ptr(raw), L.ptr(z), L.ptr(b), R, S, L.ptr(g_term), L.ptr(g_unc),
-                                         L.ptr(g_depth), L.ptr(g_rgb), L.ptr(g_dunc), None, L.ptr(d_raw),
+                                         L.ptr(g_depth), L.ptr(g_rgb), L.ptr(g_dunc), L.ptr(g_sdf), L.ptr(d_raw),
                                          L.ptr(d_beta), L.ptr(part), L.stream()), "us_composite_bwd")
         return d_raw, None, d_beta
 
@@ -210,8 +212,9 @@ class Renderer(object):
         n_rays = rays_o.shape[0]
         S = self.n_stratified + self.n_importance
         gt_depth = gt_depth.reshape(-1, 1)
-        gt_mask = (gt_depth > 0).squeeze(-1)
-        all_depth = bool(gt_mask.all())                      # the reference synchronises here too (Renderer.py:104)
+        # the reference synchronises here too (Renderer.py:104: `if not gt_mask.all()`); one reduction instead of compare + all
+        all_depth = n_rays == 0 or float(gt_depth.detach().min()) > 0
+        gt_mask = None if all_depth else (gt_depth > 0).squeeze(-1)
         if all_depth and n_rays > 0:
             # z sampling + jitter + points in ONE launch (us_sample_points)
             self._rng_calls += 1
@@ -236,8 +239,8 @@ class Renderer(object):
         """Renderer.py:139-152"""
         raw = decoders(pts, scene_rep)
         beta = decoders.beta if torch.is_tensor(decoders.beta) else torch.tensor([float(decoders.beta)], device=device)
-        term, unc, depth, rgb, dunc = _CompositeFn.apply(raw, z_vals, beta)
-        return term, unc, depth, rgb, raw[..., 3], z_vals, dunc
+        term, unc, depth, rgb, dunc, sdf = _CompositeFn.apply(raw, z_vals, beta)
+        return term, unc, depth, rgb, sdf, z_vals, dunc
 
     def render_img(self, scene_rep, decoders, c2w, truncation, device, gt_depth=None):
         """Renderer.py:160-223: chunked forward-only render of a whole image."""
