@@ -4,7 +4,9 @@ oracle/gen_golden.py -- TEST INFRASTRUCTURE.  Runs ONLY in the build container (
 Imports the reference's own Python (third-party modules that are absent here are stubbed in
 sys.modules, in memory), runs its functions on CPU with fixed seeds and stores inputs + outputs
 as small .npz fixtures under tests/golden/.  The reference source never travels; the fixtures are
-data.  Re-run:  python oracle/gen_golden.py
+data.  Re-run:  python oracle/gen_golden.py      (ALL generators, in file order: g4 / g7 / g8 / g9 take their decoders' initial weights
+from torch's global generator as the generators before them left it; every other fixture, g14 included, is the same when its generator
+runs alone.  tests/test_golden_regen.py regenerates everything into a temporary folder and compares bit for bit.)
 
 Fixtures:
   g1_rays      get_camera_rays / get_rays / get_rays_from_uv / get_samples / get_samples_all
@@ -25,6 +27,9 @@ Fixtures:
   g14_mapping_joint  Mapper.optimize_mapping with joint_opt = True (dummy self): a 6-frame window, and a 12-frame window of a 22-keyframe
                 list with the 10 x 200 extra rays of Mapper.py:385-393; one iteration (pose / table gradients, state after Adam) and two
                 iterations (final tables, decoders, poses); pytorch3d's two quaternion helpers are the oracle's restatement
+  g15_sequence  the LOOP: Tracker.run / Mapper.run bodies alternating over 34 frames of the analytic room (every frame tracked, mapped and kept
+                as a keyframe: joint_opt from the fifth keyframe, the extra rays beyond 20), optimize_tracking / optimize_mapping /
+                keyframe_selection_LC being the reference's own methods: estimated trajectory, keyframe list, ATE (BASELINE configs[4]'s "vs reference")
   g13_scene     src/UNISLAM.py update_cam / load_bound / get_resolution (dummy self) and the per_level_scale line of get_encoder, and
                 src/config.py load_config, for the room0 / scene0000 / fr1_desk settings (their numbers are inputs of the fixture)
 """
@@ -38,7 +43,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("US_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")     # (tests/test_golden_regen.py writes to a temp dir)
 REF = "/root/reference"
 
 sys.dont_write_bytecode = True
@@ -363,6 +368,7 @@ def g14():
     cfg = make_cfg(32, 8, True)
     cfg["mapping"] = {"lr": {"decoders_lr": 0.001, "hash_grids_lr": 0.05, "c_hash_grids_lr": 0.05}}
     renderer = make_renderer(cfg, H, W, fx, fy, cx, cy)
+    torch.manual_seed(1400)              # the decoders' initial weights come from the global generator: fixed here, whatever ran before
     dec0 = RefDecoders(cfg, c_dim=32, truncation=0.06, learnable_beta=True)
     sd0 = {k: v.clone() for k, v in dec0.state_dict().items()}
     gs0, gc0 = small_grid(1401, amp=0.3).params.detach().clone(), small_grid(1402, amp=0.3).params.detach().clone()
@@ -550,7 +556,17 @@ def g12():
     os.environ.setdefault("MPLBACKEND", "Agg")
     import src.tools.eval_ate as E
     # pytorch3d is absent (see the header): only the translations enter the ATE, so any quaternion serves in convert_poses
+    # (for THIS generator only: g14 behind it needs the real helper -- r5: the patch used to stay in place for the rest of the process)
     RC.matrix_to_quaternion = lambda R: torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(R.shape[0], 1)
+    try:
+        _g12_body(E)
+    finally:
+        RC.matrix_to_quaternion = O.matrix_to_quaternion
+
+
+def _g12_body(E):
+    import tempfile
+    import contextlib, io
     rng = np.random.default_rng(12)
     out = {}
     n = 60
@@ -639,8 +655,132 @@ def g13():
     npz("g13_scene", **out)
 
 
+from g15_settings import G15  # noqa: E402  (shared with tests/test_gpu_slam.py::test_g15_sequence_against_the_reference_loop)
+
+
+def g15():
+    """
+    The reference's LOOP over a sequence: Tracker.run's body (Tracker.py:296-366: constant-speed prediction, a fresh pose Adam with
+    betas (0.5, 0.999), optimize_tracking per iteration, the minimum-loss pose) and Mapper.run's body (Mapper.py:494-533: first-frame
+    factor / iterations, joint_opt from the fifth keyframe, optimize_mapping with the REAL keyframe_selection_LC, the new keyframe's
+    10 % pool) alternating frame by frame as the two processes do through their wait loops (every_frame = 1: each frame is tracked, then
+    mapped).  optimize_tracking / optimize_mapping / keyframe_selection_LC / create_optimizer / sdf_losses are the reference's methods on
+    dummy selves; the encoders are the oracle's CPU hash grids, the frames come from the build's analytic SyntheticRoom (its parameters
+    are the fixture's inputs).  Stored: the estimated trajectory, the keyframe list, per-frame errors, the ATE.
+    """
+    import copy
+    sys.path.insert(0, ROOT)
+    import unislam_amd  # noqa: F401  (the analytic scene only; nothing of the HIP path runs here)
+    from unislam_amd.synthetic import SyntheticRoom
+    P, T_, M_ = G15, G15["tracking"], G15["mapping"]
+    torch.manual_seed(P["seed"])
+    NF, H, W = P["n_frames"], P["H"], P["W"]
+    room = SyntheticRoom(n_frames=NF, H=H, W=W, fov_deg=P["fov_deg"], device="cpu", tex_freq=P["tex_freq"])
+    fx, fy, cx, cy = room.fx, room.fy, room.cx, room.cy
+    bound = O.load_bound(P["room_bound"])
+    res = int((bound[:, 1] - bound[:, 0]).max() / P["voxel"])
+    mk = lambda l2, seed: O.HashGridOracle(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": l2,
+                                               "base_resolution": 16, "per_level_scale": O.per_level_scale(res)})
+    enc_s, enc_c = mk(P["log2T"][0], 1), mk(P["log2T"][1], 2)
+    gi = torch.Generator().manual_seed(P["seed"] + 1)
+    with torch.no_grad():                                                   # tcnn's initial range, from a generator of this fixture's own
+        enc_s.params.copy_((torch.rand(enc_s.params.shape, generator=gi) * 2 - 1) * 1e-4)
+        enc_c.params.copy_((torch.rand(enc_c.params.shape, generator=gi) * 2 - 1) * 1e-4)
+    cfg = make_cfg(P["n_stratified"], P["n_importance"], True)
+    cfg["mapping"] = {"lr": {k: M_[k] for k in ("decoders_lr", "hash_grids_lr", "c_hash_grids_lr")}}
+    u = types.SimpleNamespace(bound=bound, device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy)
+    renderer = RefRenderer(cfg, u)
+    dec = RefDecoders(cfg, c_dim=32, truncation=P["truncation"], learnable_beta=True)
+    dec.bound = bound
+    dec0 = {k: v.clone() for k, v in dec.state_dict().items()}
+    dec_t = copy.deepcopy(dec)                                              # Tracker.py:106-111: the tracker's own copy, frozen
+    for p_ in dec_t.parameters():
+        p_.requires_grad_(False)
+    est = torch.zeros(NF, 4, 4)
+    gts = room.poses.clone()
+    tracking_back = torch.zeros(1).int()
+    common = dict(cfg=cfg, hash_grids_xyz=[enc_s], c_hash_grids_xyz=[enc_c], device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, bound=bound,
+                  renderer=renderer, truncation=P["truncation"], estimate_c2w_list=est, tracking_back=tracking_back)
+    trk = types.SimpleNamespace(decoders=dec_t, ignore_edge_H=T_["ignore_edge_H"], ignore_edge_W=T_["ignore_edge_W"], t_mask_mode="original",
+                                **{k: T_[k] for k in ("w_color", "w_depth", "w_sdf_fs", "w_sdf_center", "w_sdf_tail")}, **common)
+    trk.sdf_losses = lambda *a: RefTracker.sdf_losses(trk, *a)
+    mp = types.SimpleNamespace(decoders=dec, m_mask_mode="original", keyframe_selection_method="global", keyframe_dict=[], keyframe_list=[],
+                               mapping_pixels=M_["pixels"], joint_opt=False, joint_opt_cam_lr=M_["joint_opt_cam_lr"], no_vis_on_first_frame=True,
+                               mapping_window_size=M_["mapping_window_size"], visualizer=MagicMock(), LC=M_["LC"], LC_cnt=torch.zeros(1).int(),
+                               activated_mapping_mode=T_["activated_mapping_mode"],
+                               **{k: M_[k] for k in ("w_color", "w_depth", "w_sdf_fs", "w_sdf_center", "w_sdf_tail")}, **common)
+    mp.sdf_losses = lambda *a: RefMapper.sdf_losses(mp, *a)
+    mp.create_optimizer = lambda c, f: RefMapper.create_optimizer(mp, c, f)
+    mp.keyframe_selection_LC = lambda *a, **k: RefMapper.keyframe_selection_LC(mp, *a, **k)
+    num_cam_iters, m_iters = T_["iters"], M_["iters"]
+    init_phase = True
+    tb_flags, joint_flags, window_sizes = [], [], []
+    for idx in range(NF):
+        _, color, depth, gt_c2w, rays_d = room[idx]
+        # ---- Tracker.run body (Tracker.py:296-366)
+        dec_t.load_state_dict(dec.state_dict())                             # update_params_from_mapping (:246-258): the grids are shared objects
+        if idx == 0:
+            c2w = gt_c2w.clone()
+        else:
+            pre_c2w = est[idx - 1].unsqueeze(0)
+            if T_["const_speed_assumption"] and idx - 2 >= 0:
+                pre_poses = RC.matrix_to_cam_pose(torch.stack([est[idx - 2], pre_c2w.squeeze(0)], dim=0))
+                cam_pose = 2 * pre_poses[1:] - pre_poses[0:1]
+            else:
+                cam_pose = RC.matrix_to_cam_pose(pre_c2w)
+            T = torch.nn.Parameter(cam_pose[:, -3:].clone())
+            R = torch.nn.Parameter(cam_pose[:, :4].clone())
+            opt = torch.optim.Adam([{"params": [T], "lr": T_["lr_T"], "betas": (0.5, 0.999)}, {"params": [R], "lr": T_["lr_R"], "betas": (0.5, 0.999)}])
+            current_min_loss, cam_iter = float("inf"), 0
+            while cam_iter < num_cam_iters:
+                cam_pose = torch.cat([R, T], -1)
+                loss, rendered_weights = RefTracker.optimize_tracking(trk, cam_pose, color[None], depth[None], T_["pixels"], opt)
+                if loss < current_min_loss:
+                    current_min_loss, candidate = loss, cam_pose.clone().detach()
+                cam_iter += 1
+                if cam_iter == num_cam_iters - 1:
+                    w = rendered_weights.detach().mean()
+                    if T_["activated_mapping_mode"] and w > T_["uncertainty_ts"]:
+                        num_cam_iters, m_iters = T_["iters"] * 2, M_["iters"] * 2
+                        tracking_back[0] = 1
+                    else:
+                        num_cam_iters, m_iters = T_["iters"], M_["iters"]
+                        tracking_back[0] = 0
+            c2w = RC.cam_pose_to_matrix(candidate).squeeze(0)
+        est[idx] = c2w.detach().clone()
+        tb_flags.append(int(tracking_back[0]))
+        # ---- Mapper.run body (Mapper.py:494-533)
+        if idx % M_["every_frame"] == 0 or int(tracking_back[0]) == 1 or idx == NF - 1:
+            cur_c2w = est[idx]
+            lr_factor = M_["lr_first_factor"] if init_phase else M_["lr_factor"]
+            iters = M_["iters_first"] if init_phase else m_iters
+            mp.joint_opt = (len(mp.keyframe_list) > 4) and M_["joint_opt"]
+            joint_flags.append(int(mp.joint_opt))
+            window_sizes.append(len(mp.keyframe_list))
+            cur_c2w = RefMapper.optimize_mapping(mp, iters, lr_factor, idx, color, depth, gt_c2w, mp.keyframe_dict, mp.keyframe_list, cur_c2w, rays_d)
+            if mp.joint_opt:
+                est[idx] = cur_c2w.detach()
+            if idx % M_["keyframe_every"] == 0 or int(tracking_back[0]) == 1:
+                mp.keyframe_list.append(idx)
+                n_save = int(H * W * 0.1)
+                ind = torch.randperm(H * W)[:n_save]
+                mp.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "color": color.reshape(-1, 3)[ind], "depth": depth.reshape(-1)[ind],
+                                         "est_c2w": cur_c2w.detach().clone(), "rays_d": rays_d.reshape(-1, 3)[ind]})
+            init_phase = False
+    err = (est[:, :3, 3] - gts[:, :3, 3]).norm(dim=-1)
+    _, c0, d0, _, _ = room[0]
+    npz("g15_sequence", gt_c2w=gts, est_c2w=est, keyframe_list=np.array(mp.keyframe_list), tracking_back=np.array(tb_flags),
+        joint_opt=np.array(joint_flags), keyframes_before_mapping=np.array(window_sizes), lc_cnt=int(mp.LC_cnt[0]), err_m=err,
+        ate_rmse_m=float(err.pow(2).mean().sqrt()), intr=np.array([H, W, fx, fy, cx, cy]), frame0_depth_row=d0[H // 2], frame0_color_row=c0[H // 2],
+        res=res, kf_est_c2w=torch.stack([d["est_c2w"] for d in mp.keyframe_dict]),
+        **{"dec0__" + k.replace(".", "__"): v for k, v in dec0.items()},
+        **{"dec1__" + k.replace(".", "__"): v.detach() for k, v in dec.state_dict().items()})
+    print(f"g15: ATE {100 * float(err.pow(2).mean().sqrt()):.2f} cm, max {100 * float(err.max()):.2f} cm at frame {int(err.argmax())}, "
+          f"{len(mp.keyframe_list)} keyframes, LC {int(mp.LC_cnt[0])}")
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

@@ -160,6 +160,16 @@ def _g14_scene(us, g):
     return dec, es, ec
 
 
+def _tables_after_adam(got, want, rtol=1e-3, atol=2e-5, max_outliers=1e-3, outlier_atol=2e-3):
+    """table entries after Adam steps: rtol / atol for all but a few.  Adam divides an entry's step by that entry's own gradient history, so
+    an entry whose gradient is a near-cancelling sum (|g| at the rounding level of its contributions) takes a step whose size -- a visible
+    fraction of lr = 0.05 -- depends on the order of a float sum: the reference's CPU sum and the kernels' f64 sum differ there.  At most
+    0.1 % of the entries may sit outside the bar (r5, regenerated g14: 16 of 32 768), and those within 2e-3."""
+    bad = np.abs(got - want) > atol + rtol * np.abs(want)
+    assert bad.mean() <= max_outliers, (int(bad.sum()), bad.size)
+    assert float(np.abs(got - want).max()) <= outlier_atol, float(np.abs(got - want).max())
+
+
 @pytest.mark.parametrize("tag", ["w6", "w12x"])
 def test_mapwindow_reproduces_reference_joint_opt(golden, tag):
     """MapWindow driven like Mapper.optimize_mapping with joint_opt (6-frame window; 12-frame window + the 10 x 200 extra rays) against
@@ -194,8 +204,8 @@ def test_mapwindow_reproduces_reference_joint_opt(golden, tag):
         np.testing.assert_allclose(out[-1].numpy(), g[pre + "cur_c2w"], rtol=0, atol=3e-5)
         np.testing.assert_allclose(out[:-1].numpy(), g[pre + "kf_c2w"][frames], rtol=0, atol=3e-5)
         if iters == 2:
-            np.testing.assert_allclose(es.params.detach().cpu().numpy(), g[pre + "grid_s"], rtol=1e-3, atol=2e-5)
-            np.testing.assert_allclose(ec.params.detach().cpu().numpy(), g[pre + "grid_c"], rtol=1e-3, atol=2e-5)
+            _tables_after_adam(es.params.detach().cpu().numpy(), g[pre + "grid_s"])
+            _tables_after_adam(ec.params.detach().cpu().numpy(), g[pre + "grid_c"])
             for k, v in dec.state_dict().items():
                 np.testing.assert_allclose(v.cpu().numpy(), g[pre + "dec__" + k.replace(".", "__")], rtol=1e-3, atol=2e-5)
 
@@ -610,8 +620,28 @@ def test_pose_conversion_kernels_equal_the_torch_chains():
     ref_back = torch.eye(4).repeat(400, 1, 1); ref_back[:, :3, :3] = O.quaternion_to_matrix(ref[:, :4]); ref_back[:, :3, 3] = ref[:, 4:]
     assert torch.allclose(back.cpu(), ref_back, rtol=0, atol=5e-7) and torch.allclose(back.cpu(), c2w, rtol=0, atol=2e-6)
     assert torch.equal(back[:, 3].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]).repeat(400, 1))
-    pred = C.predict_cam_pose(c2w[3].to(DEV), c2w[4].to(DEV))
-    assert pred.shape == (1, 7) and torch.allclose(pred.cpu(), 2 * ref[4:5] - ref[3:4], rtol=0, atol=5e-7)
+    # the constant-speed prediction: element-wise on the 7 numbers (Tracker.py:317-320), the newer quaternion first put on the older one's
+    # hemisphere (q and -q are one rotation; r5)
+    for a, b_ in ((3, 4), (100, 101), (200, 201), (45, 46)):
+        pred = C.predict_cam_pose(c2w[a].to(DEV), c2w[b_].to(DEV))
+        q1 = ref[b_:b_ + 1].clone()
+        if float((ref[a, :4] * q1[0, :4]).sum()) < 0:
+            q1[:, :4] = -q1[:, :4]
+        assert pred.shape == (1, 7) and torch.allclose(pred.cpu(), 2 * q1 - ref[a:a + 1], rtol=0, atol=5e-7)
+    # two poses a small turn apart on either side of a quarter turn about -x: quaternions (cos, -sin, 0, 0) with |cos| ~ |sin|; the
+    # largest-candidate rule of matrix_to_quaternion switches from the r branch to the i branch between them and answers with (nearly)
+    # OPPOSITE quaternions; the element-wise extrapolation without the hemisphere step would predict ~3 q instead of ~q
+    import math
+    def rot_x(a_):
+        m = torch.eye(4); m[1, 1] = m[2, 2] = math.cos(a_); m[1, 2] = -math.sin(a_); m[2, 1] = math.sin(a_); return m
+    m0, m1 = rot_x(-(math.pi / 2 - 0.01)), rot_x(-(math.pi / 2 + 0.01))
+    p0, p1 = O.matrix_to_cam_pose(torch.stack([m0, m1]))
+    assert float((p0[:4] * p1[:4]).sum()) < -0.99                           # the case at hand
+    for dev_path in (True, False):
+        pred = C.predict_cam_pose(m0.to(DEV), m1.to(DEV)) if dev_path else C.predict_cam_pose(m0.to(DEV).requires_grad_(True), m1.to(DEV))
+        Rp = C.cam_pose_to_matrix(pred.detach())[0, :3, :3].cpu()
+        want = rot_x(-(math.pi / 2 + 0.03))[:3, :3]                          # the same turn once more
+        assert float((Rp - want).abs().max()) < 1e-3, (dev_path, Rp)
     # tensors inside autograd keep the differentiable torch chain
     p = got[:2].clone().requires_grad_(True)
     C.cam_pose_to_matrix(p).sum().backward()

@@ -198,6 +198,8 @@ def predict_cam_pose(c2w_before, c2w_last):
         L.check(L.lib().us_matrix_to_cam_pose(L.ptr(m), 1, 1, L.ptr(out), L.stream()), "us_matrix_to_cam_pose")
         return out
     pre = matrix_to_cam_pose(m)
+    if float((pre[0, :4] * pre[1, :4]).sum()) < 0:           # q and -q are one rotation: extrapolate on one hemisphere (csrc/window.hip)
+        pre = torch.cat([pre[:1], torch.cat([-pre[1:, :4], pre[1:, 4:]], -1)], 0)
     return 2 * pre[1:] - pre[0:1]
 
 

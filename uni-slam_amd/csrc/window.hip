@@ -302,6 +302,15 @@ __global__ __launch_bounds__(64) void k_matrix_to_pose(const float* __restrict__
     if (extrapolate) {
         float q1[7];
         w_matrix_pose(c2w + 16, q1);
+        // Tracker.py:317-320 extrapolates the two quaternions element by element.  q and -q are one rotation, and which of the two
+        // matrix_to_quaternion returns depends on its branch (pytorch3d: the largest of the four candidates' norms): where the branch
+        // switches between the two frames, or the real part is negative under one convention and positive under the other, 2 q1 - q0
+        // would point anywhere.  Put q1 on q0's hemisphere first: equal to the reference wherever its prediction is sane (q0 . q1 > 0
+        // already), and independent of the helper's sign convention -- the one unpinned detail that could change a result.
+        if (q[0] * q1[0] + q[1] * q1[1] + q[2] * q1[2] + q[3] * q1[3] < 0.0f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q1[c] = -q1[c];
+        }
 #pragma unroll
         for (int c = 0; c < 7; ++c) q[c] = 2.0f * q1[c] - q[c];
     }

@@ -156,6 +156,7 @@ class Mapper:
         self.arena = KeyframeArena(n_kf + 1, int(H * W * 0.1), slam.device)
         self.kf_c2w = torch.zeros((self.arena.K, 4, 4), device=slam.device)             # est_c2w per arena row (src/Mapper.py:447-457 writes them back)
         self._wins = {}
+        self.kind_counts = {}
         self.cur_has_zero = False
         self.timing = None
 
@@ -243,9 +244,11 @@ class Mapper:
         c2ws = self.kf_c2w[torch.as_tensor(rows, device=dev)]
         has_zero = self.cur_has_zero or any(kd[f]["has_zero"] for f in optimize_frame if f != -1)
         joint = self.joint_opt and b > 1
-        extra = (10, 200) if (not s.tracking_back and len(kl) > 20) else None           # extra rays from the newest frames (:381-390)
+        extra = (10, 200) if (not s.tracking_back and len(kl) > 20 and c.get("extra_rays", True)) else None   # extra rays from the newest frames (:381-390)
         self._mark("pool of the frame + window rows")
         win = self._window(joint, extra is not None, has_zero, lr_factor)
+        kind = (bool(joint), extra is not None, bool(has_zero), float(lr_factor))
+        self.kind_counts[kind] = self.kind_counts.get(kind, 0) + 1                    # how often each kind of window was mapped (tests, logs)
         self.step.reset_optimizer(lr_factor)                                            # a fresh Adam per mapped frame (:358-364)
         win.bind(rows, c2ws, pixs_per_image, extra)
         self._mark("optimiser reset + bind")

@@ -13,8 +13,21 @@ from .common import get_camera_rays
 
 
 class SyntheticRoom:
+    # path="loop": a closed circle of radius 0.7 m (turn 1.637 deg per 2 cm step: 220 frames per round) in the free half of the room,
+    # at least 0.2 m from every surface -- for runs longer than the default arc allows (see `clearance`)
+    LOOP = dict(start=(4.2, 1.3, -0.1), yaw0_deg=-53.13, turn_deg=1.637)
+
     def __init__(self, n_frames=40, H=120, W=160, fov_deg=80.0, device="cuda:0", room=((0.0, 6.0), (-0.6, 3.0), (-1.2, 1.0)),
-                 step_m=0.02, turn_deg=0.8, seed=0, tex_freq=1.0):
+                 step_m=0.02, turn_deg=0.8, seed=0, tex_freq=1.0, start=(1.3, 1.2, -0.1), yaw0_deg=0.0, path=None, clearance=0.05):
+        """
+        clearance: every camera position must keep this distance (m) from every surface, else ValueError.  r5: the default arc (radius
+        1.43 m from (1.3, 1.2)) passes 0.14 m from the sphere at frame ~105 and LEAVES THE ROOM through the wall y = 3.0 at frame 194 --
+        a 300-frame run on it showed a 'drift' of 8.6 cm from frame 200 on that was the camera looking at the room from outside.
+        """
+        if path == "loop":
+            start, yaw0_deg, turn_deg = self.LOOP["start"], self.LOOP["yaw0_deg"], self.LOOP["turn_deg"]
+        elif path is not None:
+            raise ValueError(f"SyntheticRoom: unknown path {path!r}")
         self.n_img, self.H, self.W, self.device = n_frames, H, W, torch.device(device)
         self.fx = self.fy = 0.5 * W / math.tan(math.radians(fov_deg) / 2)
         self.cx, self.cy = (W - 1) / 2.0, (H - 1) / 2.0
@@ -24,7 +37,14 @@ class SyntheticRoom:
         self.block_c = torch.tensor([2.2, 2.1, -0.7], device=self.device)
         self.block_h = torch.tensor([0.45, 0.35, 0.5], device=self.device)
         self.dirs = get_camera_rays(H, W, self.fx, self.fy, self.cx, self.cy).to(self.device)      # [H,W,3] camera frame
-        self.poses = self._trajectory(n_frames, step_m, turn_deg, seed)
+        self.poses = self._trajectory(n_frames, step_m, turn_deg, seed, start, yaw0_deg, level=(path == "loop"))
+        if clearance is not None and n_frames > 0:
+            d = self.sdf(self.poses[:, :3, 3])
+            bad = torch.nonzero(d < clearance)
+            if bad.numel():
+                k = int(bad[0])
+                raise ValueError(f"SyntheticRoom: the camera path comes within {float(d[k]):.3f} m of a surface at frame {k} (clearance {clearance} m; "
+                                 f"negative: inside an object or outside the room).  Use fewer frames, path='loop', or another start / turn_deg.")
         self._cache = {}
 
     # ---- scene ------------------------------------------------------------------------------------------------
@@ -43,10 +63,10 @@ class SyntheticRoom:
         return (0.75 * base + 0.25 * tint).clamp(0, 1)
 
     # ---- camera path --------------------------------------------------------------------------------------------
-    def _trajectory(self, n, step_m, turn_deg, seed):
-        """camera starts near the room centre looking along +x (yaw) and drifts on a slow arc; z is up in the world"""
+    def _trajectory(self, n, step_m, turn_deg, seed, start=(1.3, 1.2, -0.1), yaw0_deg=0.0, level=False):
+        """camera starts at `start` looking along yaw0 (default: near the room centre, along +x) and drifts on a slow arc; z is up in the world"""
         poses = []
-        pos = torch.tensor([1.3, 1.2, -0.1]); yaw = 0.0; pitch = -0.05
+        pos = torch.tensor([float(v) for v in start]); yaw = math.radians(yaw0_deg); pitch = -0.05
         for k in range(n):
             cy_, sy_ = math.cos(yaw), math.sin(yaw)
             fwd = torch.tensor([cy_ * math.cos(pitch), sy_ * math.cos(pitch), math.sin(pitch)])
@@ -56,7 +76,10 @@ class SyntheticRoom:
             c2w = torch.eye(4)
             c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, up, -fwd, pos
             poses.append(c2w.clone())
-            pos = pos + step_m * (0.8 * fwd + 0.6 * right) + torch.tensor([0.0, 0.0, 0.004 * math.sin(0.3 * k)])
+            move = step_m * (0.8 * fwd + 0.6 * right)
+            if level:                                                           # (a closed loop: the pitch does not carry the camera down)
+                move[2] = 0.0
+            pos = pos + move + torch.tensor([0.0, 0.0, 0.004 * math.sin(0.3 * k)])
             yaw += math.radians(turn_deg); pitch += math.radians(0.1 * math.cos(0.25 * k))
         return torch.stack(poses).to(self.device)
 
