@@ -54,11 +54,11 @@ def parse_args(argv=None):
                     help="MFMA operand type of the decoders.  bf16 (headline): v_mfma_f32_16x16x32_bf16 with split operands (hi + lo) in the "
                          "forward products -- rendered depth / colour within 4e-5 of the fp32 decoders on identical parameters "
                          "(tools/bf16_deviation.py; bound 1e-3), bf16 operands in the gradient products; fp32: f32-input MFMA throughout")
-    ap.add_argument("--grad-comm", default="bf16_colour", choices=["fp32", "bf16", "bf16_colour"],
-                    help="payload type of the gradient all-reduce (N > 1).  bf16_colour (default): the colour table's segment -- 44.7 of the 51.7 MB -- "
-                         "travels as bfloat16, the geometry (sdf table, decoders, beta) as fp32: a 15-iteration window converges to the same map "
-                         "(held-out depth 7e-7, colour 8e-6 from fp32 gradients; tests/test_gpu_step.py); fp32: N ranks reproduce one process on "
-                         "the concatenated batch to rounding; bf16: everything narrow")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16", "bf16_colour"],
+                    help="payload type of the gradient all-reduce (N > 1).  fp32 (default): N ranks reproduce one process on the concatenated batch "
+                         "to rounding -- the reference's fp32 Adam input; bf16_colour (lossy, opt-in): the colour table's segment -- 44.7 of the 51.7 MB "
+                         "-- travels as bfloat16, the geometry (sdf table, decoders, beta) as fp32: a 15-iteration window converges to the same map "
+                         "(held-out depth 7e-7, colour 8e-6 from fp32 gradients; tests/test_gpu_step.py); bf16: everything narrow")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: reduce-scatter the gradient, Adam on this rank's shard, all-gather the parameters")
     ap.add_argument("--dp-mode", default="local_fast", choices=["local_fast", "colour_first"],
@@ -70,9 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--joint", default="auto", choices=["auto", "0", "1"],
                     help="both grids in one encoder launch and one binned table-gradient pass (csrc/hashgrid_joint.hip); auto = MapStep's default")
     ap.add_argument("--no-graph", action="store_true", help="launch every iteration eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--dp-graph", default="inside", choices=["inside", "between"],
-                    help="N > 1: the step as ONE hipGraph with the RCCL calls captured inside it (default), or hipGraph segments with the "
-                         "collectives eager between them (graph.SegmentedGraph)")
+    ap.add_argument("--dp-graph", default="between", choices=["inside", "between"],
+                    help="N > 1: hipGraph segments with the collectives eager between them (graph.SegmentedGraph; default -- the form the world-2 "
+                         "tests cover), or the step as ONE hipGraph with the RCCL calls captured inside it (0.52 instead of 0.62 ms of rank-local "
+                         "work, but only ever run on a 1-rank group: opt in on a node where it can be watched)")
     ap.add_argument("--fixed-batch", action="store_true", help="re-render one fixed batch every step (round 1's bench) instead of a fresh draw")
     ap.add_argument("--probe-steps", type=int, default=10, help="eager iterations with HIP events around the hot kernels, after the timed region")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed iterations before the W warm-up steps (clock ramp)")

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunislam_hip.so")
+LIB_PATH = os.environ.get("US_LIB_PATH") or os.path.join(_HERE, "libunislam_hip.so")     # (US_LIB_PATH: a timing / experiments build, development only)
 US_MAX_LEVELS = 32
 US_ERR_CONFIG = -3          # unislam_hip.h: unsupported descriptor / configuration
 US_GRID_CLAMP01 = 1

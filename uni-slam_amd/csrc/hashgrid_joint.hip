@@ -671,7 +671,11 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         };
         auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, auto with_entries) {
             auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
+#if defined(J_WR_X_NOATOMIC) || defined(J_WR_X_LINEAR_STAGE)      // (timing experiments: the stage is in no order; keep the copy-out's stores contiguous)
+                const uint32_t R = (uint32_t)(((uint64_t)(blockIdx.x * n_levels + level) * J_STAGE + k + sb + (gr[(a.x >> 16) & (J_LVL_BINS - 1)] & 0u)) % rec_cap);
+#else
                 const uint32_t R = gr[a.x >> 16] + k + sb;
+#endif
                 if (R < rec_cap) {
                     if (decltype(with_entries)::value) rec_e[R] = (uint16_t)a.x;
                     rec_v[R] = make_uint2(a.y, z);
@@ -697,7 +701,13 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     k8[c] = 0xFFFFu;
+#if defined(J_WR_X_NOATOMIC)         // timing experiment (garbage results): no cursor atomics, conflict-free stage positions
+                    if ((tail >> c) & 1u) k8[c] = (uint32_t)c * J_ROW_POINTS + tid;
+#elif defined(J_WR_X_LINEAR_STAGE)   // timing experiment (garbage results): the atomics run, the stage positions are conflict-free
+                    if ((tail >> c) & 1u) { const uint32_t dummy = atomicAdd(&cur[par][(e[c] >> BIN_LINE_LOG2) & nbm], 1u); k8[c] = dummy < 0xFFFFFFFFu ? (uint32_t)c * J_ROW_POINTS + tid : 0u; }
+#else
                     if ((tail >> c) & 1u) k8[c] = atomicAdd(&cur[par][(e[c] >> BIN_LINE_LOG2) & nbm], 1u);
+#endif
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {

@@ -112,8 +112,16 @@ class SegmentedGraph:
                 begin()
                 try:
                     self.out = fn(cut)
-                finally:
-                    end(None)
+                except BaseException:
+                    # fn failed under capture: close the open capture so that the stream is usable again, but let the ORIGINAL error
+                    # through (ending an invalidated capture usually raises too) and keep no half-built segments
+                    try:
+                        end(None)
+                    except Exception:
+                        pass
+                    self.segments = []
+                    raise
+                end(None)
         finally:
             if was:
                 gc.enable()

@@ -502,6 +502,7 @@ class MapStep:
         # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
         binned = self.ws is not None
         self._folded = False
+        self._grad_image_written = False                         # only the branch that writes the bf16 image in THIS call sets it (dist.GradComm.announce)
         # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
         # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
         defer = bool(self.joint and binned and not self.chunk_rays and self.overlap and not self._probing)
@@ -713,9 +714,12 @@ class MapStep:
         leave its gradient as the bfloat16 image (self._grad_bf16) as well.  That launch writes every entry exactly once: no bin is split
         over workgroups (US_GRID_BWD_DETERMINISTIC from here on, in the scan passes too).  Returns whether the path is taken."""
         ok = bool(on) and self.joint and self.dp_mode == "local_fast"
-        self._grad_image = ok
-        if ok:
+        if ok and not self._grad_image:
+            self._det_before_image = self._det
             self._det = L.US_GRID_BWD_DETERMINISTIC
+        elif not ok and self._grad_image:
+            self._det = getattr(self, "_det_before_image", 0)    # what the constructor's `deterministic` asked for
+        self._grad_image = ok
         return ok
 
     def adam_step(self, ranges=None, part=None, poses=None):

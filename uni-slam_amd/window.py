@@ -251,7 +251,11 @@ class MapWindow:
                 import torch.distributed as dist
                 from .dist import _pg
                 if collectives is None:
-                    collectives = "inside" if dist.get_backend(_pg(s.group)) == "nccl" else "between"
+                    # "inside" has only ever run on a 1-rank RCCL group (no node with more GPUs was available to the builder): work handles,
+                    # finish_first and the optimiser in parts inside a captured graph are untested at world > 1, and a hang during replay only
+                    # ends at the process group's timeout.  Default: "inside" for one rank, "between" (tested with gloo at world 2 / 8) beyond.
+                    nccl = dist.get_backend(_pg(s.group)) == "nccl"
+                    collectives = "inside" if (nccl and dist.get_world_size(_pg(s.group)) == 1) else "between"
                 if collectives not in ("inside", "between"):
                     raise L.UniSlamHipError(f"MapWindow.capture: collectives {collectives!r} not in ('inside', 'between')")
                 inside = collectives == "inside"
@@ -269,6 +273,10 @@ class MapWindow:
             self._graph = None
             raise L.UniSlamHipError("MapWindow.replay: the MapStep's buffers were reallocated after this graph was captured (it holds the "
                                     "old addresses); capture() again")
+        arena = getattr(self, "arena", None)
+        if arena is not None and arena.generation != self.generation:       # KeyframeArena.grow(): the graph holds the freed pools' addresses
+            self._graph = None
+            raise L.UniSlamHipError("ArenaWindow.replay: the arena has grown since this graph was captured; build a new window")
         if self._device_draw:
             if indices is not None:
                 raise L.UniSlamHipError("MapWindow.replay: this graph draws its pixels itself; capture(device_draw=False) to pass indices")
@@ -401,6 +409,7 @@ class ArenaWindow(MapWindow):
         self.shape_dev = torch.zeros(8, dtype=torch.int32, device=dev)
         self.slots = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self._stage = [torch.zeros(8 + self.cap, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._stage_ev = [None] * len(self._stage)                  # the copy out of stage k: waited for before the host writes it again
         self._stage_k = 0
         self.c2w_first = torch.eye(4, device=dev)
         f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
@@ -424,11 +433,16 @@ class ArenaWindow(MapWindow):
         xf, xn = (min(int(extra[0]), b), int(extra[1])) if extra else (0, 0)
         if b * n_per > self.rows_a or xf * xn > self.rows_b or n_per < 1:
             raise L.UniSlamHipError(f"ArenaWindow: window of {b} x {n_per} + {xf} x {xn} rays does not fit rows {self.rows_a} + {self.rows_b}")
-        st = self._stage[self._stage_k]; self._stage_k = (self._stage_k + 1) % len(self._stage)
+        k = self._stage_k
+        st = self._stage[k]; self._stage_k = (k + 1) % len(self._stage)
+        if self._stage_ev[k] is not None:
+            self._stage_ev[k].synchronize()                          # (four binds ago: normally long done)
         st[:8] = torch.tensor([b, n_per, xf, xn, 1, 0, 0, 0], dtype=torch.int32)
         st[8:8 + b] = torch.as_tensor(slots, dtype=torch.int32)
         self.shape_dev.copy_(st[:8], non_blocking=True)
         self.slots[:b].copy_(st[8:8 + b], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        self._stage_ev[k] = ev
         self.b, self.n_per, self.extra = b, int(n_per), ((xf, xn) if xf and xn else None)
 
     def bind(self, slots, c2ws, n_per, extra=None):
