@@ -1049,3 +1049,4 @@ def test_iterate_folds_the_decoder_reductions_into_their_adam_launch():
     # the decoder gradients of the last iteration are in the gradient buffer either way (the unfolded optimiser pass clears them: compare
     # against a recomputation)
     assert float(a[4].abs().max()) > 0
+

@@ -20,7 +20,7 @@ def build():
                                             "base_resolution": 16, "per_level_scale": pls}).to(dev)
     es, ec = mk(16), mk(19)
     R = b * n_per + min(xf, b) * xn
-    step = us.MapStep(es, ec, dec, bound, 48, 16, 0.06, bench.W, bench.LR, max_rays=R)
+    step = us.MapStep(es, ec, dec, bound, 48, 16, 0.06, bench.W, bench.LR, max_rays=R, deterministic=bool(int(os.environ.get("DET", "0"))))
     c2ws, pd, pc, pr = bench.keyframe_pools(b, bound, 1000, dev)
     win = us.MapWindow(step, c2ws, pd, pc, pr, n_per, joint_opt=bool(joint), cam_lr=1e-3, extra=(xf, xn) if xf else None, has_zero_depth=False)
     return step, win

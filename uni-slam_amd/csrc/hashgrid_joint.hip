@@ -867,11 +867,46 @@ __global__ __launch_bounds__(256) void k_jitems(JLevels lv, uint32_t n_levels, u
 }
 
 
+// torch.optim.Adam of the two tables' param groups (src/Mapper.py:118-126,445) applied INSIDE the sweep (us_hashgrid_bwd_joint_adam): with
+// US_GRID_BWD_OVERWRITE | US_GRID_BWD_DETERMINISTIC every entry of both tables is written exactly once, by the workgroup that owns its
+// bin, at the moment its final sum stands in LDS -- so that workgroup reads p, m, v of the entry and writes them back: no gradient table
+// written (write_grad 0), none read back by an optimiser pass, one kernel boundary less.  The arithmetic per element is adam_segs_body's
+// (render.hip): the same bits as the separate pass.  p == nullptr: off.
+struct JTableAdam {
+    float *pA, *mA, *vA, *pB, *mB, *vB;
+    float lrA, lrB, one_minus_b1, b2, one_minus_b2, eps;
+    const float* step_dev;               // us_adam_step_inc's float[8]: ALREADY advanced for this step
+    int write_grad;
+};
+__device__ __forceinline__ void j_adam2(float g0, float g1, float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, float step_size,
+                                        float bc2_sqrt, const JTableAdam& ta) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 mv = __builtin_nontemporal_load(reinterpret_cast<const f2*>(M)), vv = __builtin_nontemporal_load(reinterpret_cast<const f2*>(V));
+    f2 pv = *reinterpret_cast<const f2*>(P), mo, vo;
+    {
+        const float mi = mv.x + ta.one_minus_b1 * (g0 - mv.x);
+        const float vi = vv.x * ta.b2 + (ta.one_minus_b2 * g0) * g0;
+        const float denom = sqrtf(vi) / bc2_sqrt + ta.eps;
+        pv.x = pv.x + (-step_size) * (mi / denom);
+        mo.x = mi; vo.x = vi;
+    }
+    {
+        const float mi = mv.y + ta.one_minus_b1 * (g1 - mv.y);
+        const float vi = vv.y * ta.b2 + (ta.one_minus_b2 * g1) * g1;
+        const float denom = sqrtf(vi) / bc2_sqrt + ta.eps;
+        pv.y = pv.y + (-step_size) * (mi / denom);
+        mo.y = mi; vo.y = vi;
+    }
+    *reinterpret_cast<f2*>(P) = pv;
+    __builtin_nontemporal_store(mo, reinterpret_cast<f2*>(M)); __builtin_nontemporal_store(vo, reinterpret_cast<f2*>(V));
+}
+
 __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, uint32_t SA, uint32_t SB,
                                                             const uint32_t* __restrict__ items_tab, const uint32_t* __restrict__ hdr,
                                                             const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
                                                             float* __restrict__ gradA,
-                                                            float* __restrict__ gradB, uint16_t* __restrict__ gradB16, int overwrite, int side_sel
+                                                            float* __restrict__ gradB, uint16_t* __restrict__ gradB16, int overwrite, int side_sel,
+                                                            const JTableAdam ta
 #ifdef J_ACC_TIMING
                                                             , unsigned long long* __restrict__ dbg     // timing build (tools/acc_balance.py): per workgroup
 #endif                                                                                                 // start, end (100 MHz ticks), items, records
@@ -888,6 +923,11 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
     __shared__ uint32_t n_items, n_zitems;
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < J_ACC_DOUBLES + 4 * 8; k += J_ACC_THREADS) acc[k] = 0.0;
+    float ssA = 0.0f, ssB = 0.0f, bc2s = 1.0f;                   // Adam in the sweep: step sizes lr / (1 - b1^t), sqrt(1 - b2^t) as k_adam_segs forms them
+    if (ta.pA) {
+        const double* aux = reinterpret_cast<const double*>(ta.step_dev + 2);
+        ssA = (float)((double)ta.lrA / aux[0]); ssB = (float)((double)ta.lrB / aux[0]); bc2s = (float)aux[1];
+    }
     // ---- which items: workgroup b takes the table's indices i G + b on even turns i and i G + (G - 1 - b) on odd ones -- within a turn
     // the items grow with the index (finer levels: more records per bin), and the alternation cancels that trend over a list
     const uint32_t G = gridDim.x;
@@ -971,7 +1011,11 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
             if (e >= hs) continue;
             float* p = gl + (size_t)e * 2u;
             const float v0 = (float)s0, v1 = (float)s1;
-            if (hot) {
+            if (ta.pA && !hot) {                                 // (deterministic mode: no bin is hot)
+                const size_t o = ((size_t)goff + e) * 2u;
+                j_adam2(v0, v1, (side ? ta.pB : ta.pA) + o, (side ? ta.mB : ta.mA) + o, (side ? ta.vB : ta.vA) + o, side ? ssB : ssA, bc2s, ta);
+                if (ta.write_grad) *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
+            } else if (hot) {
                 if (v0 != 0.0f) atomicAdd(p, v0);
                 if (v1 != 0.0f) atomicAdd(p + 1, v1);
             } else if (overwrite) {
@@ -1027,7 +1071,12 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
         float* gl = (((zm >> 24) & 1u) ? gradB : gradA) + (size_t)zitems[JI_GOFF][z] * 2u;
         for (uint32_t loc = tid; loc < znl; loc += J_ACC_THREADS) {
             const uint32_t e = entry_of(loc, zm & 0xFFFFu, (zm >> 16) & 0xFFu);
-            if (e < zhs) {
+            if (e < zhs && ta.pA) {                              // a zero gradient still moves the entry: m and v decay, p follows m
+                const uint32_t zs = (zm >> 24) & 1u;
+                const size_t o = ((size_t)zitems[JI_GOFF][z] + e) * 2u;
+                j_adam2(0.0f, 0.0f, (zs ? ta.pB : ta.pA) + o, (zs ? ta.mB : ta.mA) + o, (zs ? ta.vB : ta.vA) + o, zs ? ssB : ssA, bc2s, ta);
+                if (ta.write_grad) *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
+            } else if (e < zhs) {
                 *reinterpret_cast<float2*>(gl + (size_t)e * 2u) = make_float2(0.0f, 0.0f);
                 if (((zm >> 24) & 1u) && gradB16) *reinterpret_cast<uint32_t*>(gradB16 + ((size_t)zitems[JI_GOFF][z] + e) * 2u) = 0u;
             }
@@ -1237,7 +1286,7 @@ extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, con
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
                      float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
-                     int64_t plane_stride = 0, uint16_t* gradB16 = nullptr) {
+                     int64_t plane_stride = 0, uint16_t* gradB16 = nullptr, const JTableAdam* adam = nullptr) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -1294,8 +1343,11 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
 #endif
                            );
     const uint32_t n_acc_items = side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA);
+    JTableAdam ta;
+    memset(&ta, 0, sizeof(ta));
+    if (adam) ta = *adam;
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, (uint32_t)ACC_EXTRA_MAX,
-                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, gradB16, overwrite, side_sel
+                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, gradB16, overwrite, side_sel, ta
 #ifdef J_ACC_TIMING
                        , (unsigned long long*)((char*)workspace + us_hashgrid_joint_workspace_bytes(a, b, n) - (size_t)J_ACCP_GROUPS * 32u)   // the last 64 KiB of the
 #endif                                                                                                                                          // record planes: never reached
@@ -1308,6 +1360,23 @@ extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* 
                                      const float* dL_dyB, int64_t n, float* gradA, float* gradB, int flags, void* workspace,
                                      size_t workspace_bytes, void* stream) {
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
+                                          int64_t n, float* gradA, float* gradB, const us_table_adam_desc* adam, int flags, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    US_REQUIRE(adam && adam->pA && adam->mA && adam->vA && adam->pB && adam->mB && adam->vB && adam->step_dev, US_ERR_NULL, "us_hashgrid_bwd_joint_adam: NULL pointer");
+    US_REQUIRE((flags & US_GRID_BWD_OVERWRITE) && (flags & US_GRID_BWD_DETERMINISTIC), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint_adam: the optimiser step is applied by the one workgroup that owns an entry, once: needs US_GRID_BWD_OVERWRITE and "
+               "US_GRID_BWD_DETERMINISTIC (no bin split over several workgroups) -- in the scan call as well");
+    US_REQUIRE(((((uintptr_t)adam->pA) | ((uintptr_t)adam->mA) | ((uintptr_t)adam->vA) | ((uintptr_t)adam->pB) | ((uintptr_t)adam->mB) | ((uintptr_t)adam->vB)) & 7u) == 0 &&
+               (((uintptr_t)adam->step_dev) & 7u) == 0, US_ERR_SHAPE, "us_hashgrid_bwd_joint_adam: tables, moments and step_dev must be 8-byte aligned");
+    US_REQUIRE(n > 0, US_ERR_SHAPE, "us_hashgrid_bwd_joint_adam: n %lld (an empty batch has no sweep to carry the step: use the optimiser's own launch)", (long long)n);
+    JTableAdam ta;
+    ta.pA = adam->pA; ta.mA = adam->mA; ta.vA = adam->vA; ta.pB = adam->pB; ta.mB = adam->mB; ta.vB = adam->vB;
+    ta.lrA = (float)adam->lrA; ta.lrB = (float)adam->lrB; ta.one_minus_b1 = (float)(1.0 - adam->beta1); ta.b2 = (float)adam->beta2;
+    ta.one_minus_b2 = (float)(1.0 - adam->beta2); ta.eps = (float)adam->eps; ta.step_dev = adam->step_dev; ta.write_grad = adam->write_grad;
+    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, nullptr, &ta);
 }
 
 extern "C" int us_hashgrid_bwd_joint_img(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,

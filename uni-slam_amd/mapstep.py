@@ -34,6 +34,16 @@ def _align(n, a=2048):     # 2048 floats: 16-byte alignment and equal shards for
 
 
 class MapStep:
+    # flags of the table gradient's bin policy: what the constructor / enable_grad_image asked for, plus "no split bins" while the tables'
+    # optimiser step rides in the accumulate pass (fuse_adam): scan call and gradient call must agree
+    @property
+    def _det(self):
+        return self._det_base | (L.US_GRID_BWD_DETERMINISTIC if getattr(self, "fuse_adam", False) else 0)
+
+    @_det.setter
+    def _det(self, v):
+        self._det_base = int(v)
+
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
                  joint=None, deterministic=False, max_workspace_bytes=4 << 30, dp_mode="local_fast"):
@@ -82,6 +92,18 @@ class MapStep:
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
         self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
+        # fuse_adam (r5; single process, joint kernels; set it before the first iteration): iterate() applies the tables' Adam step INSIDE the
+        # accumulate pass's sweep (us_hashgrid_bwd_joint_adam) -- no gradient table written, none read back, the optimiser launch shrinks to
+        # the decoders' (and poses') group.  Every entry is then written exactly once, by one workgroup: bins are not split
+        # (US_GRID_BWD_DETERMINISTIC, measured at no cost: 0.4886 against 0.4884 ms at 4096 x 64, 0.508 against 0.507 with all rays from ONE
+        # camera).  Same bits as the separate pass (tests/test_gpu_window.py).  OFF by default -- measured, MI355X, 4096 x 64 replayed: the
+        # accumulate pass grows from 78 to 121 us (the sweep's reads of p, m, v sit between two barriers of every item, their latency
+        # exposed; no registers left to prefetch them: 63 of 64), the optimiser launch falls from 55 to ~8 us: 0.4926 ms against 0.4884
+        # for the separate streaming pass, which moves its 362 MB at 6.5 TB/s with the decoders' group riding along; with the small launch
+        # on the side stream beside the table gradient: 0.505 (a queue crossing).  keep_table_grad: also write the gradient tables.
+        self.fuse_adam = False
+        self.keep_table_grad = False
+        self._tables_stepped = False
         # budget of the table gradient's scratch (it is sized for the worst case, 8 records per point and level: 3 KB per point for
         # both grids).  A batch that would need more is walked in ranges of rays (us_hashgrid_bwd_*_range), the first range writing
         # the gradient tables, the others adding: 4096 x 64 needs 0.8 GB, the 32 768-ray sweep point 6.6 GB -> two ranges.
@@ -502,6 +524,7 @@ class MapStep:
         # backward adds to, was cleared by the previous adam_step (zero_grad_mask) -- or is cleared here.
         binned = self.ws is not None
         self._folded = False
+        self._tables_stepped = False
         self._grad_image_written = False                         # only the branch that writes the bf16 image in THIS call sets it (dist.GradComm.announce)
         # Single process, joint grids, two streams: the small reductions of the backward pass (decoder-gradient partials, d(beta), Adam's
         # step count) are taken off the critical path -- they run on the side stream beside the table gradient instead of ahead of it.
@@ -625,6 +648,19 @@ class MapStep:
                 self._timed("hashgrid_bwd_joint_sdf", lambda: lib.us_hashgrid_bwd_joint(
                     ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
                     jflags | L.US_GRID_BWD_ONLY_A | L.US_GRID_BWD_RECORDS_READY, P(self.ws), self.ws_bytes, st))
+            elif fold and self.fuse_adam and self.group is None:
+                # the tables' optimiser step rides in the accumulate pass's sweep; adam_step() then only takes the decoders' (and poses') group
+                if not self._step_advanced:                      # (one-stream mode: the forward pass queued no increment)
+                    L.check(lib.us_adam_step_inc(P(self.step_dev), 0.9, 0.999, st), "us_adam_step_inc")
+                    self._step_advanced = True
+                self._tables_stepped = True
+                f = self.lr_factor
+                ta = L.TableAdamDesc(off(fl, self.o_tab_s), off(self.m, self.o_tab_s), off(self.v, self.o_tab_s), off(fl, self.o_tab_c),
+                                     off(self.m, self.o_tab_c), off(self.v, self.o_tab_c), self.lr["sdf_grid"] * f, self.lr["color_grid"] * f, 0.9, 0.999, 1e-8,
+                                     P(self.step_dev), 1 if self.keep_table_grad else 0)
+                self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint_adam(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
+                                                                                         off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
+                                                                                         ctypes.byref(ta), jflags, P(self.ws), self.ws_bytes, st))
             else:
                 self._timed("hashgrid_bwd_joint", lambda: lib.us_hashgrid_bwd_joint(ds, dc, P(self.pts), P(self.d_feat_s), P(self.d_feat_c), N,
                                                                                     off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c), jflags,
@@ -646,33 +682,40 @@ class MapStep:
         if on_ready is not None:
             on_ready(self.grad[:self.o_tab_c])
         if ray_grads:
-            if not hasattr(self, "g_o") or self.g_o.shape[0] < R:
-                f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
-                self.g_o, self.g_d, self.d_pts = f(self.max_rays, 3), f(self.max_rays, 3), None
-            if getattr(self, "_dpts_valid", False):
-                # the decoders' backward launch has left the two grids' shares of dL/d(point): add, reduce to the rays
-                self._timed("ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, R, S, P(self.g_o),
-                                                                              P(self.g_d), st))
-            elif self._dydx_valid and S <= 128:
-                # the forward pass left dy/dx: one streaming launch contracts it with dL/dy and reduces to the rays
-                self._timed("hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s),
-                                                                                    P(self.dydx_c), R, S, P(self.z), self.bhost, P(self.g_o), P(self.g_d),
-                                                                                    None, st))
-            elif lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
-                # both grids' input gradient and its reduction to the rays in ONE launch (no [N,3] round trip, no second gather launch)
-                self._timed("hashgrid_bwd_input_rays", lambda: lib.us_hashgrid_bwd_input_rays(
-                    ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_s), P(self.d_feat_c), R, S, P(self.z),
-                    self.bhost, P(self.g_o), P(self.g_d), None, 3, st))
-            else:
-                if self.d_pts is None or self.d_pts.shape[0] < R:
-                    self.d_pts = torch.empty((self.max_rays, S, 3), dtype=torch.float32, device=self.device)
-                L.check(lib.us_hashgrid_bwd_input_gather(ds, off(fl, self.o_tab_s), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
-                        "us_hashgrid_bwd_input_gather")
-                L.check(lib.us_hashgrid_bwd_input_gather(dc, off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_c), N, P(self.d_pts),
-                                                         3 | L.US_GRID_ACCUMULATE, st), "us_hashgrid_bwd_input_gather")
-                L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
+            self._ray_gradients(R)
         self.n_rays = R
         return self.loss
+
+    def _ray_gradients(self, R):
+        """dL/d(rays_o), dL/d(rays_d) of the last backward pass into self.g_o / self.g_d (on the current stream)"""
+        lib, st, P, S, N, fl = L.lib(), L.stream(), L.ptr, self.S, R * self.S, self.flat
+        off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
+        if not hasattr(self, "g_o") or self.g_o.shape[0] < R:
+            f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
+            self.g_o, self.g_d, self.d_pts = f(self.max_rays, 3), f(self.max_rays, 3), None
+        if getattr(self, "_dpts_valid", False):
+            # the decoders' backward launch has left the two grids' shares of dL/d(point): add, reduce to the rays
+            self._timed("ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, R, S, P(self.g_o),
+                                                                          P(self.g_d), st))
+        elif self._dydx_valid and S <= 128:
+            # the forward pass left dy/dx: one streaming launch contracts it with dL/dy and reduces to the rays
+            self._timed("hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s),
+                                                                                P(self.dydx_c), R, S, P(self.z), self.bhost, P(self.g_o), P(self.g_d),
+                                                                                None, st))
+        elif lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
+            # both grids' input gradient and its reduction to the rays in ONE launch (no [N,3] round trip, no second gather launch)
+            self._timed("hashgrid_bwd_input_rays", lambda: lib.us_hashgrid_bwd_input_rays(
+                ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_s), P(self.d_feat_c), R, S, P(self.z),
+                self.bhost, P(self.g_o), P(self.g_d), None, 3, st))
+        else:
+            if self.d_pts is None or self.d_pts.shape[0] < R:
+                self.d_pts = torch.empty((self.max_rays, S, 3), dtype=torch.float32, device=self.device)
+            L.check(lib.us_hashgrid_bwd_input_gather(ds, off(fl, self.o_tab_s), P(self.pts), P(self.d_feat_s), N, P(self.d_pts), 3, st),
+                    "us_hashgrid_bwd_input_gather")
+            L.check(lib.us_hashgrid_bwd_input_gather(dc, off(fl, self.o_tab_c), P(self.pts), P(self.d_feat_c), N, P(self.d_pts),
+                                                     3 | L.US_GRID_ACCUMULATE, st), "us_hashgrid_bwd_input_gather")
+            L.check(lib.us_ray_points_bwd(P(self.d_pts), P(self.z), self.bhost, R, S, P(self.g_o), P(self.g_d), st), "us_ray_points_bwd")
 
     def _backward_in_ranges(self, R, on_ready):
         """the decoders' backward passes over the whole batch, then the table gradients range by range (scratch within max_workspace_bytes)"""
@@ -735,6 +778,11 @@ class MapStep:
         f = self.lr_factor
         groups = ((0, self.n_dec, self.lr["decoders"] * f), (self.o_tab_s, self.es.desc.n_params, self.lr["sdf_grid"] * f),
                   (self.o_tab_c, self.ec.desc.n_params, self.lr["color_grid"] * f))
+        stepped, self._tables_stepped = self._tables_stepped, False     # backward(fold=True) with fuse_adam: the tables' step is done
+        if stepped and (ranges is not None or part is not None):
+            raise L.UniSlamHipError("MapStep.adam_step: the tables were stepped inside the accumulate pass (fuse_adam); ranges / parts do not apply")
+        if stepped:
+            groups = (groups[0], (self.o_tab_s, 0, 0.0), (self.o_tab_c, 0, 0.0))
         if ranges is None and getattr(self, "_folded", False):
             # backward(fold=True) left the decoders' partial rows and beta's per-ray partials: their sums and the decoder group's Adam
             # in one launch, then the tables
@@ -754,6 +802,8 @@ class MapStep:
             if self.one_launch_adam:
                 # the whole optimiser step in ONE launch: the decoder group's reductions + Adam ride as three slices of the tables' launch
                 tabs = list(groups)[1:]
+                if stepped:                                      # the accumulate pass's sweep has applied the tables' step (fuse_adam)
+                    tabs = [(self.o_tab_s, 0, 0.0), (self.o_tab_c, 0, 0.0)]
                 I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
                 L.check(lib.us_adam_step_model(*dec_args, P(self.flat), P(self.grad), P(self.m), P(self.v), 2, I64(*[g[0] for g in tabs]),
                                                I64(*[g[1] for g in tabs]), DBL(*[g[2] for g in tabs]), 0.9, 0.999, 1e-8, P(self.step_dev),
