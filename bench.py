@@ -648,10 +648,10 @@ def run_rank(args):
     if sharded:
         comm = "fp32"                                                                    # (the reduce-scatter works in place on the fp32 buffer)
 
-    def build_step(prec, table_std=None, group="auto", dp_mode=None, sharded_adam=None):
+    def build_step(prec, table_std=None, group="auto", dp_mode=None, sharded_adam=None, tcnn=False, hidden=None):
         torch.manual_seed(0)
-        cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": False}, "model": {"mlp_precision": prec}}
-        dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden, truncation=0.06, n_blocks=2).to(dev)
+        cfg = {"grid_mode": "hash_grid", "grid": {"tcnn_network": bool(tcnn)}, "model": {"mlp_precision": prec}}
+        dec = us.Decoders(cfg, c_dim=32, hidden_size=args.hidden if hidden is None else hidden, truncation=0.06, n_blocks=2).to(dev)
         es, ec = mk(16), mk(19)                                                          # replica.yaml:29-30
         if table_std is not None:                                                        # "trained-like" N(0, 0.1) tables
             with torch.no_grad():
@@ -733,6 +733,20 @@ def run_rank(args):
     el = float(t.item())
     ms = 1e3 * el / args.steps
 
+    # per-step GPU time of the same runner, one HIP event pair per step on the launch stream (median, p10, p90), AFTER the timed
+    # region (the K timed steps above are bracketed by nothing but the barrier + synchronize of the contract)
+    ev_stats = None
+    if world == 1:
+        n_ev = max(50, args.steps)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for a_, b_ in evs:
+            a_.record(); nxt(); b_.record()
+        torch.cuda.synchronize()
+        ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
+        ev_stats = {"n": n_ev, "median_ms": q(0.5), "p10_ms": q(0.1), "p90_ms": q(0.9), "min_ms": ts[0], "max_ms": ts[-1],
+                    "note": "HIP events around every step (graph launch to graph end on the launch stream), a separate pass after the timed region"}
+
     kern = None
     if not args.no_probe:
         # ---- the kernels' own durations: a SEPARATE pass after the timed region (every rank runs it: the iterations hold the
@@ -762,14 +776,16 @@ def run_rank(args):
                "config": {"workload": "BASELINE configs[1]: Replica room0, 4096 rays x 64 samples (48 stratified + 16 surface), "
                                       "L=16 F=2 hash grids log2T 16 (sdf) / 19 (colour) res 816, 2 hidden x %d MLP decoders with bias, "
                                       "mapping iteration = pixel draw+ray gather+sample+encode+decode+composite+loss+backward+dense Adam, camera poses "
-                                      "fixed (joint_opt off: the iteration of the first five keyframes, src/Mapper.py:519; the joint_opt iteration, "
-                                      "which also optimises the window's poses, is timed beside it under `joint_opt`)" % args.hidden,
+                                      "fixed (joint_opt off: the iteration of the first five keyframes, src/Mapper.py:519).  The reference's STEADY STATE "
+                                      "is the joint_opt iteration (configs/UNISLAM.yaml:50: its default), which also optimises the window's poses: "
+                                      "timed in the same run as `steady_state_joint_opt` (~15 %% slower); Replica's own 1 x 16 tcnn-layout f16 decoders: "
+                                      "`replica_tcnn_decoders`; the reference's own call sequence under autograd: `drop_in_api`" % args.hidden,
                           "rays_per_gpu": R, "samples_per_ray": S, "points_per_gpu": N, "n_params": int(step.n_flat),
                           "batch": (f"fresh per step: {n_per} pixels from each of {N_KEYFRAMES} keyframe pools of {P} pixels, drawn inside the step (us_window_sample: "
                                     f"counter-based draw + gather + rotation + sampling, one launch of the replayed graph)"
                                     if fresh else "one fixed batch re-rendered every step"),
                           "parallelism": f"dp{world} (frames/rays sharded, {comm_desc})"},
-               "rays_per_s_per_gpu": R / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss),
+               "rays_per_s_per_gpu": R / (ms / 1e3), "mapping_iter_ms": ms, "final_loss": float(loss), "step_time_hip_events": ev_stats,
                "launch": (("hipGraph replay of MapWindow.iterate (joint_opt off): pixel draw + gather + sampling in one launch, then MapStep.iterate"
                            if world == 1 else "hipGraph segments of MapWindow.iterate between the collectives (statistics all-reduce, gradient segments)")
                           if (use_graph and fresh and launch_kind["graph"]) else "hipGraph replay of MapStep.iterate" if (use_graph and not fresh) else "eager")}
@@ -839,8 +855,25 @@ def run_rank(args):
                 rec["fp32_decoders"] = side_run(build_step("fp32")[0])
             # tables with "trained-like" N(0, 0.1) entries: alpha is no longer degenerate, the gradients are dense in value
             rec["trained_like_tables"] = side_run(build_step(args.mlp_precision, table_std=0.1)[0])
+            # Replica's OWN decoder configuration (configs/Replica/replica.yaml:33 grid.tcnn_network True -> src/networks/decoders.py:50-70):
+            # FullyFusedMLP 32 -> 16 -> out, ONE hidden layer, no bias, half-precision arithmetic (f16 MFMA here), tcnn's flat parameter
+            # layout -- SURVEY 8d's "ref-exact (16-wide)" run of cfg2 beside the "2x32" headline
+            try:
+                r_ = side_run(build_step("f16", tcnn=True, hidden=16)[0])
+                r_["decoders"] = "tcnn layout (sdf_decoder.params / color_decoder.params), 1 hidden x 16, no bias, f16 MFMA operands (us_mlp_desc US_PREC_F16)"
+                rec["replica_tcnn_decoders"] = r_
+            except Exception as e:                            # report, do not hide
+                rec["replica_tcnn_decoders"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_extras:
             rec["joint_opt"] = joint_opt_bench(us, lambda: build_step(args.mlp_precision), bound, dev, args.steps, args.warmup)
+            jo = rec["joint_opt"].get("4096_rays_16_keyframes", {})
+            if "joint_opt_iteration_ms" in jo:
+                # the reference's STEADY-STATE iteration (joint_opt: True is its default, configs/UNISLAM.yaml:50, active from the fifth keyframe,
+                # src/Mapper.py:519): the same batch with the window's poses optimised along -- promoted to the top level beside `value`
+                rec["steady_state_joint_opt"] = {"ms_per_step": jo["joint_opt_iteration_ms"], "rays_per_s": jo["rays_per_s"],
+                                                 "what": "the headline's batch (4096 rays x 64 over 16 keyframes) with joint_opt on: pose -> rays, the pose "
+                                                         "gradients and the poses' Adam group inside the iteration; `value` above is the iteration "
+                                                         "with the poses fixed (the first five keyframes of a run)"}
         if world == 1 and not args.no_extras:
             rec["drop_in_api"] = drop_in_bench(us, dev, args.mlp_precision, args.hidden, bound, mk, max(10, args.steps // 2), args.warmup, R, n_strat, n_imp)
         if world == 1 and not args.no_extras:

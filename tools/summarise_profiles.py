@@ -36,6 +36,8 @@ avg = lambda v: sum(v) / max(len(v), 1)
 # the first launches of a run are not the steady state (set-up iterations on placeholder rays): per-kernel MEDIANS for the byte counters
 med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
 lines = [f"# rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA), bench.py --steps 20 --warmup 5 --no-overlap, MI355X, {T}",
+         "# (--no-overlap: every launch on ONE stream, so that a counter row belongs to one kernel -- the optimiser then shows as k_adam_segs<4> + k_mlp_reduce_pair + k_step_inc,",
+         "#  where the replayed headline runs ONE k_adam_segs_model<4> launch (profiles/*_timeline.txt); same bytes, same kernels otherwise)",
          "# per-launch medians of the byte counters, averages of the rest. FETCH_SIZE / WRITE_SIZE in KiB as reported (raw): on gfx950 FETCH_SIZE reports half of the bytes of a wide",
          "# coalesced streaming read (MI355X_MICROARCH.md, HBM); traffic.json doubles it for the kernels whose reads are such streams.",
          "# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)  (MFMA pipe busy cycles per SIMD-cycle while the CU is busy)",
