@@ -38,8 +38,9 @@ def timed(fn, k=200):
 
 step, win = build()
 e = timed(win.iterate)
-win.capture()
-g = timed(win.replay)
+U = int(os.environ.get("UNROLL", "1"))
+win.capture(unroll=U)
+g = timed(win.replay, k=200 // U) / U
 print(f"window b={b} n_per={n_per} extra={xf}x{xn} rays={win.R} joint_opt={joint}: eager {e:.4f} ms, graph {g:.4f} ms, "
       f"{win.R / g / 1e3:.2f} M rays/s; loss {float(win.replay()):.5f}")
 if os.environ.get("PROBE"):

@@ -192,14 +192,21 @@ class MapWindow:
         return self._launches(t_rand, zero_depth_draws, device_draw=indices is None)
 
     # ------------------------------------------------------------------------------------------ hipGraph
-    def capture(self, t_rand=False, device_draw=True, collectives=None):
+    def capture(self, t_rand=False, device_draw=True, collectives=None, unroll=1):
         """capture _launches() (the zero-depth branch included: its row count stays on the device) into a hipGraph: replay() is ONE graph
         launch, pixel draw included (device_draw; False: replay(indices) / torch.randint fill the static index tensors first).  The
         jitter comes from the in-kernel generator (varied per replay by the device-side step count) unless t_rand=True: then
         self.t_rand [R,S] (and, for a window with depth holes, self.zd_draws) are static inputs to fill.  The model, the optimiser state
         and the poses are left as they were.  With a process group on the MapStep every rank must call capture() (its warm-up iterations
-        hold collectives); collectives: see below."""
+        hold collectives); collectives: see below.
+        unroll (single process, r5): the graph holds `unroll` CONSECUTIVE iterations and replay() runs them all (the loss of the last one
+        is returned) -- between two graph launches the GPU idles for ~15 us (profiles/r05_timeline.txt), between two kernels of one graph
+        for none to 6: a mapped frame's 15 iterations are three launches of a 5-iteration graph.  Every iteration of the graph draws its own
+        pixels and jitter (the seeds baked into the launches differ, and the device-side step count is mixed in)."""
         from .graph import CapturedIteration, SegmentedGraph
+        unroll = int(unroll)
+        if unroll < 1 or (unroll > 1 and (self.step.group is not None or t_rand or not device_draw)):
+            raise L.UniSlamHipError("MapWindow.capture: unroll > 1 needs a single process and the in-kernel pixel draw and jitter")
         s = self.step
         if s._step_advanced:
             raise L.UniSlamHipError("MapWindow.capture: a forward pass of the MapStep is pending; finish its optimiser step first")
@@ -241,7 +248,11 @@ class MapWindow:
                     torch.cuda.current_stream().wait_stream(side)
                 restore()                                        # the real learning rates are what the capture records
             if s.group is None:
-                graph = CapturedIteration(lambda: self._launches(device_draw=self._device_draw), warmup=0)
+                def body():
+                    for _ in range(unroll):
+                        out = self._launches(device_draw=self._device_draw)
+                    return out
+                graph = CapturedIteration(body, warmup=0)
             else:
                 # data-parallel: the rank-local launches as hipGraph segments, the collectives between them (dist.dp_iterate's `cut`)
                 # collectives "inside" (default over RCCL): the process group's calls are captured INTO the one graph -- RCCL kernels as graph
@@ -264,7 +275,7 @@ class MapWindow:
         finally:
             restore()                                            # (the capture pass does not execute; its host-side counters are undone)
             s.probe = keep[11]
-        self._graph, self._graph_gen = graph, s.generation
+        self._graph, self._graph_gen, self._unroll = graph, s.generation, unroll
 
     def replay(self, indices=None, indices_extra=None):
         if self._graph is None:
@@ -282,7 +293,7 @@ class MapWindow:
                 raise L.UniSlamHipError("MapWindow.replay: this graph draws its pixels itself; capture(device_draw=False) to pass indices")
         else:
             self.draw(indices, indices_extra)
-        self.step.opt_step += 1
+        self.step.opt_step += getattr(self, "_unroll", 1)
         return self._graph.replay()
 
     # ------------------------------------------------------------------------------------------ results
