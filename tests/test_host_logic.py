@@ -1,0 +1,69 @@
+"""
+Host logic that needs no GPU: the product fails LOUDLY without the HIP path (no CPU fallback anywhere), the analytic test scene refuses
+camera paths that leave the room, the registry that keeps captured graphs alive, and the reference-shaped optimiser's bookkeeping.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_drop_in_modules_refuse_cpu_tensors():
+    import unislam_amd as us
+    cfg = {"rendering": {"perturb": True, "n_stratified": 8, "n_importance": 4}, "scale": 1, "grid_mode": "hash_grid", "grid": {"tcnn_network": False}}
+    dec = us.Decoders(cfg, c_dim=32, truncation=0.06)
+    ecfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 10, "base_resolution": 16, "per_level_scale": 1.3}
+    es, ec = us.HashGridEncoding(3, ecfg), us.HashGridEncoding(3, ecfg)
+    with pytest.raises(us.UniSlamHipError):
+        dec(torch.rand(7, 3), ([es], [ec]))                      # CPU tensors: no fallback, an error
+    p = torch.nn.Parameter(torch.randn(5))
+    opt = us.optim.Adam([{"params": [p], "lr": 0}])
+    opt.param_groups[0]["lr"] = 0.1                              # the reference sets the learning rates afterwards (src/Mapper.py:123-126)
+    opt.step()                                                   # no gradient yet: nothing to do, no error
+    p.grad = torch.ones(5)
+    with pytest.raises(us.UniSlamHipError):
+        opt.step()
+    with pytest.raises(ValueError):
+        us.optim.Adam([p], weight_decay=0.1)
+    # the nn.Linear parameters' packing order is the kernels' flat layout: weights (last matrix padded to 16 rows), then biases
+    lay = dec._pack_layout()
+    n_s, n_c = dec._n_packed
+    assert n_s == 32 * 16 + 16 * 16 + 16 * 16 + 16 + 16 + 16 and n_c == n_s
+    offs = [o for _, o in lay]
+    assert offs == sorted(offs) and offs[0] == 0 and lay[6][1] == n_s and len(lay) == 12
+    assert [tuple(p_.shape) for p_, _ in lay[:6]] == [(16, 32), (16, 16), (1, 16), (16,), (16,), (1,)]
+
+
+def test_synthetic_room_refuses_paths_through_walls():
+    from unislam_amd.synthetic import SyntheticRoom
+    with pytest.raises(ValueError, match="frame 191"):
+        SyntheticRoom(n_frames=300, H=6, W=8, device="cpu")      # the default arc leaves the room through y = 3.0 at frame 194
+    ok = SyntheticRoom(n_frames=190, H=6, W=8, device="cpu")
+    assert float(ok.sdf(ok.poses[:, :3, 3]).min()) >= 0.05
+    loop = SyntheticRoom(n_frames=660, H=6, W=8, device="cpu", path="loop", clearance=0.2)       # three rounds of the closed loop
+    pos = loop.poses[:, :3, 3]
+    assert float(loop.sdf(pos).min()) > 0.2
+    assert float((pos[220] - pos[0]).norm()) < 0.03 and float((pos[440] - pos[0]).norm()) < 0.03 and float((pos[110] - pos[0]).norm()) > 1.3
+    with pytest.raises(ValueError):
+        SyntheticRoom(n_frames=5, H=6, W=8, device="cpu", path="spiral")
+    # the default path is what it always was (fixture g15 and the slam tests' bounds rest on it)
+    assert torch.allclose(ok.poses[0, :3, 3], torch.tensor([1.3, 1.2, -0.1])) and abs(float(ok.poses[100, 0, 3]) - 3.14) < 0.01
+
+
+def test_graph_registry_keeps_and_releases():
+    from unislam_amd import graph
+    n0 = len(graph._KEEP)
+    sentinel = object()
+    graph._keep(sentinel)
+    assert len(graph._KEEP) == n0 + 1 and graph._KEEP[-1] is sentinel
+    assert graph.release_all() == n0 + 1 and graph._KEEP == []
+    os.environ["US_KEEP_GRAPHS"] = "0"                           # the old behaviour, for reproducing the runtime fault
+    try:
+        graph._keep(sentinel)
+        assert graph._KEEP == []
+    finally:
+        del os.environ["US_KEEP_GRAPHS"]
