@@ -91,6 +91,7 @@ SIGNATURES = {
     "us_hashgrid_fwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.POINTER(TableAdamDesc), c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_bwd_joint_part": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_int, c_int, c_int, c_f]),
     "us_hashgrid_bwd_joint_img": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_range": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_binned_range": (c_int, [_GP, c_f, c_f, c_i64, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
                                                             const uint32_t* __restrict__ totals, const uint32_t* __restrict__ dw_off,
                                                             uint32_t row_stride, uint16_t* __restrict__ rec_e, uint2* __restrict__ rec_v,
-                                                            uint32_t rec_cap, int64_t plane_stride
+                                                            uint32_t rec_cap, int64_t plane_stride, uint32_t level_lo
 #ifdef J_WR_TIMING
                                                             , unsigned long long* __restrict__ dbg     // timing build (tools/wr_levels.py): [workgroup][24] clocks
 #endif
@@ -618,15 +618,16 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         if (tid == nlb - 1u) ttot[par] = excl + c;
     };
 
+    // levels [level_lo, n_levels): the whole pass, or one part of a pass cut by levels (us_hashgrid_bwd_joint_part)
     uint32_t c1, p1, o1, t1, incl1;
     float dn[4];
-    setup_load(0, c1, p1, o1, t1);
-    load_dy(0, dn);
-    setup_scan(0, c1, incl1);
+    setup_load(level_lo, c1, p1, o1, t1);
+    load_dy(level_lo, dn);
+    setup_scan((int)(level_lo & 1u), c1, incl1);
     __syncthreads();
-    setup_fin(0, 0, c1, p1, o1, t1, incl1);
+    setup_fin((int)(level_lo & 1u), level_lo, c1, p1, o1, t1, incl1);
 
-    for (uint32_t level = 0; level < n_levels; ++level) {
+    for (uint32_t level = level_lo; level < n_levels; ++level) {
 #ifdef J_WR_TIMING
         if (threadIdx.x == 0) dbg[24 * blockIdx.x + 1 + level] = wall_clock64();
 #endif
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
                                                             const uint16_t* __restrict__ rec_e, const uint2* __restrict__ rec_v,
                                                             float* __restrict__ gradA,
                                                             float* __restrict__ gradB, uint16_t* __restrict__ gradB16, int overwrite, int side_sel,
-                                                            const JTableAdam ta
+                                                            const JTableAdam ta, uint32_t binA0, uint32_t binA1, uint32_t binB0, uint32_t binB1
 #ifdef J_ACC_TIMING
                                                             , unsigned long long* __restrict__ dbg     // timing build (tools/acc_balance.py): per workgroup
 #endif                                                                                                 // start, end (100 MHz ticks), items, records
@@ -933,12 +934,17 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
     const uint32_t G = gridDim.x;
     const uint32_t n_x = min(hdr[0], e_max);
     const uint32_t nA = n_x + SA, nB = n_x + SB;                 // items of grid A / B: extra chunks + bins with a side in that grid
-    const uint32_t lo = side_sel == 1 ? nA : 0u, cnt_u = side_sel < 0 ? nA + nB : (side_sel ? nB : nA);
+    // the items taken: grid A's indices [a0, a1) and grid B's [b0, b1) of its list -- everything (or one grid: side_sel), or, for a pass cut by
+    // levels (binA1 > binA0 or binB1 > binB0; unsplit bins: no extra chunks), the bins [binX0, binX1) of each grid's level-by-level list
+    const bool part = binA1 > binA0 || binB1 > binB0;
+    const uint32_t a0 = part ? n_x + binA0 : 0u, a1 = part ? n_x + binA1 : (side_sel == 1 ? 0u : nA);
+    const uint32_t b0 = part ? n_x + binB0 : 0u, b1 = part ? n_x + binB1 : (side_sel == 0 ? 0u : nB);
+    const uint32_t cntA = a1 - a0, cnt_u = cntA + (b1 - b0);
     if (tid < 64) {                                              // wave 0, lane i: the workgroup's i-th turn
         const uint32_t turn = tid;
         const uint32_t v = turn * G + ((turn & 1u) ? G - 1u - blockIdx.x : blockIdx.x);
         const bool in = turn < (uint32_t)J_ACCP_MAXI && v < cnt_u;
-        const uint32_t u = in ? lo + v : 0u;
+        const uint32_t u = in ? (v < cntA ? a0 + v : nA + b0 + (v - cntA)) : 0u;
         uint32_t fields[JI_FIELDS];
 #pragma unroll
         for (int f = 0; f < JI_FIELDS; ++f) fields[f] = items_tab[(size_t)f * JT_CAP + u];
@@ -1286,7 +1292,8 @@ extern "C" int us_hashgrid_dydx_rays(uint32_t n_levels, const float* dL_dyA, con
 
 static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
                      float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream, bool scan_only,
-                     int64_t plane_stride = 0, uint16_t* gradB16 = nullptr, const JTableAdam* adam = nullptr) {
+                     int64_t plane_stride = 0, uint16_t* gradB16 = nullptr, const JTableAdam* adam = nullptr, int part_lo = 0, int part_hi = 0,
+                     int part_what = 0) {
     if (n < 0) return US_ERR_SHAPE;
     J_CHECK_PAIR("us_hashgrid_bwd_joint");
     hipStream_t s = (hipStream_t)stream;
@@ -1335,19 +1342,30 @@ static int bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* 
     US_REQUIRE(!((flags & US_GRID_BWD_ONLY_A) && (flags & US_GRID_BWD_ONLY_B)), US_ERR_CONFIG, "us_hashgrid_bwd_joint: ONLY_A and ONLY_B are exclusive");
     US_REQUIRE(!(flags & US_GRID_BWD_RECORDS_READY) || side_sel >= 0, US_ERR_CONFIG,
                "us_hashgrid_bwd_joint: US_GRID_BWD_RECORDS_READY continues a call that summed the other grid (US_GRID_BWD_ONLY_A / _B)");
-    if (!(flags & US_GRID_BWD_RECORDS_READY))
-        hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
-                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n
+    // a pass cut by levels (us_hashgrid_bwd_joint_part): levels [part_lo, part_hi), record pass and / or accumulate pass
+    const bool part = part_what != 0;
+    uint32_t binA0 = 0, binA1 = 0, binB0 = 0, binB1 = 0;
+    if (part) {
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t sa = (lv.l[l].flags & J_SPLIT) ? 1u << lv.l[l].lgA : 1u << lv.l[l].lgB, sb_ = 1u << lv.l[l].lgB;
+            if ((int)l < part_lo) { binA0 += sa; binB0 += sb_; }
+            if ((int)l < part_hi) { binA1 += sa; binB1 += sb_; }
+        }
+    }
+    if (!(flags & US_GRID_BWD_RECORDS_READY) && (!part || (part_what & 1)))
+        hipLaunchKernelGGL(k_jwrite, dim3(w.n_rows), dim3(J_ROW_POINTS), 0, s, lv, part ? (uint32_t)part_hi : L, x, dL_dyA, dL_dyB, n, clamp, w.counts, w.prefix, w.totals, w.dw_off,
+                           w.stride, w.rec_e, w.rec_v, w.rec_cap, plane_stride > 0 ? plane_stride : n, part ? (uint32_t)part_lo : 0u
 #ifdef J_WR_TIMING
                            , (unsigned long long*)((char*)workspace + ((us_hashgrid_joint_workspace_bytes(a, b, n) & ~(size_t)7) - (size_t)393216))   // the planes' unused end
 #endif
                            );
-    const uint32_t n_acc_items = side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA);
+    if (part && !(part_what & 2)) { US_CHECK_LAUNCH("us_hashgrid_bwd_joint_part"); return US_OK; }
+    const uint32_t n_acc_items = part ? (binA1 - binA0) + (binB1 - binB0) : (side_sel < 0 ? 2u * ACC_EXTRA_MAX + SA + SB : ACC_EXTRA_MAX + (side_sel ? SB : SA));
     JTableAdam ta;
     memset(&ta, 0, sizeof(ta));
     if (adam) ta = *adam;
     hipLaunchKernelGGL(k_jaccum_p, dim3(n_acc_items < J_ACCP_GROUPS ? n_acc_items : J_ACCP_GROUPS), dim3(J_ACC_THREADS), 0, s, (uint32_t)ACC_EXTRA_MAX,
-                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, gradB16, overwrite, side_sel, ta
+                       SA, SB, w.items, w.hdr, w.rec_e, w.rec_v, gradA, gradB, gradB16, overwrite, side_sel, ta, binA0, binA1, binB0, binB1
 #ifdef J_ACC_TIMING
                        , (unsigned long long*)((char*)workspace + us_hashgrid_joint_workspace_bytes(a, b, n) - (size_t)J_ACCP_GROUPS * 32u)   // the last 64 KiB of the
 #endif                                                                                                                                          // record planes: never reached
@@ -1377,6 +1395,19 @@ extern "C" int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_d
     ta.lrA = (float)adam->lrA; ta.lrB = (float)adam->lrB; ta.one_minus_b1 = (float)(1.0 - adam->beta1); ta.b2 = (float)adam->beta2;
     ta.one_minus_b2 = (float)(1.0 - adam->beta2); ta.eps = (float)adam->eps; ta.step_dev = adam->step_dev; ta.write_grad = adam->write_grad;
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, nullptr, &ta);
+}
+
+extern "C" int us_hashgrid_bwd_joint_part(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
+                                          int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, int level_lo,
+                                          int level_hi, int what, void* stream) {
+    US_REQUIRE(a && level_lo >= 0 && level_lo < level_hi && level_hi <= (int)a->n_levels, US_ERR_SHAPE, "us_hashgrid_bwd_joint_part: levels [%d, %d)", level_lo, level_hi);
+    US_REQUIRE(what >= 1 && what <= 3, US_ERR_CONFIG, "us_hashgrid_bwd_joint_part: what = %d (1 record pass, 2 accumulate pass, 3 both)", what);
+    US_REQUIRE((flags & US_GRID_BWD_COUNTED) && (flags & US_GRID_BWD_SCANNED) && (flags & US_GRID_BWD_DETERMINISTIC) && (flags & US_GRID_BWD_OVERWRITE) &&
+               !(flags & (US_GRID_BWD_ONLY_A | US_GRID_BWD_ONLY_B | US_GRID_BWD_RECORDS_READY)), US_ERR_CONFIG,
+               "us_hashgrid_bwd_joint_part: a part of a pass whose counts and scans are in place (COUNTED | SCANNED), with unsplit bins "
+               "(DETERMINISTIC: a level's bins are then its only items) in OVERWRITE mode, both grids");
+    US_REQUIRE(n > 0, US_ERR_SHAPE, "us_hashgrid_bwd_joint_part: n %lld", (long long)n);
+    return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, nullptr, nullptr, level_lo, level_hi, what);
 }
 
 extern "C" int us_hashgrid_bwd_joint_img(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
