@@ -655,24 +655,79 @@ def g13():
     npz("g13_scene", **out)
 
 
-from g15_settings import G15  # noqa: E402  (shared with tests/test_gpu_slam.py::test_g15_sequence_against_the_reference_loop)
+from g15_settings import G15, G16  # noqa: E402  (shared with tests/test_gpu_slam.py: the HIP drivers run with the same numbers)
 
 
-def g15():
+class _DrawLog:
+    """Records every draw the reference's loop takes from torch's global CPU generator -- torch.randint (pixel indices: src/common.py:116,155),
+    torch.rand (z jitter: src/utils/Renderer.py:55; sample_pdf: src/common.py:64), torch.randperm (keyframe pools: src/Mapper.py:335,518; the
+    tracking-back draw: :257) -- WITHOUT touching the stream: per call its kind, two size numbers, the f64 sum of what was drawn and the frame it
+    belongs to.  A replay (tests/test_gpu_slam.py: a torch.Generator set to the stored state, consumed in the same order by the HIP drivers)
+    is checked against this log call by call."""
+    KINDS = ("randint", "rand", "randperm")
+
+    def __init__(self):
+        self.kind, self.a, self.b, self.sum, self.frame, self.cur = [], [], [], [], [], 0
+        self.loss, self.loss_frame = [], []                              # every scalar the loop calls .backward() on, in order (the iterations' losses)
+
+    def __enter__(self):
+        self._orig = {k: getattr(torch, k) for k in self.KINDS}
+        for k in self.KINDS:
+            setattr(torch, k, self._wrap(k))
+        self._backward = torch.Tensor.backward
+        log, orig_backward = self, self._backward
+
+        def backward(t, *a, **kw):
+            log.loss.append(float(t.detach())); log.loss_frame.append(log.cur)
+            return orig_backward(t, *a, **kw)
+        torch.Tensor.backward = backward
+        return self
+
+    def __exit__(self, *a):
+        for k, f in self._orig.items():
+            setattr(torch, k, f)
+        torch.Tensor.backward = self._backward
+        return False
+
+    def _wrap(self, k):
+        orig = self._orig[k]
+
+        def f(*args, **kw):
+            out = orig(*args, **kw)
+            if k == "randint":
+                a, b = int(args[0]), out.numel()
+            elif k == "rand":
+                a, b = (int(out.shape[0]), int(out.shape[1])) if out.dim() == 2 else (out.numel(), 1)
+            else:
+                a, b = int(args[0]), 0
+            self.kind.append(self.KINDS.index(k)); self.a.append(a); self.b.append(b)
+            self.sum.append(float(out.double().sum())); self.frame.append(self.cur)
+            return out
+        return f
+
+    def arrays(self):
+        return dict(draw_kind=np.array(self.kind, dtype=np.uint8), draw_a=np.array(self.a, dtype=np.int32), draw_b=np.array(self.b, dtype=np.int32),
+                    draw_sum=np.array(self.sum, dtype=np.float64), draw_frame=np.array(self.frame, dtype=np.int32),
+                    loss_log=np.array(self.loss, dtype=np.float32), loss_frame=np.array(self.loss_frame, dtype=np.int32))
+
+
+def _ref_loop(P):
     """
     The reference's LOOP over a sequence: Tracker.run's body (Tracker.py:296-366: constant-speed prediction, a fresh pose Adam with
-    betas (0.5, 0.999), optimize_tracking per iteration, the minimum-loss pose) and Mapper.run's body (Mapper.py:494-533: first-frame
-    factor / iterations, joint_opt from the fifth keyframe, optimize_mapping with the REAL keyframe_selection_LC, the new keyframe's
-    10 % pool) alternating frame by frame as the two processes do through their wait loops (every_frame = 1: each frame is tracked, then
-    mapped).  optimize_tracking / optimize_mapping / keyframe_selection_LC / create_optimizer / sdf_losses are the reference's methods on
-    dummy selves; the encoders are the oracle's CPU hash grids, the frames come from the build's analytic SyntheticRoom (its parameters
-    are the fixture's inputs).  Stored: the estimated trajectory, the keyframe list, per-frame errors, the ATE.
+    betas (0.5, 0.999), optimize_tracking per iteration, the minimum-loss pose, the uncertainty-triggered doubling of the iteration counts
+    and the tracking-back flag) and Mapper.run's body (Mapper.py:494-533: first-frame factor / iterations, joint_opt from the fifth keyframe,
+    optimize_mapping with the REAL keyframe_selection_LC, the new keyframe's 10 % pool) alternating frame by frame as the two processes do
+    through their wait loops.  optimize_tracking / optimize_mapping / keyframe_selection_LC / create_optimizer / sdf_losses are the
+    reference's methods on dummy selves; the encoders are the oracle's CPU hash grids, the frames come from the build's analytic
+    SyntheticRoom (its parameters are the fixture's inputs).  Returns the fixture's arrays: the estimated trajectory, the keyframe list,
+    per-frame errors and flags, iteration counts, the windows keyframe_selection_LC chose, the generator state at the loop's start and
+    the log of every draw (_DrawLog).
     """
     import copy
     sys.path.insert(0, ROOT)
     import unislam_amd  # noqa: F401  (the analytic scene only; nothing of the HIP path runs here)
     from unislam_amd.synthetic import SyntheticRoom
-    P, T_, M_ = G15, G15["tracking"], G15["mapping"]
+    T_, M_ = P["tracking"], P["mapping"]
     torch.manual_seed(P["seed"])
     NF, H, W = P["n_frames"], P["H"], P["W"]
     room = SyntheticRoom(n_frames=NF, H=H, W=W, fov_deg=P["fov_deg"], device="cpu", tex_freq=P["tex_freq"])
@@ -686,6 +741,7 @@ def g15():
     with torch.no_grad():                                                   # tcnn's initial range, from a generator of this fixture's own
         enc_s.params.copy_((torch.rand(enc_s.params.shape, generator=gi) * 2 - 1) * 1e-4)
         enc_c.params.copy_((torch.rand(enc_c.params.shape, generator=gi) * 2 - 1) * 1e-4)
+    table0_sums = (float(enc_s.params.detach().double().sum()), float(enc_c.params.detach().double().sum()))    # (a replay restates this draw)
     cfg = make_cfg(P["n_stratified"], P["n_importance"], True)
     cfg["mapping"] = {"lr": {k: M_[k] for k in ("decoders_lr", "hash_grids_lr", "c_hash_grids_lr")}}
     u = types.SimpleNamespace(bound=bound, device=DEV, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy)
@@ -711,76 +767,128 @@ def g15():
                                **{k: M_[k] for k in ("w_color", "w_depth", "w_sdf_fs", "w_sdf_center", "w_sdf_tail")}, **common)
     mp.sdf_losses = lambda *a: RefMapper.sdf_losses(mp, *a)
     mp.create_optimizer = lambda c, f: RefMapper.create_optimizer(mp, c, f)
-    mp.keyframe_selection_LC = lambda *a, **k: RefMapper.keyframe_selection_LC(mp, *a, **k)
+    selections = []
+
+    def select(*a, **k):                                                    # (the reference's method; what it returned is kept for the fixture)
+        sel = RefMapper.keyframe_selection_LC(mp, *a, **k)
+        selections.append([int(x) for x in sel])
+        return sel
+    mp.keyframe_selection_LC = select
     num_cam_iters, m_iters = T_["iters"], M_["iters"]
     init_phase = True
-    tb_flags, joint_flags, window_sizes = [], [], []
-    for idx in range(NF):
-        _, color, depth, gt_c2w, rays_d = room[idx]
-        # ---- Tracker.run body (Tracker.py:296-366)
-        dec_t.load_state_dict(dec.state_dict())                             # update_params_from_mapping (:246-258): the grids are shared objects
-        if idx == 0:
-            c2w = gt_c2w.clone()
-        else:
-            pre_c2w = est[idx - 1].unsqueeze(0)
-            if T_["const_speed_assumption"] and idx - 2 >= 0:
-                pre_poses = RC.matrix_to_cam_pose(torch.stack([est[idx - 2], pre_c2w.squeeze(0)], dim=0))
-                cam_pose = 2 * pre_poses[1:] - pre_poses[0:1]
+    tb_flags, joint_flags, window_sizes, track_iters, map_iters, mapped, unc_mean, unc_evals = [], [], [], [], [], [], [], []
+    rng_state = torch.get_rng_state().clone()                                # the global generator as the loop finds it
+    snaps, pool_idx = {}, []
+    log = _DrawLog()
+    with log:
+        for idx in range(NF):
+            log.cur = idx
+            _, color, depth, gt_c2w, rays_d = room[idx]
+            if idx in P.get("snapshots", ()):
+                # the loop's whole state as frame idx finds it: a replay can START here (tests: one frame from the reference's own state)
+                tag = f"snap{idx}__"
+                snaps.update({tag + "table_sdf": enc_s.params.detach().clone(), tag + "table_color": enc_c.params.detach().clone(),
+                              tag + "rng_state": torch.get_rng_state().clone(), tag + "draw_pos": len(log.kind), tag + "loss_pos": len(log.loss),
+                              tag + "num_cam_iters": num_cam_iters, tag + "m_iters": m_iters, tag + "tracking_back": int(tracking_back[0]),
+                              tag + "n_keyframes": len(mp.keyframe_list), tag + "n_mapped": len(mapped),
+                              tag + "kf_est_c2w": torch.stack([d["est_c2w"].detach() for d in mp.keyframe_dict])})
+                snaps.update({tag + "dec__" + k.replace(".", "__"): v.detach().clone() for k, v in dec.state_dict().items()})
+            # ---- Tracker.run body (Tracker.py:296-366)
+            dec_t.load_state_dict(dec.state_dict())                             # update_params_from_mapping (:246-258): the grids are shared objects
+            n_it, w_frame = 0, float("nan")
+            if idx == 0:
+                c2w = gt_c2w.clone()
             else:
-                cam_pose = RC.matrix_to_cam_pose(pre_c2w)
-            T = torch.nn.Parameter(cam_pose[:, -3:].clone())
-            R = torch.nn.Parameter(cam_pose[:, :4].clone())
-            opt = torch.optim.Adam([{"params": [T], "lr": T_["lr_T"], "betas": (0.5, 0.999)}, {"params": [R], "lr": T_["lr_R"], "betas": (0.5, 0.999)}])
-            current_min_loss, cam_iter = float("inf"), 0
-            while cam_iter < num_cam_iters:
-                cam_pose = torch.cat([R, T], -1)
-                loss, rendered_weights = RefTracker.optimize_tracking(trk, cam_pose, color[None], depth[None], T_["pixels"], opt)
-                if loss < current_min_loss:
-                    current_min_loss, candidate = loss, cam_pose.clone().detach()
-                cam_iter += 1
-                if cam_iter == num_cam_iters - 1:
-                    w = rendered_weights.detach().mean()
-                    if T_["activated_mapping_mode"] and w > T_["uncertainty_ts"]:
-                        num_cam_iters, m_iters = T_["iters"] * 2, M_["iters"] * 2
-                        tracking_back[0] = 1
-                    else:
-                        num_cam_iters, m_iters = T_["iters"], M_["iters"]
-                        tracking_back[0] = 0
-            c2w = RC.cam_pose_to_matrix(candidate).squeeze(0)
-        est[idx] = c2w.detach().clone()
-        tb_flags.append(int(tracking_back[0]))
-        # ---- Mapper.run body (Mapper.py:494-533)
-        if idx % M_["every_frame"] == 0 or int(tracking_back[0]) == 1 or idx == NF - 1:
-            cur_c2w = est[idx]
-            lr_factor = M_["lr_first_factor"] if init_phase else M_["lr_factor"]
-            iters = M_["iters_first"] if init_phase else m_iters
-            mp.joint_opt = (len(mp.keyframe_list) > 4) and M_["joint_opt"]
-            joint_flags.append(int(mp.joint_opt))
-            window_sizes.append(len(mp.keyframe_list))
-            cur_c2w = RefMapper.optimize_mapping(mp, iters, lr_factor, idx, color, depth, gt_c2w, mp.keyframe_dict, mp.keyframe_list, cur_c2w, rays_d)
-            if mp.joint_opt:
-                est[idx] = cur_c2w.detach()
-            if idx % M_["keyframe_every"] == 0 or int(tracking_back[0]) == 1:
-                mp.keyframe_list.append(idx)
-                n_save = int(H * W * 0.1)
-                ind = torch.randperm(H * W)[:n_save]
-                mp.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "color": color.reshape(-1, 3)[ind], "depth": depth.reshape(-1)[ind],
-                                         "est_c2w": cur_c2w.detach().clone(), "rays_d": rays_d.reshape(-1, 3)[ind]})
-            init_phase = False
+                pre_c2w = est[idx - 1].unsqueeze(0)
+                if T_["const_speed_assumption"] and idx - 2 >= 0:
+                    pre_poses = RC.matrix_to_cam_pose(torch.stack([est[idx - 2], pre_c2w.squeeze(0)], dim=0))
+                    cam_pose = 2 * pre_poses[1:] - pre_poses[0:1]
+                else:
+                    cam_pose = RC.matrix_to_cam_pose(pre_c2w)
+                T = torch.nn.Parameter(cam_pose[:, -3:].clone())
+                R = torch.nn.Parameter(cam_pose[:, :4].clone())
+                opt = torch.optim.Adam([{"params": [T], "lr": T_["lr_T"], "betas": (0.5, 0.999)}, {"params": [R], "lr": T_["lr_R"], "betas": (0.5, 0.999)}])
+                current_min_loss, cam_iter = float("inf"), 0
+                while cam_iter < num_cam_iters:
+                    cam_pose = torch.cat([R, T], -1)
+                    loss, rendered_weights = RefTracker.optimize_tracking(trk, cam_pose, color[None], depth[None], T_["pixels"], opt)
+                    if loss < current_min_loss:
+                        current_min_loss, candidate = loss, cam_pose.clone().detach()
+                    cam_iter += 1
+                    if cam_iter == num_cam_iters - 1:
+                        w = rendered_weights.detach().mean()
+                        w_frame = float(w)
+                        unc_evals.append((idx, cam_iter, w_frame))          # (a frame that doubles its count is evaluated again at the new count - 1)
+                        if T_["activated_mapping_mode"] and w > T_["uncertainty_ts"]:
+                            num_cam_iters, m_iters = T_["iters"] * 2, M_["iters"] * 2
+                            tracking_back[0] = 1
+                        else:
+                            num_cam_iters, m_iters = T_["iters"], M_["iters"]
+                            tracking_back[0] = 0
+                n_it = cam_iter
+                c2w = RC.cam_pose_to_matrix(candidate).squeeze(0)
+            est[idx] = c2w.detach().clone()
+            tb_flags.append(int(tracking_back[0])); track_iters.append(n_it); unc_mean.append(w_frame)
+            # ---- Mapper.run body (Mapper.py:494-533)
+            if idx % M_["every_frame"] == 0 or int(tracking_back[0]) == 1 or idx == NF - 1:
+                cur_c2w = est[idx]
+                lr_factor = M_["lr_first_factor"] if init_phase else M_["lr_factor"]
+                iters = M_["iters_first"] if init_phase else m_iters
+                mp.joint_opt = (len(mp.keyframe_list) > 4) and M_["joint_opt"]
+                joint_flags.append(int(mp.joint_opt))
+                window_sizes.append(len(mp.keyframe_list))
+                mapped.append(idx); map_iters.append(int(iters))
+                if len(mp.keyframe_dict) == 0:
+                    selections.append([])                                   # (no selection call on an empty keyframe list, Mapper.py:303-304)
+                cur_c2w = RefMapper.optimize_mapping(mp, iters, lr_factor, idx, color, depth, gt_c2w, mp.keyframe_dict, mp.keyframe_list, cur_c2w, rays_d)
+                if mp.joint_opt:
+                    est[idx] = cur_c2w.detach()
+                if idx % M_["keyframe_every"] == 0 or int(tracking_back[0]) == 1:
+                    mp.keyframe_list.append(idx)
+                    n_save = int(H * W * 0.1)
+                    ind = torch.randperm(H * W)[:n_save]
+                    pool_idx.append(ind.clone())
+                    mp.keyframe_dict.append({"gt_c2w": gt_c2w, "idx": idx, "color": color.reshape(-1, 3)[ind], "depth": depth.reshape(-1)[ind],
+                                             "est_c2w": cur_c2w.detach().clone(), "rays_d": rays_d.reshape(-1, 3)[ind]})
+                init_phase = False
+            if idx in P.get("snapshots", ()):
+                snaps[f"snap{idx}__kf_est_c2w_after"] = torch.stack([d["est_c2w"].detach() for d in mp.keyframe_dict])
     err = (est[:, :3, 3] - gts[:, :3, 3]).norm(dim=-1)
     _, c0, d0, _, _ = room[0]
-    npz("g15_sequence", gt_c2w=gts, est_c2w=est, keyframe_list=np.array(mp.keyframe_list), tracking_back=np.array(tb_flags),
-        joint_opt=np.array(joint_flags), keyframes_before_mapping=np.array(window_sizes), lc_cnt=int(mp.LC_cnt[0]), err_m=err,
-        ate_rmse_m=float(err.pow(2).mean().sqrt()), intr=np.array([H, W, fx, fy, cx, cy]), frame0_depth_row=d0[H // 2], frame0_color_row=c0[H // 2],
-        res=res, kf_est_c2w=torch.stack([d["est_c2w"] for d in mp.keyframe_dict]),
-        **{"dec0__" + k.replace(".", "__"): v for k, v in dec0.items()},
-        **{"dec1__" + k.replace(".", "__"): v.detach() for k, v in dec.state_dict().items()})
-    print(f"g15: ATE {100 * float(err.pow(2).mean().sqrt()):.2f} cm, max {100 * float(err.max()):.2f} cm at frame {int(err.argmax())}, "
-          f"{len(mp.keyframe_list)} keyframes, LC {int(mp.LC_cnt[0])}")
+    sel_off = np.cumsum([0] + [len(s_) for s_ in selections])
+    out = dict(gt_c2w=gts, est_c2w=est, keyframe_list=np.array(mp.keyframe_list), tracking_back=np.array(tb_flags),
+               joint_opt=np.array(joint_flags), keyframes_before_mapping=np.array(window_sizes), lc_cnt=int(mp.LC_cnt[0]), err_m=err,
+               ate_rmse_m=float(err.pow(2).mean().sqrt()), intr=np.array([H, W, fx, fy, cx, cy]), frame0_depth_row=d0[H // 2], frame0_color_row=c0[H // 2],
+               res=res, kf_est_c2w=torch.stack([d["est_c2w"] for d in mp.keyframe_dict]),
+               **{"dec0__" + k.replace(".", "__"): v for k, v in dec0.items()},
+               **{"dec1__" + k.replace(".", "__"): v.detach() for k, v in dec.state_dict().items()})
+    # (r6) what a draw-for-draw replay needs and checks: the generator's state at the loop's start, the draw log, the loop's decisions
+    out.update(rng_state=rng_state.numpy(), track_iters=np.array(track_iters), mapped_frames=np.array(mapped), map_iters=np.array(map_iters),
+               unc_mean=np.array(unc_mean, dtype=np.float64), unc_evals=np.array(unc_evals, dtype=np.float64).reshape(-1, 3), selected_flat=np.array([x for s_ in selections for x in s_], dtype=np.int32),
+               selected_off=sel_off.astype(np.int32), table_sdf_sum=table0_sums[0], table_color_sum=table0_sums[1], **log.arrays())
+    if snaps:
+        out.update(snaps, kf_pool_idx=torch.stack(pool_idx).to(torch.int32))
+    print(f"ref loop: ATE {100 * float(err.pow(2).mean().sqrt()):.2f} cm, max {100 * float(err.max()):.2f} cm at frame {int(err.argmax())}, "
+          f"{len(mp.keyframe_list)} keyframes {mp.keyframe_list}, LC {int(mp.LC_cnt[0])}, tracking back at {[i for i, f in enumerate(tb_flags) if f]}, "
+          f"{len(log.kind)} draws")
+    return out
+
+
+def g15():
+    """the reference's loop (_ref_loop) with oracle/g15_settings.py G15: every frame tracked, mapped and kept as a keyframe"""
+    npz("g15_sequence", **_ref_loop(G15))
+
+
+def g16():
+    """the reference's loop with G16: a mapped frame every 3rd, a keyframe every 2nd of those, ACTIVATED MAPPING on (uncertainty-triggered
+    iteration doubling + tracking back: Tracker.py:352-363, Mapper.py:253-272,516) and a mapping window small enough for keyframe_selection_LC
+    to choose while tracking back; + SNAPSHOTS of the loop's whole state at the start of a few frames, so that a replay can start from the
+    reference's own state: one frame of the loop at a time, free of the Adam-amplified divergence a whole-sequence replay accumulates"""
+    npz("g16_policy", **_ref_loop(G16))
 
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()

@@ -29,6 +29,65 @@ DEFAULTS = {   # configs/UNISLAM.yaml + configs/Replica/replica.yaml
 }
 
 
+class TorchDraws:
+    """
+    The REFERENCE's random stream for the loop (r6): every draw the reference's tracker and mapper take from torch's global CPU generator, taken
+    here from a torch.Generator in the same order and with the same shapes --
+        tracking iteration     torch.randint(crop pixels, (n,))                                      src/common.py:116
+                               torch.rand((R', S))  for the R' rays that passed the pre-filter        src/utils/Renderer.py:55
+        keyframe selection     torch.randint(H * W, (50,)); torch.randperm(nonzero) while tracking back   src/Mapper.py:197-199,257
+        pool of a frame        torch.randperm(H * W)[:10 %]                                          src/Mapper.py:335,518
+        mapping iteration      torch.randint(P, (n * b,)) [+ torch.randint(P, (200 * 10,))]            src/common.py:155, src/Mapper.py:385-387
+                               torch.rand((R', S)) [+ the two draws of the zero-depth branch]          src/utils/Renderer.py:55,117; src/common.py:64
+    -- so that a SLAM(draws=TorchDraws(state=...)) run renders the same pixels with the same jitter as a reference run that started from
+    that generator state.  With a draw source the drivers run eagerly (one host read of the pre-filter flags per iteration: the number of
+    jitter rows is data-dependent in the reference); without one (default) every draw happens inside the kernels and the loops replay graphs.
+    """
+
+    def __init__(self, generator=None, state=None, seed=None):
+        self.g = generator if generator is not None else torch.Generator()
+        if state is not None:
+            self.g.set_state(torch.as_tensor(state, dtype=torch.uint8))
+        elif seed is not None:
+            self.g.manual_seed(int(seed))
+
+    def randint(self, high, n):
+        return torch.randint(int(high), (int(n),), generator=self.g)
+
+    def rand(self, rows, cols):
+        return torch.rand((int(rows), int(cols)), generator=self.g)
+
+    def randperm(self, n):
+        return torch.randperm(int(n), generator=self.g)
+
+
+def _jitter_rows(draws, valid, gd, S, n_strat, n_imp, perturb, has_zero):
+    """the jitter of one iteration from the draw source, laid out for the kernels: t_rand [R, S] with the reference's row k in the k-th
+    row that passed the pre-filter AND carries a depth (src/utils/Renderer.py:87-101), and -- windows with depth holes -- the zero-depth
+    branch's two draws by COMPACTED row of !(depth > 0) (us_zero_depth_resample), the reference's row j in the j-th of them that passed"""
+    v = valid.bool().cpu()
+    d = gd.cpu() > 0
+    R = v.shape[0]
+    nz = v & d
+    t_rand = torch.zeros((R, S))
+    if perturb:
+        t_rand[nz] = draws.rand(int(nz.sum()), S)
+    zd = None
+    z0 = v & ~d
+    if has_zero:
+        tu, u = torch.zeros((R, n_strat)), torch.zeros((R, n_imp))
+        if bool(z0.any()):
+            comp = torch.cumsum((~d).int(), 0) - 1                      # compacted row of every row without a depth
+            rows = comp[z0]
+            if perturb:
+                tu[rows] = draws.rand(int(z0.sum()), n_strat)
+            u[rows] = draws.rand(int(z0.sum()), n_imp)
+        zd = (tu, u)
+    elif bool(z0.any()):
+        raise RuntimeError("draw replay: a ray without a depth in a window flagged has_zero_depth=False")
+    return t_rand, zd
+
+
 def keyframe_overlap(pts, keyframes_c2ws, H, W, fx, fy, cx, cy, edge=20):
     """Mapper.py:217-240: fraction of the sample points `pts` [M,3] that project inside each keyframe's image."""
     device = pts.device
@@ -48,7 +107,7 @@ def keyframe_overlap(pts, keyframes_c2ws, H, W, fx, fy, cx, cy, edge=20):
 
 
 def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, device,
-                          tracking_back=False, activated_mapping_mode=True, LC=True, num_samples=8, num_rays=50):
+                          tracking_back=False, activated_mapping_mode=True, LC=True, num_samples=8, num_rays=50, draws=None):
     """
     Mapper.keyframe_selection_LC (src/Mapper.py:177-274): indices into the keyframe list (excluding its last two entries) of the
     keyframes to optimise with the current view: ALL of them ("global"), from the loop partner on after a loop closure, or the
@@ -58,7 +117,9 @@ def keyframe_selection_LC(num, idx, gt_color, gt_depth, c2w, num_keyframes, keyf
     H, W, fx, fy, cx, cy = cam
     if gt_depth.is_cuda and torch.is_tensor(estimate_c2w_list) and estimate_c2w_list.is_cuda:
         return _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, tracking_back,
-                                          activated_mapping_mode, LC, num_samples, num_rays)
+                                          activated_mapping_mode, LC, num_samples, num_rays, draws)
+    if draws is not None:
+        raise RuntimeError("keyframe_selection_LC: a draw source is served by the device path (CUDA tensors)")
     rays_o, rays_d, gd, _ = get_samples(0, H, 0, W, num_rays, H, W, fx, fy, cx, cy, c2w.unsqueeze(0), gt_depth.unsqueeze(0),
                                         gt_color.unsqueeze(0), device)
     gd = gd.reshape(-1, 1)
@@ -107,7 +168,7 @@ def rigid_inverse(c2ws):
 
 
 def _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_list, estimate_c2w_list, cam, tracking_back,
-                               activated_mapping_mode, LC, num_samples, num_rays):
+                               activated_mapping_mode, LC, num_samples, num_rays, draws=None):
     """keyframe_selection_LC for device tensors: the pixel draw, ONE launch for the overlap of every keyframe (us_keyframe_overlap: rays,
     points, rigid inverse and projection on the fly), ONE read of the K shares; the selection rules on the host as above"""
     from . import _lib as L
@@ -117,8 +178,9 @@ def _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_
     loop, selected = False, list(range(0, num))
     pct = torch.zeros(max(K, 0), device=dev)
     vals = []
+    pix_drawn = draws.randint(H * W, num_rays).to(dev) if draws is not None else None    # (the reference draws whatever K is: Mapper.py:197)
     if K > 0:
-        pix = torch.randint(H * W, (num_rays,), device=dev)                              # common.py:116: the draw of get_samples
+        pix = pix_drawn if draws is not None else torch.randint(H * W, (num_rays,), device=dev)   # common.py:116: the draw of get_samples
         kf = torch.as_tensor(keyframe_list[:K], dtype=torch.int64, device=dev)
         L.check(L.lib().us_keyframe_overlap(L.ptr(L.f32(c2w)), L.ptr(L.f32(gt_depth)), L.ptr(pix), num_rays, num_samples, L.host_floats([fx, fy, cx, cy]),
                                             H, W, 20, L.ptr(L.f32(estimate_c2w_list)), L.ptr(kf), K, L.ptr(pct), L.stream()), "us_keyframe_overlap")
@@ -128,6 +190,8 @@ def _keyframe_selection_device(num, idx, gt_depth, c2w, num_keyframes, keyframe_
             selected, loop = list(range(0, num))[best:], True
     if tracking_back and activated_mapping_mode:
         selected = []
+        if draws is not None:
+            draws.randperm(sum(1 for x in vals if x != 0))                               # Mapper.py:256-257: drawn, then overridden by the ranking
         if K > 0:
             order = sorted(range(K), key=lambda k: vals[k], reverse=True)
             selected = [k for k in order if vals[k] > 0.00][:num_keyframes]
@@ -164,6 +228,12 @@ class Mapper:
     def _pool_into(self, row, color, depth, rays_d):
         """10 % of the pixels of a frame as its sampling pool (Mapper.py:329-337,516-523), written into arena row `row`; returns whether the
         pool holds pixels without a depth (one host read per pool: it picks the window's graph)"""
+        d = self.s.draws
+        if d is not None:                                                               # the reference's cut: torch.randperm(H * W)[:10 %] (Mapper.py:335,518)
+            ind = d.randperm(depth.numel())[:self.arena.P].to(depth.device)
+            dp = depth.reshape(-1)[ind]
+            self.arena.put(row, color.reshape(-1, 3)[ind], dp, rays_d.reshape(-1, 3)[ind])
+            return bool((dp <= 0).any())
         self._pool_count = getattr(self, "_pool_count", 0) + 1
         seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._pool_count) & (2 ** 64 - 1)
         return bool(int(self.arena.cut(row, color, depth, rays_d, seed)))
@@ -180,7 +250,7 @@ class Mapper:
             self.step.reset_optimizer(lr_factor)                                        # the learning rates the graph records
             win = ArenaWindow(self.step, self.arena, c["pixels"], 2000 if extra_on else 0, joint_opt=joint, cam_lr=c["joint_opt_cam_lr"],
                               has_zero_depth=has_zero)
-            if bool(c.get("graph_replay", True)):
+            if bool(c.get("graph_replay", True)) and self.s.draws is None:
                 win.capture()
             self._wins[key] = win
         return win
@@ -229,7 +299,7 @@ class Mapper:
         else:
             optimize_frame, _, loop = keyframe_selection_LC(len(kd) - 2, idx, cur_color, cur_depth, cur_c2w, c["mapping_window_size"] - 1,
                                                             kl, s.estimate_c2w_list, s.cam, dev, s.tracking_back,
-                                                            s.cfg["tracking"]["activated_mapping_mode"], c["LC"])
+                                                            s.cfg["tracking"]["activated_mapping_mode"], c["LC"], draws=s.draws)
             self.LC_cnt += int(loop)
         if len(kl) > 1:
             optimize_frame = sorted(optimize_frame + [len(kl) - 1] + [len(kl) - 2])
@@ -254,8 +324,11 @@ class Mapper:
         self._mark("optimiser reset + bind")
         # the loop of :366-445: pose -> rays, render, loss, backward, pose step and Adam are HIP launches on static buffers, one graph
         step = win.replay if win._graph is not None else win.iterate
+        if s.draws is not None:
+            step = lambda: self._iterate_drawn(win)
         for _ in range(int(iters)):
             step()
+        s.history["mapped"].append(dict(idx=int(idx), iters=int(iters), frames=list(optimize_frame), joint=bool(joint), lr_factor=float(lr_factor)))
         self._mark("iterations")
         if joint:
             opt = win.c2ws()                                                            # put the updated camera poses back (:447-457)
@@ -263,6 +336,20 @@ class Mapper:
             cur_c2w = opt[-1]
         self._mark("pose write-back")
         return cur_c2w
+
+    def _iterate_drawn(self, win):
+        """one mapping iteration with the pixels and the jitter of the draw source (TorchDraws): src/common.py:155, src/Mapper.py:385-387,
+        src/utils/Renderer.py:55 in the reference's order"""
+        d, st, dev = self.s.draws, self.step, self.s.device
+        ia = d.randint(win.P, win.b * win.n_per).to(dev)
+        ib = d.randint(win.P, win.extra[0] * win.extra[1]).to(dev) if win.extra else None
+        win.draw(ia, ib)
+        valid, gd = win.probe_valid()
+        t_rand, zd = _jitter_rows(d, valid, gd, st.S, st.n_strat, st.n_imp, st.perturb, win.has_zero)
+        zd = None if zd is None else (zd[0].to(dev), zd[1].to(dev))
+        loss = win.iterate(ia, ib, t_rand=t_rand.to(dev), zero_depth_draws=zd)
+        self.s.history["losses"].append(float(loss))
+        return loss
 
     def map_frame(self, idx, color, depth, gt_c2w, rays_d):
         """one pass of the Mapper.run loop body for frame idx (Mapper.py:494-533)"""
@@ -335,6 +422,8 @@ class Tracker:
                 self._capture(k, begin)
             return self._graphs[k].replay()
 
+        if s.draws is not None:
+            run = lambda k: [self._iterate_drawn(n_pix) for _ in range(k)][-1]
         it = 0
         while it < self.num_cam_iters:                                                  # re-read: the count may double mid-frame
             # the minimum-loss candidate (:346-348) is kept by the pose step's launch: step.min_loss / step.best_pose, on the device
@@ -350,7 +439,21 @@ class Tracker:
                 else:
                     self.num_cam_iters = c["iters"]
                     s.m_iters, s.tracking_back = s.cfg["mapping"]["iters"], False
+        s.history["track_iters"][idx] = it
         return cam_pose_to_matrix(self.step.best_pose.reshape(1, 7))[0]
+
+    def _iterate_drawn(self, n_pix):
+        """one tracking iteration with the pixels and the jitter of the draw source (TorchDraws): src/common.py:116, src/utils/Renderer.py:55"""
+        d, st, dev = self.s.draws, self.step, self.s.device
+        H, W, eh, ew = st.frame
+        pix = d.randint((H - 2 * eh) * (W - 2 * ew), n_pix).to(dev)
+        v = st.probe_valid(n_pix, pix).bool().cpu()
+        t_rand = torch.zeros((n_pix, st.S))
+        if st.perturb:
+            t_rand[v] = d.rand(int(v.sum()), st.S)
+        out = st.iterate_fused(n_pix, t_rand=t_rand.to(dev), indices=pix)
+        self.s.history["losses"].append(float(out[0]))
+        return out
 
 
     def _capture(self, k, begin):
@@ -394,8 +497,12 @@ class SLAM:
     hash grids / decoders: the modules the reference builds at src/UNISLAM.py:241-259.
     """
 
-    def __init__(self, frames, cam, hash_grid_sdf, hash_grid_color, decoders, bound, cfg=None):
+    def __init__(self, frames, cam, hash_grid_sdf, hash_grid_color, decoders, bound, cfg=None, draws=None):
+        """draws: None (default: pixels and jitter are drawn inside the kernels, the loops replay captured graphs) | a TorchDraws: the
+        reference's random stream, consumed as its loop consumes it (eager iterations; for draw-for-draw comparisons with a reference run)"""
         import copy
+        self.draws = draws
+        self.history = {"track_iters": {}, "tracking_back": {}, "mapped": [], "losses": []}          # the loop's decisions, for logs and tests
         self.frames, self.cam = frames, cam
         self.cfg = copy.deepcopy(DEFAULTS)
         for k, v in (cfg or {}).items():
@@ -411,10 +518,14 @@ class SLAM:
         self.m_iters, self.tracking_back = self.cfg["mapping"]["iters"], False
         self.mapper, self.tracker = Mapper(self), Tracker(self)
 
-    def run(self, n_frames=None, log=None):
+    def run(self, n_frames=None, log=None, start=0, total=None):
+        """frames [start, n_frames) of the sequence; total: the sequence's length where it is not n_frames (its last frame is always
+        mapped, src/Mapper.py:487-488).  start > 0 continues a run whose state the caller has put in place (estimate_c2w_list[:start], the
+        mapper's keyframes, the iteration counts)."""
         every = self.cfg["mapping"]["every_frame"]
         n = len(self.frames) if n_frames is None else n_frames
-        if n > 0 and self.cfg.get("prewarm", True) and not getattr(self, "_prewarmed", False):
+        last = (n if total is None else int(total)) - 1
+        if n > 0 and self.cfg.get("prewarm", True) and self.draws is None and not getattr(self, "_prewarmed", False):
             # everything a frame would otherwise pay for once, somewhere in the sequence: graph captures of both loops, the joint_opt
             # scratch, first launches of every kernel -- on a stand-in (frame 0), before the first frame is timed by anyone
             _, color, depth, gt_c2w, rays_d = self.frames[0]
@@ -426,7 +537,7 @@ class SLAM:
                                      (c["joint_opt"], True, hz, c["lr_factor"])])
             self.tracker.prewarm(color, depth, gt_c2w)
             self._prewarmed = True
-        for idx in range(n):
+        for idx in range(int(start), n):
             _, color, depth, gt_c2w, rays_d = self.frames[idx]
             color, depth, gt_c2w, rays_d = (t.to(self.device, non_blocking=True) for t in (color, depth, gt_c2w, rays_d))   # disk readers yield CPU tensors (UNISLAM/Tracker.py:303-306)
             self.gt_c2w_list[idx] = gt_c2w
@@ -434,7 +545,8 @@ class SLAM:
                 self.estimate_c2w_list[0] = gt_c2w                                       # the first pose is given (Mapper.py:479)
             else:
                 self.estimate_c2w_list[idx] = self.tracker.track_frame(idx, color, depth)
-            if idx % every == 0 or self.tracking_back or idx == n - 1:                  # Mapper.py:487-493
+            self.history["tracking_back"][idx] = bool(self.tracking_back)
+            if idx % every == 0 or self.tracking_back or idx == last:                   # Mapper.py:487-493
                 self.mapper.map_frame(idx, color, depth, gt_c2w, rays_d)
                 self.tracker.params_stale = True
             if log is not None:

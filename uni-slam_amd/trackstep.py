@@ -310,6 +310,24 @@ class TrackStep:
             b1, b2, 1e-8, P(self.pstep), P(self.loss), P(self.min_loss), P(self.best_pose), P(self.draw_ctr), st))
         return self.loss, self.unc[:n], self.valid[:n]
 
+    def probe_valid(self, batch_size, indices):
+        """us_track_sample ALONE for the given pixels at the current pose: the pre-filter flags [n] (uint8, device) the next iterate_fused()
+        call will compute for them.  For callers that replay a recorded random stream (slam.TorchDraws): the reference draws its jitter for
+        the rays that PASSED the pre-filter only (src/Tracker.py:177-194 compacts, then src/utils/Renderer.py:55 draws [R', S]), so the
+        number of rows to draw is needed before the iteration.  Nothing but this object's per-iteration scratch is written."""
+        lib, st, P = L.lib(), L.stream(), L.ptr
+        H, W, eh, ew = self.frame
+        n = int(batch_size)
+        if n > self.max_rays:
+            self._alloc(n)
+        self._track_inputs(n)
+        L.check(lib.us_track_sample(
+            P(self.pose), P(indices.contiguous()), n, self.intr, ew, eh, W - 2 * ew, H - 2 * eh, P(self.img_d), P(self.img_c), W, self.bhost, P(self.t_uni),
+            self.n_strat, P(self.t_surf), self.n_imp, ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation),
+            None, 0, P(self.draw_ctr), 0, None, None, P(self.t_dirs), P(self.t_gd), P(self.t_gc), P(self.valid), P(self.z), P(self.pts), st),
+            "us_track_sample")
+        return self.valid[:n]
+
     def mean_uncertainty(self, unc, valid):
         """mean pixel uncertainty of the rays that passed the pre-filter (Tracker.py:353, `rendered_weights.detach().mean()`): one launch,
         the result stays on the device (self.mean_unc[1])"""

@@ -159,6 +159,14 @@ class MapWindow:
                                      ctypes.c_float(3 * s.truncation), tr, s._seed(0), P(s.step_dev), 1 if s.perturb else 0, P(self.ro),
                                      P(self.rd), P(self.dirs), P(self.gd), P(self.gc), P(s.valid), P(s.z), P(s.pts), st), "us_window_sample")
 
+    def probe_valid(self):
+        """the sampling launch ALONE on the pixels of draw() at the current poses: (pre-filter flags [R] uint8, gt_depth [R]) as the next
+        iterate() will see them (padding rows of an ArenaWindow come out invalid).  For callers that replay a recorded random stream
+        (slam.TorchDraws): the reference draws its jitter for the rays that passed the pre-filter only (src/Mapper.py:396-406 compacts,
+        src/utils/Renderer.py:55 draws [R', S])."""
+        self._sample(None, False)
+        return self.step.valid[:self.R], self.gd
+
     def _pose_desc(self):
         """_pose_step()'s arguments as the descriptor us_adam_step_model takes"""
         P, s = (lambda t: ctypes.c_void_p(t.data_ptr())), self.step
