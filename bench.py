@@ -427,6 +427,7 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
                 win.capture(collectives="between")
                 o[tag + "_graph_segments_ms"] = timed(win.replay)
                 o[tag + "_graph_segments"] = len(win._graph.segments)
+                o[tag + "_graph_segments_launched"] = win._graph.n_launched    # (r6: a segment that recorded nothing is skipped on replay)
                 win.capture()                                # RCCL: the collectives captured into the ONE graph (the default)
                 o[tag + "_replayed_ms"] = timed(win.replay)
             out[mode] = o
@@ -441,6 +442,99 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
         if own_pg and dist.is_initialized():
             dist.destroy_process_group()
     return out
+
+
+def _tcnn_only_model_class():
+    """(torch is imported by the rank processes only: the class is made on demand)"""
+    class _TcnnOnlyModel(torch.nn.Module):
+        """
+        BENCH SCAFFOLDING for `drop_in_api.tcnn_only`: what a maintainer gets from the THREE changed lines of INTEGRATION.md 1 alone -- the
+        reference's own torch code around `tcnn.Encoding` / `tcnn.Network`, restated here (the reference cannot travel to the GPU box):
+        decoders as src/networks/decoders.py:49-70,91-105,118-128,143-153,182-205 (clamp -> enc(p) -> net(h) per decoder -> cat), rendering as
+        src/utils/Renderer.py:42-57,81-101,132-152 (linspace, cat + sort, jitter, points, sdf2alpha, cat + cumprod, five reductions), sampling
+        as src/common.py:152-166 (rotate ALL pool directions, then gather), pre-filter + four compactions + loss as src/Mapper.py:396-440 with
+        sdf_losses :141-175.  Every op but the two tcnn modules is a torch op.
+        """
+
+        def __init__(self, tcnn, hidden, prec, log2T, res, bound, truncation, w, n_strat, n_imp):
+            super().__init__()
+            enc = lambda l2: tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
+                                                                           "log2_hashmap_size": l2, "base_resolution": 16,
+                                                                           "per_level_scale": per_level_scale(res)}, dtype=torch.float)
+            net = lambda n_out, act: tcnn.Network(n_input_dims=32, n_output_dims=n_out, network_config={
+                "otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": hidden, "n_hidden_layers": 2,
+                "precision": prec})                                   # ("precision": this build's extension key; 2 hidden x `hidden`: the bench's decoders)
+            self.hash_grids_xyz, self.c_hash_grids_xyz = [enc(log2T[0])], [enc(log2T[1])]
+            self.enc_s, self.enc_c = self.hash_grids_xyz[0], self.c_hash_grids_xyz[0]         # (registered; the reference keeps them in 1-element lists)
+            self.sdf_decoder, self.color_decoder = net(1, "Tanh"), net(3, "Sigmoid")
+            self.beta = torch.nn.Parameter(10 * torch.ones(1))
+            self.bound, self.tr, self.w, self.n_strat, self.n_imp = bound, truncation, w, n_strat, n_imp
+
+        def decoders(self, p):
+            p_nor = p.reshape(-1, 3)
+            sdf = self.sdf_decoder(self.hash_grids_xyz[0](torch.clamp(p_nor, min=0, max=1))).squeeze()
+            rgb = self.color_decoder(self.c_hash_grids_xyz[0](torch.clamp(p_nor, min=0, max=1)))
+            raw = torch.cat([rgb, sdf.unsqueeze(-1)], dim=-1)
+            return raw.reshape(*p.shape[:-1], -1)
+
+        def render(self, rays_d, rays_o, gt_depth):
+            dev, tr = rays_o.device, self.tr
+            t_uni = torch.linspace(0., 1., steps=self.n_strat, device=dev)
+            t_surf = torch.linspace(0., 1., steps=self.n_imp, device=dev)
+            gd = gt_depth.reshape(-1, 1)
+            z_surf = gd.expand(-1, self.n_imp) - (1.5 * tr) + (3 * tr * t_surf)
+            z_free = 0.0 + 1.2 * gd.expand(-1, self.n_strat) * t_uni
+            z, _ = torch.sort(torch.cat([z_free, z_surf], dim=-1), dim=-1)
+            mids = 0.5 * (z[..., 1:] + z[..., :-1])
+            upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
+            z = lower + (upper - lower) * torch.rand(z.shape, device=dev)
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+            pts = (pts - self.bound[:, 0]) / (self.bound[:, 1] - self.bound[:, 0])
+            raw = self.decoders(pts)
+            alpha = 1. - torch.exp(-self.beta * torch.sigmoid(-raw[..., 3] * self.beta))
+            weights = alpha * torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1), device=dev), (1. - alpha + 1e-10)], -1), -1)[:, :-1]
+            rgb = torch.sum(weights[..., None] * raw[..., :3], -2)
+            depth = torch.sum(weights * z, -1)
+            unc = torch.square(1 - torch.sum(weights, -1))
+            return unc, depth, rgb, raw[..., 3], z
+
+        def sdf_losses(self, sdf, z, gd):
+            tr, w = self.tr, self.w
+            front = torch.where(z < (gd[:, None] - tr), torch.ones_like(z), torch.zeros_like(z)).bool()
+            back = torch.where(z > (gd[:, None] + tr), torch.ones_like(z), torch.zeros_like(z)).bool()
+            center = torch.where((z > (gd[:, None] - 0.4 * tr)) * (z < (gd[:, None] + 0.4 * tr)), torch.ones_like(z), torch.zeros_like(z)).bool()
+            tail = (~front) * (~back) * (~center)
+            fs = torch.mean(torch.square(sdf[front] - torch.ones_like(sdf[front])))
+            c = torch.mean(torch.square((z + sdf * tr)[center] - gd[:, None].expand(z.shape)[center]))
+            t = torch.mean(torch.square((z + sdf * tr)[tail] - gd[:, None].expand(z.shape)[tail]))
+            return w["fs"] * fs + w["center"] * c + w["tail"] * t
+
+        def iteration(self, opt, c2ws, pd, pc, pr, n_per):
+            dev = pd.device
+            opt.zero_grad()
+            b = c2ws.shape[0]
+            idx = torch.randint(pd.shape[1], (n_per * b,), device=dev).reshape(b, -1)
+            gd = torch.gather(pd, 1, idx)
+            gc = torch.gather(pc, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+            rd = torch.sum(pr.unsqueeze(-2) * c2ws[:, None, :3, :3], -1)                      # all P directions of every frame, then the gather
+            ro = c2ws[:, None, :3, -1].expand(rd.shape)
+            rd = torch.gather(rd, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).reshape(-1, 3)
+            ro = torch.gather(ro, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).reshape(-1, 3)
+            gd, gc = gd.reshape(-1), gc.reshape(-1, 3)
+            with torch.no_grad():
+                t = (self.bound.unsqueeze(0) - ro.unsqueeze(-1)) / rd.unsqueeze(-1)
+                t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+                inside = t >= gd
+            rd, ro, gd, gc = rd[inside], ro[inside], gd[inside], gc[inside]
+            unc, depth, color, sdf, z = self.render(rd, ro, gd)
+            depth_mask = (gd > 0) & ((1 - unc.detach()) > 0.99)
+            loss = self.sdf_losses(sdf[depth_mask], z[depth_mask], gd[depth_mask])
+            loss = loss + self.w["color"] * torch.square(gc - color).mean()
+            loss = loss + self.w["depth"] * torch.square(gd[depth_mask] - depth[depth_mask]).mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+    return _TcnnOnlyModel
 
 
 def drop_in_bench(us, dev, prec, hidden, bound, mk, steps, warmup, R, n_strat, n_imp):
@@ -509,11 +603,26 @@ def drop_in_bench(us, dev, prec, hidden, bound, mk, steps, warmup, R, n_strat, n
             ms, loss = timed(lambda: iteration(*m, compact))
             out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": loss}
             del m
+        # the module seam ALONE (`import unislam_amd.tcnn as tcnn`, three changed lines): everything around the two tcnn
+        # modules is the reference's own torch code (_TcnnOnlyModel above) -- ~60 torch launches per iteration around four module calls
+        import unislam_amd.tcnn as tcnn
+        res = int((bound[:, 1] - bound[:, 0]).max() / 0.01)
+        for tag, opt_kind in (("tcnn_only", "torch"), ("tcnn_only_fused_adam", "fused")):
+            torch.manual_seed(0)
+            m = _tcnn_only_model_class()(tcnn, hidden, prec, (16, 19), res, bound.to(dev), 0.06, W, n_strat, n_imp).to(dev)
+            groups = [{"params": list(m.sdf_decoder.parameters()) + list(m.color_decoder.parameters()) + [m.beta], "lr": LR["decoders"]},
+                      {"params": [m.enc_s.params], "lr": LR["sdf_grid"]}, {"params": [m.enc_c.params], "lr": LR["color_grid"]}]
+            opt = us.optim.Adam(groups) if opt_kind == "fused" else torch.optim.Adam(groups)
+            ms, loss = timed(lambda: m.iteration(opt, c2ws, pd, pc, pr, n_per))
+            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": loss}
+            del m, opt
         out["ms_per_iter"] = out["torch_adam_compaction"]["ms_per_iter"]
         out["rays_per_s"] = out["torch_adam_compaction"]["rays_per_s"]
         out["note"] = ("headline of this block = torch_adam_compaction: the reference's lines unchanged except the imports; fused_adam_* swaps "
                        "torch.optim.Adam for unislam_amd.optim.Adam (same constructor, one launch per step); *_valid_flag hands the pre-filter's mask "
-                       "to the loss instead of compacting four tensors (no host synchronisation)")
+                       "to the loss instead of compacting four tensors (no host synchronisation); tcnn_only = ONLY `import unislam_amd.tcnn as tcnn` "
+                       "(INTEGRATION.md 1): the reference's own torch renderer / sampler / losses around tcnn.Encoding + tcnn.Network, each encoder "
+                       "and decoder its own autograd node (counted forward + scan + binned table gradient on a cached workspace, row-major features)")
     except Exception as e:                                # report, do not hide
         out["error"] = repr(e)[:400]
     return out

@@ -231,3 +231,114 @@ def test_reference_shaped_iteration_equals_mapstep(us, prec):
         assert float((d > 2e-4 * scale).float().mean()) <= 1e-3 and float(d.max()) <= 2e-3, (float((d > 2e-4 * scale).float().mean()), float(d.max()))
     for (k, a), (_, b_) in zip(dec.named_parameters(), dec2.named_parameters()):
         assert _rel(a, b_) <= 2e-4, k
+
+
+# ---------------------------------------------------------------------------------------------- r6: the node against the ORACLE, the seam alone
+def _oracle_model(dec, es, ec, log2T):
+    """the CPU oracle with this model's parameters (torch-MLP decoders: the layout fixture g4 pins; the C hash grid)"""
+    od = O.DecodersOracle()
+    od.load_state_dict({k: v.detach().cpu() for k, v in dec.state_dict().items()})
+    oes, oec = O.HashGridOracle(3, enc_cfg(log2T[0])), O.HashGridOracle(3, enc_cfg(log2T[1]))
+    with torch.no_grad():
+        oes.params.copy_(es.params.detach().cpu()); oec.params.copy_(ec.params.detach().cpu())
+    return od, oes, oec
+
+
+def test_one_node_forward_at_full_size_against_the_oracle(us):
+    """BASELINE configs[1]'s 4096 x 64 = 262 144 points through _DecodersFusedFn (fp32 decoders) against the CPU oracle on the same
+    parameters: raw 1e-6, both table gradients 1e-4 of the largest entry, decoder gradients 1e-4, dL/dp 1e-3 -- this file's other tests
+    compare HIP with HIP (one node against two modules); this one anchors the node itself (g4 / g7 / g9 run through it at fixture sizes)."""
+    log2T = (16, 19)
+    dec, es, ec = _model(us, False, "fp32", log2T=log2T)
+    od, oes, oec = _oracle_model(dec, es, ec, log2T)
+    n = 4096 * 64
+    torch.manual_seed(3)
+    p = torch.rand(n, 3) * 1.04 - 0.02
+    probe = torch.randn(n, 4)
+    x = p.to(DEV).requires_grad_(True)
+    raw = dec(x, ([es], [ec]))
+    (raw * probe.to(DEV)).sum().backward()
+    xo = p.clone().requires_grad_(True)
+    raw_o = od(xo, ([oes], [oec]))
+    (raw_o * probe).sum().backward()
+    np.testing.assert_allclose(raw.detach().cpu().numpy(), raw_o.detach().numpy(), rtol=0, atol=1e-6)
+    assert _rel(es.params.grad, oes.params.grad) <= 1e-4 and _rel(ec.params.grad, oec.params.grad) <= 1e-4
+    n_dec = 0
+    for (k, a), (_, b) in zip(dec.named_parameters(), od.named_parameters()):
+        assert (a.grad is None) == (b.grad is None), k           # (beta takes no part in Decoders.forward)
+        if a.grad is not None:
+            assert _rel(a.grad, b.grad) <= 1e-4, k
+            n_dec += 1
+    assert n_dec == 12
+    # dL/dp jumps where a coordinate sits on a cell face of a fine level (and is zero outside [0,1]): compare away from the largest 0.1 %
+    d = (x.grad.cpu() - xo.grad).abs().reshape(-1)
+    assert float(torch.quantile(d[::7], 0.999)) <= 1e-3 * float(xo.grad.abs().max())
+
+
+@pytest.mark.parametrize("n,det", [(20000, False), (4096 * 16, True), (300, False)])
+def test_module_seam_alone_against_the_oracle(us, n, det):
+    """`import unislam_amd.tcnn as tcnn` ALONE: enc(x) as its own autograd node -- r6: us_hashgrid_fwd_counted +
+    us_hashgrid_bwd_scan in the forward pass, us_hashgrid_bwd_binned(COUNTED | SCANNED) in the backward pass, scratch cached on the module
+    (n >= 16384; below that the plain encoder + the sliced gradient) -- and net(h), against the CPU oracle: features 1e-6, table gradient 1e-4,
+    input gradient 1e-3 away from cell faces.  The scratch is allocated once."""
+    import unislam_amd.tcnn as tcnn
+    torch.manual_seed(4)
+    enc = tcnn.Encoding(n_input_dims=3, encoding_config=enc_cfg(17), dtype=torch.float).to(DEV)
+    if det:
+        enc.grid_bwd_flags = us._lib.US_GRID_BWD_DETERMINISTIC
+    oenc = O.HashGridOracle(3, enc_cfg(17))
+    with torch.no_grad():
+        enc.params.copy_(torch.randn_like(enc.params) * 0.1); oenc.params.copy_(enc.params.detach().cpu())
+    grads = []
+    for rep in range(2):
+        p = torch.rand(n, 3)
+        probe = torch.randn(n, 32)
+        x = p.to(DEV).requires_grad_(True)
+        enc.zero_grad(set_to_none=True); oenc.zero_grad(set_to_none=True)
+        h = enc(x)
+        (h * probe.to(DEV)).sum().backward()
+        xo = p.clone().requires_grad_(True)
+        ho = oenc(xo)
+        (ho * probe).sum().backward()
+        np.testing.assert_allclose(h.detach().cpu().numpy(), ho.detach().numpy(), rtol=0, atol=1e-6)
+        assert _rel(enc.params.grad, oenc.params.grad) <= 1e-4
+        d = (x.grad.cpu() - xo.grad).abs().reshape(-1)
+        assert float(torch.quantile(d, 0.999)) <= 1e-3 * float(xo.grad.abs().max())
+        grads.append(enc.params.grad.clone())
+        ws = enc._ws
+        assert (ws is not None) == (n >= 16384)
+    assert enc._ws is ws                                        # one scratch for both iterations
+    # a forward pass overtaken by another one of the same module counts again in a scratch of its own
+    pa, pb = torch.rand(n, 3, device=DEV), torch.rand(n, 3, device=DEV)
+    qa = torch.randn(n, 32, device=DEV)
+    enc.zero_grad(set_to_none=True)
+    ha = enc(pa); enc(pb)
+    (ha * qa).sum().backward()
+    g_overtaken = enc.params.grad.clone()
+    enc.zero_grad(set_to_none=True)
+    (enc(pa) * qa).sum().backward()
+    assert _rel(g_overtaken, enc.params.grad) <= 1e-5
+    # the network as its own node: the scratch of its backward pass is cached too
+    net = tcnn.Network(n_input_dims=32, n_output_dims=3, network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid",
+                                                                        "n_neurons": 16, "n_hidden_layers": 1}).to(DEV)
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        net(enc(pa)).sum().backward()
+        w = net._ws
+    assert net._ws is w and net.params.grad is not None
+
+
+def test_backward_after_an_in_place_update_of_the_decoders_raises(us):
+    """the node's backward pass reads the decoders' weights from the packed vector as it is THEN; an optimizer.step() between forward and
+    backward (torch.optim.Adam or unislam_amd.optim.Adam) must raise like a modified saved tensor does, not differentiate at the new weights"""
+    for kind in ("torch", "fused"):
+        dec, es, ec = _model(us, False, "fp32")
+        opt = (us.optim.Adam if kind == "fused" else torch.optim.Adam)(list(dec.parameters()), lr=1e-3)   # (the tables ARE saved tensors: torch checks those itself)
+        p = torch.rand(20000, 3, device=DEV)
+        raw = dec(p, ([es], [ec]))
+        raw.sum().backward(retain_graph=True)                   # fine: nothing changed yet
+        opt.step()
+        with pytest.raises(us.UniSlamHipError, match="modified in place"):
+            raw.sum().backward()
+        dec.zero_grad(set_to_none=True)
+        dec(p, ([es], [ec])).sum().backward()                   # a fresh forward pass is fine again

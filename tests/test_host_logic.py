@@ -54,16 +54,28 @@ def test_synthetic_room_refuses_paths_through_walls():
     assert torch.allclose(ok.poses[0, :3, 3], torch.tensor([1.3, 1.2, -0.1])) and abs(float(ok.poses[100, 0, 3]) - 3.14) < 0.01
 
 
-def test_graph_registry_keeps_and_releases():
+def test_graph_registry_keeps_and_releases(monkeypatch):
+    """the registry of captured graphs on a PRIVATE list (the process-global one holds the graphs of earlier GPU tests): FIFO release --
+    an entry is dropped only when its owner is gone AND nothing older is left in front of it (destroying a graph breaks the OLDER ones)"""
+    import gc
     from unislam_amd import graph
-    n0 = len(graph._KEEP)
+    monkeypatch.setattr(graph, "_KEEP", [])
+
+    class Owner:
+        pass
+    a, b, c = Owner(), Owner(), Owner()
+    ga, gb, gc_ = object(), object(), object()
+    graph._keep(ga, a); graph._keep(gb, b); graph._keep(gc_, c)
+    assert [e[0] for e in graph._KEEP] == [ga, gb, gc_] and graph.collect() == 0
+    del b; gc.collect()
+    assert graph.collect() == 0 and len(graph._KEEP) == 3          # b's graph is not the oldest: destroying it would break a's
+    del a; gc.collect()
+    assert graph.collect() == 2 and [e[0] for e in graph._KEEP] == [gc_]   # now a's goes, then b's, oldest first; c's owner lives
     sentinel = object()
+    graph._keep(sentinel)                                          # no owner: kept until release_all()
+    del c; gc.collect()
+    assert graph.collect() == 1 and [e[0] for e in graph._KEEP] == [sentinel] and graph.collect() == 0
+    assert graph.release_all() == 1 and graph._KEEP == []
+    monkeypatch.setenv("US_KEEP_GRAPHS", "0")                      # the old behaviour, for reproducing the runtime fault
     graph._keep(sentinel)
-    assert len(graph._KEEP) == n0 + 1 and graph._KEEP[-1] is sentinel
-    assert graph.release_all() == n0 + 1 and graph._KEEP == []
-    os.environ["US_KEEP_GRAPHS"] = "0"                           # the old behaviour, for reproducing the runtime fault
-    try:
-        graph._keep(sentinel)
-        assert graph._KEEP == []
-    finally:
-        del os.environ["US_KEEP_GRAPHS"]
+    assert graph._KEEP == []

@@ -72,6 +72,9 @@ class _DecodersFusedFn(torch.autograd.Function):
             L.check(lib.us_mlp_fwd(ms, ps, P(feat_s), n, _off(raw, 3), 4, L.US_MLP_LEVEL_MAJOR, st), "us_mlp_fwd")
             L.check(lib.us_mlp_fwd(mc, pc, P(feat_c), n, P(raw), 4, L.US_MLP_LEVEL_MAJOR, st), "us_mlp_fwd")
         ctx.dec, ctx.es, ctx.ec, ctx.counted = dec, es, ec, None
+        # the backward pass reads the decoders' weights from the packed vector as it is THEN (they are not copied per call): note their
+        # versions, so that an in-place update between forward and backward raises as it would for a tensor autograd saved
+        ctx.versions = [p._version for p in dec_params] if any(need[4:]) else None
         if want_tab:
             g_s = torch.empty(es.desc.n_params, dtype=torch.float32, device=dev)
             g_c = torch.empty(ec.desc.n_params, dtype=torch.float32, device=dev)
@@ -88,6 +91,13 @@ class _DecodersFusedFn(torch.autograd.Function):
         x, ts, tc, feat_s, feat_c, raw = ctx.saved_tensors
         dec, es, ec = ctx.dec, ctx.es, ctx.ec
         n, dev = x.shape[0], x.device
+        if ctx.versions is not None:
+            now = [p._version for p in dec._dec_params()]
+            if now != ctx.versions:
+                k = next(i for i, (a, b) in enumerate(zip(now, ctx.versions)) if a != b)
+                raise L.UniSlamHipError(f"Decoders.forward's backward pass: decoder parameter {k} (shape {tuple(dec._dec_params()[k].shape)}) was modified in "
+                                        f"place after the forward pass (version {ctx.versions[k]} -> {now[k]}, e.g. an optimizer.step() between forward and "
+                                        "backward): its gradient would be taken at the new weights; run the forward pass again")
         d_raw = L.f32(d_raw)
         ds, dc = ctypes.byref(es.desc), ctypes.byref(ec.desc)
         ms, mc = ctypes.byref(dec.mlp_descs()[0]), ctypes.byref(dec.mlp_descs()[1])
@@ -111,11 +121,16 @@ class _DecodersFusedFn(torch.autograd.Function):
         g_s = g_c = None
         flags = L.US_GRID_CLAMP01 | L.US_GRID_LEVEL_MAJOR
         if want_tab:
+            if ctx.counted is None:     # a second backward pass through this node (retain_graph): gradient tables and scratch of its own
+                nbytes = dec._fused_bytes(es, ec, n)
+                ctx.counted = (torch.empty(es.desc.n_params, dtype=torch.float32, device=dev), torch.empty(ec.desc.n_params, dtype=torch.float32, device=dev),
+                               torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes, -1)
             g_s, g_c, ws, nbytes, gen = ctx.counted
+            ctx.counted = None          # (the returned gradients must be the only references: AccumulateGrad then takes them without a copy)
             jflags = flags | L.US_GRID_BWD_OVERWRITE | dec.grid_bwd_flags
             if gen == dec._fused_gen:
                 jflags |= L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED
-            else:                       # another forward pass has used the cached scratch since: count again, in a scratch of this call's own
+            elif gen >= 0:              # another forward pass has used the cached scratch since: count again, in a scratch of this call's own
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             L.check(lib.us_hashgrid_bwd_joint(ds, dc, P(x), P(d_feat_s), P(d_feat_c), n, P(g_s), P(g_c), jflags, P(ws), nbytes, st),
                     "us_hashgrid_bwd_joint")
@@ -305,6 +320,7 @@ class Decoders(nn.Module):
             b.requires_grad_(a.requires_grad)
         if hasattr(self, "bound"):
             new.bound = self.bound
+        new.fused, new.grid_bwd_flags = self.fused, self.grid_bwd_flags
         return new
 
     @staticmethod

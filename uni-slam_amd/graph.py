@@ -13,23 +13,44 @@ capture that contains an optimiser's lazy state initialisation would re-zero the
 """
 import gc
 import os
+import warnings
+import weakref
 
 import torch
 
-# Every captured graph is kept alive here until release_all().  Reason (r5, reproduced twice each way on the MI355X box with
-# `pytest tests/test_gpu_dropin.py tests/test_gpu_slam.py`; native backtrace in profiles/r05_hipgraph_destroy_segv.txt): with the HIP
-# runtime torch 2.10+rocm7.0 bundles, destroying ONE graph that has parallel branches (hipGraphExecDestroy, reached from the garbage
+# Every captured graph is kept alive here for as long as a NEWER one may still be replayed.  Reason (r5, reproduced twice each way on the
+# MI355X box with `pytest tests/test_gpu_dropin.py tests/test_gpu_slam.py`; native backtrace in profiles/r05_hipgraph_destroy_segv.txt): with
+# the HIP runtime torch 2.10+rocm7.0 bundles, destroying ONE graph that has parallel branches (hipGraphExecDestroy, reached from the garbage
 # collector when a MapStep / window / SLAM object dies) leaves every OLDER multi-branch graph exec with dangling branch streams: its next
-# hipGraphLaunch dies in hip::Graph::UpdateStreams (SIGSEGV on the host).  All graphs of this package fork side streams, so none may be
-# destroyed while another one may still be replayed.  A graph holds its launch records and the few small allocations made under
-# capture (the iteration's buffers are preallocated): the drivers capture one graph per KIND of window, so the registry stays small;
-# code that captures per mapped frame should call release_all() at a point where no captured graph will be replayed again.
-_KEEP = []
+# hipGraphLaunch dies in hip::Graph::UpdateStreams (SIGSEGV on the host).  All graphs of this package fork side streams, so a graph may only
+# be destroyed when no older one is alive.  r6: the registry is a FIFO -- each entry holds the graph and a weak reference to the object that
+# replays it (CapturedIteration / SegmentedGraph); before every new capture the entries at the FRONT whose owners are dead are dropped,
+# oldest first (the oldest graph has no older one to break).  So a long run that re-captures (a window per mapped frame, a re-capture after
+# KeyframeArena.grow() or a MapStep reallocation) holds the graphs that are still in use plus those younger than the oldest one in use, not
+# every graph ever captured.  release_all() drops everything; only safe when no captured graph will be replayed again.
+_KEEP = []                  # [(graph, weakref to its owner | None)], oldest first
+_WARN_AT = 256              # a registry this long means per-frame captures whose owners stay alive: say so once
+_warned = [False]
 
 
-def _keep(g):
+def _keep(g, owner=None):
     if os.environ.get("US_KEEP_GRAPHS", "1") != "0":     # "0": the old behaviour (for reproducing the runtime fault)
-        _KEEP.append(g)
+        _KEEP.append((g, weakref.ref(owner) if owner is not None else None))
+        if len(_KEEP) > _WARN_AT and not _warned[0]:
+            _warned[0] = True
+            warnings.warn(f"unislam_amd.graph: {len(_KEEP)} captured hipGraphs are alive (each holds its launch records and a private memory pool). "
+                          "Capture one graph per KIND of iteration and rebind its inputs (ArenaWindow.bind), or drop the objects that own old "
+                          "graphs: they are destroyed oldest-first at the next capture.")
+
+
+def collect():
+    """destroy the graphs at the FRONT of the registry whose owners are gone (oldest first: safe, see _KEEP); returns how many.  Called
+    before every capture -- never during one (hipGraphDestroy is not permitted while a stream captures)."""
+    n = 0
+    while _KEEP and _KEEP[0][1] is not None and _KEEP[0][1]() is None:
+        _KEEP.pop(0)
+        n += 1
+    return n
 
 
 def release_all():
@@ -49,8 +70,9 @@ class CapturedIteration:
             for _ in range(warmup):
                 fn()
         torch.cuda.current_stream().wait_stream(s)
+        collect()
         self.graph = torch.cuda.CUDAGraph()
-        _keep(self.graph)
+        _keep(self.graph, self)
         # No cyclic garbage collection while the stream captures: an older graph that is only reachable from a garbage cycle would be
         # destroyed by the collector in the middle of the capture, and hipGraphDestroy is "not permitted when stream is capturing"
         # (seen in a 40-frame SLAM run with one captured MapWindow per mapped frame).  The callable is dropped afterwards: it usually
@@ -86,6 +108,7 @@ class SegmentedGraph:
 
     def __init__(self, fn, join=None):
         self.segments = []
+        collect()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         was = gc.isenabled()
@@ -94,14 +117,19 @@ class SegmentedGraph:
 
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
-            _keep(cur[0])
+            _keep(cur[0], self)
             cur[0].capture_begin(capture_error_mode="thread_local")
 
         def end(op):
             if join is not None:
                 join()
-            cur[0].capture_end()
-            self.segments.append((cur[0], op))
+            # a segment that recorded NOTHING (two cuts in a row: e.g. the optimiser in parts with nothing between the collectives) is not
+            # launched on replay -- an empty hipGraph still costs a graph launch (torch says "The CUDA Graph is empty" at capture_end)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                cur[0].capture_end()
+            empty = any("Graph is empty" in str(x.message) for x in w)
+            self.segments.append((None if empty else cur[0], op))
 
         def cut(op):
             end(op)
@@ -129,7 +157,13 @@ class SegmentedGraph:
 
     def replay(self):
         for g, op in self.segments:
-            g.replay()
+            if g is not None:
+                g.replay()
             if op is not None:
                 op()
         return self.out
+
+    @property
+    def n_launched(self):
+        """segments that hold work (the others are skipped on replay)"""
+        return sum(1 for g, _ in self.segments if g is not None)

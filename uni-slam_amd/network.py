@@ -36,14 +36,14 @@ class _MlpFn(torch.autograd.Function):
     """y[N, n_out] = MLP(x[N, 32]; params).  `out` may be a preallocated strided view target (raw[N,4] columns)."""
 
     @staticmethod
-    def forward(ctx, x, params, desc):
+    def forward(ctx, x, params, desc, owner=None):
         x = L.f32(x.detach())
         p = L.f32(params.detach())
         n = x.shape[0]
         out = torch.empty((n, desc.n_out), dtype=torch.float32, device=x.device)
         L.check(L.lib().us_mlp_fwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), n, L.ptr(out), desc.n_out, 0, L.stream()),
                 "us_mlp_fwd")
-        ctx.desc = desc
+        ctx.desc, ctx.owner = desc, owner
         ctx.save_for_backward(x, p, out)
         return out
 
@@ -59,10 +59,15 @@ class _MlpFn(torch.autograd.Function):
             ws, nbytes = None, 0
             if gp is not None:
                 nbytes = int(L.lib().us_mlp_bwd_workspace_bytes(ctypes.byref(desc)))
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                if ctx.owner is not None:         # the partial-row scratch is cached on the module (consumed inside this one call)
+                    if ctx.owner._ws is None or ctx.owner._ws.numel() < nbytes or ctx.owner._ws.device != x.device:
+                        ctx.owner._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                    ws = ctx.owner._ws
+                else:
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             L.check(L.lib().us_mlp_bwd(ctypes.byref(desc), L.ptr(p), L.ptr(x), L.ptr(out), desc.n_out, L.ptr(dy),
                                        desc.n_out, n, L.ptr(gx), L.ptr(gp), 0, L.ptr(ws), nbytes, L.stream()), "us_mlp_bwd")
-        return gx, gp, None
+        return gx, gp, None, None
 
 
 def fused_mlp(x, params, desc):
@@ -92,6 +97,7 @@ class FusedMLP(nn.Module):
             p[o:o + fo * fi] = (torch.rand(fo * fi, generator=g) * 2 - 1) * lim
             o += fo * fi
         self.params = nn.Parameter(p)
+        self._ws = None                 # cached scratch of the backward pass (never pickled)
 
     def layer_shapes(self):
         s = [(self.width, self.n_input_dims)] + [(self.width, self.width)] * (self.n_hidden - 1) + [(16, self.width)]
@@ -100,10 +106,12 @@ class FusedMLP(nn.Module):
     def __getstate__(self):
         s = self.__dict__.copy()
         s.pop("desc", None)
+        s["_ws"] = None
         return s
 
     def __setstate__(self, s):
         self.__dict__.update(s)
+        self.__dict__.setdefault("_ws", None)
         self.desc = make_mlp_desc(self.n_input_dims, self.width, self.n_hidden, self.n_output_dims,
                                   self.network_config.get("output_activation", "None"), self.bias,
                                   self.network_config.get("precision", "fp32"))
@@ -116,4 +124,4 @@ class FusedMLP(nn.Module):
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != self.n_input_dims:
             raise ValueError(f"FusedMLP: expected [N,{self.n_input_dims}], got {tuple(x.shape)}")
-        return _MlpFn.apply(x, self.params, self.desc)
+        return _MlpFn.apply(x, self.params, self.desc, self)

@@ -63,4 +63,8 @@ class Adam(torch.optim.Optimizer):
                                                  VP(*[t[2].data_ptr() for t in part]), VP(*[t[3].data_ptr() for t in part]),
                                                  I64(*[t[0].numel() for t in part]), DBL(*[t[4] for t in part]), b1, b2, eps, step, stream),
                         "us_adam_step_tensors")
+                for t in part:
+                    # the kernel wrote the parameter through its raw pointer: tell autograd (a backward pass that saved it, or the decoders'
+                    # one-node forward pass that recorded its version, must see the in-place update as torch.optim.Adam's would be seen)
+                    torch.autograd.graph.increment_version(t[0])
         return loss
