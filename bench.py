@@ -195,6 +195,90 @@ def keyframe_pools(n_frames, bound, seed, device):
     return st(c2ws), st(depths), st(colors), st(dirs_all)
 
 
+def step_stats(fn, steps, warmup):
+    """side-run timing, the headline's way: `warmup` untimed calls, `steps` calls between two synchronisations (wall time per step), then
+    `steps` more with one HIP event pair per call on the launch stream -> (ms per step, last return value, {median, p10, p90} of the events)"""
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a_, b_ in evs:
+        a_.record(); out = fn(); b_.record()
+    torch.cuda.synchronize()
+    ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+    q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
+    return ms, out, {"n": steps, "median_ms": q(0.5), "p10_ms": q(0.1), "p90_ms": q(0.9)}
+
+
+def gather_rate_curve(path=None):
+    """[(table bytes, G lane-loads/s)] of RANDOM 8-byte gathers by table size, as tools/ta_bench.hip measured them on the MI355X
+    (profiles/r06_ta_bench.txt: one 1024-thread workgroup per CU, every lane its own address; 16-byte gathers run at the same rates)"""
+    import re
+    path = path or os.path.join(ROOT, "profiles", "r06_ta_bench.txt")
+    pts = []
+    if os.path.exists(path):
+        for ln in open(path):
+            m = re.match(r"random\s+8-byte gathers, table\s+([0-9.]+) MiB:.*?([0-9.]+) G lane-loads/s", ln)
+            if m:
+                pts.append((float(m.group(1)) * 2 ** 20, float(m.group(2))))
+    return sorted(pts)
+
+
+def _rate_at(curve, nbytes):
+    """log-log interpolation of the curve (flat beyond its ends)"""
+    if nbytes <= curve[0][0]:
+        return curve[0][1]
+    for (b0, r0), (b1, r1) in zip(curve, curve[1:]):
+        if nbytes <= b1:
+            t = (math.log(nbytes) - math.log(b0)) / (math.log(b1) - math.log(b0))
+            return math.exp(math.log(r0) + t * (math.log(r1) - math.log(r0)))
+    return curve[-1][1]
+
+
+def encoder_request_roofline(descs, pts, kernel_ms):
+    """
+    The encoder against the bound it actually sits at: the rate at which the memory system serves RANDOM gather requests from a
+    table of a level's size -- not HBM bytes (the tables live in the L2s / Infinity Cache; traffic is 0.6 x algorithmic).  Lane loads are
+    counted from this batch's points exactly as gather_corners (csrc/hashgrid_dev.h) issues them: per point, level and grid 4 sixteen-byte
+    gathers (the x / x+1 vertices of a cell edge together) -- plus 4 eight-byte ones on a HASHED level when the cell's x is odd (the pair is
+    then not an aligned neighbour pair).  ceiling = sum over levels and grids of loads / rate(level's slab bytes), rate from the
+    microbenchmark curve (gather_rate_curve: uniformly random addresses, every lane its own line); frac = ceiling time / measured time.
+    A frac above 1 on coarse levels is expected (a ray's neighbouring samples share lines; the microbenchmark's lanes never do).
+    """
+    curve = gather_rate_curve()
+    if not curve:
+        return None
+    x = pts.reshape(-1, 3).clamp(0, 1)
+    n = x.shape[0]
+    loads, t_model, by_level = 0, 0.0, []
+    for d in descs:
+        for l in range(d.n_levels):
+            entries = int(d.offset[l + 1] - d.offset[l])
+            res = int(d.resolution[l])
+            hashed = res ** 3 > entries
+            k = 4 * n
+            if hashed:
+                gx = torch.floor(x[:, 0] * float(d.scale[l]) + 0.5).to(torch.int64)
+                k += 4 * int((gx & 1).sum())
+            rate = _rate_at(curve, entries * 8)
+            loads += k
+            t_model += k / (rate * 1e9)
+            by_level.append((l, entries * 8, k, rate))
+    t = kernel_ms * 1e-3
+    coarse = sum(k / (r * 1e9) for (_, b, k, r) in by_level if b <= 4 * 2 ** 20)
+    return {"bound": "random gather requests (L2 / Infinity Cache request rate by table size)", "lane_loads_per_launch": loads,
+            "achieved": loads / t / 1e9, "unit": "G lane-loads/s", "ceiling_ms": 1e3 * t_model, "frac": t_model / t,
+            "ceiling_ms_levels_up_to_4MiB": 1e3 * coarse, "ceiling_ms_levels_beyond_4MiB": 1e3 * (t_model - coarse),
+            "curve": "profiles/r06_ta_bench.txt (tools/ta_bench.hip; tools/gather_scope.hip: the same rate with loads that bypass the CU's cache)",
+            "note": "ceiling = sum over levels and grids of lane loads / rate(slab bytes); uniformly random addresses in the microbenchmark, so "
+                    "levels whose samples share lines run ahead of it"}
+
+
 def _median(xs):
     """median launch duration of a probe pass (a first launch that pays for lazy set-up does not move it)"""
     xs = sorted(xs)
@@ -374,6 +458,7 @@ def joint_opt_bench(us, build_step, bound, dev, steps, warmup):
                 torch.cuda.synchronize()
                 rounds.append(1e3 * (time.perf_counter() - t0) / steps)
             ms = sorted(rounds)[1]
+            ev = step_stats(win.replay, steps, 0)[2]
             moved = float((win.c2ws() - c2ws).abs().max())
             step.probe, step.probe_every, step._it = {}, 1, 0
             for _ in range(10):
@@ -383,7 +468,7 @@ def joint_opt_bench(us, build_step, bound, dev, steps, warmup):
             step.probe = None
             out[tag] = {"joint_opt_iteration_ms": ms, "rays": win.R, "rays_per_s": win.R / (ms / 1e3), "final_loss": float(loss),
                         "launch": "hipGraph replay of MapWindow (poses, pose Adam state and pixel indices on the device)",
-                        "max_pose_matrix_change": moved, "kernel_ms": kern, "rounds_ms": [round(x, 4) for x in rounds]}
+                        "max_pose_matrix_change": moved, "kernel_ms": kern, "rounds_ms": [round(x, 4) for x in rounds], "step_time_hip_events": ev}
         except Exception as e:                            # report, do not hide
             out[tag] = {"error": repr(e)[:300]}
     return out
@@ -584,24 +669,12 @@ def drop_in_bench(us, dev, prec, hidden, bound, mk, steps, warmup, R, n_strat, n
             opt.step()
             return loss.detach()
 
-        def timed(fn):
-            for _ in range(warmup):
-                fn()
-            rounds = []
-            for _ in range(3):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(steps):
-                    loss = fn()
-                torch.cuda.synchronize()
-                rounds.append(1e3 * (time.perf_counter() - t0) / steps)
-            return sorted(rounds)[1], float(loss)
-
         for tag, opt_kind, compact in (("torch_adam_compaction", "torch", True), ("torch_adam_valid_flag", "torch", False),
                                        ("torch_adam_fused_kwarg_compaction", "torch_fused_kwarg", True),
                                        ("fused_adam_compaction", "fused", True), ("fused_adam_valid_flag", "fused", False)):
             m = build(opt_kind)
-            ms, loss = timed(lambda: iteration(*m, compact))
-            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": loss}
+            ms, loss, ev = step_stats(lambda: iteration(*m, compact), steps, warmup)
+            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": float(loss), "step_time_hip_events": ev}
             del m
         # the module seam ALONE (`import unislam_amd.tcnn as tcnn`, three changed lines): everything around the two tcnn
         # modules is the reference's own torch code (_TcnnOnlyModel above) -- ~60 torch launches per iteration around four module calls
@@ -613,8 +686,8 @@ def drop_in_bench(us, dev, prec, hidden, bound, mk, steps, warmup, R, n_strat, n
             groups = [{"params": list(m.sdf_decoder.parameters()) + list(m.color_decoder.parameters()) + [m.beta], "lr": LR["decoders"]},
                       {"params": [m.enc_s.params], "lr": LR["sdf_grid"]}, {"params": [m.enc_c.params], "lr": LR["color_grid"]}]
             opt = us.optim.Adam(groups) if opt_kind == "fused" else torch.optim.Adam(groups)
-            ms, loss = timed(lambda: m.iteration(opt, c2ws, pd, pc, pr, n_per))
-            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": loss}
+            ms, loss, ev = step_stats(lambda: m.iteration(opt, c2ws, pd, pc, pr, n_per), steps, warmup)
+            out[tag] = {"ms_per_iter": ms, "rays_per_s": R / (ms / 1e3), "final_loss": float(loss), "step_time_hip_events": ev}
             del m, opt
         out["ms_per_iter"] = out["torch_adam_compaction"]["ms_per_iter"]
         out["rays_per_s"] = out["torch_adam_compaction"]["rays_per_s"]
@@ -669,21 +742,14 @@ def config3_bench(us, dev, prec, steps, warmup):
                               max_rays=R)
 
         def timed(fn):
-            for _ in range(warmup):
-                fn()
-            rounds = []
-            for _ in range(3):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(steps):
-                    loss = fn()
-                torch.cuda.synchronize()
-                rounds.append(1e3 * (time.perf_counter() - t0) / steps)
-            return sorted(rounds)[1], float(loss)
+            ms_, loss_, ev_ = step_stats(fn, steps, warmup)
+            return ms_, float(loss_), ev_
 
         step = build()
         win = us.MapWindow(step, c2ws, pd, pc, pr, R // b, joint_opt=False, has_zero_depth=None)
         win.capture()
-        ms, loss = timed(win.replay)
+        ms, loss, ev = timed(win.replay)
+        out["step_time_hip_events"] = ev
         n0 = int(step.zd_count)
         out.update({"mapping_iter_ms": ms, "rays_per_s": R / (ms / 1e3), "samples_per_s": N / (ms / 1e3), "final_loss": loss, "rays": R,
                     "samples_per_ray": S, "zero_depth_rays_last_iteration": n0, "n_params": int(step.n_flat),
@@ -701,11 +767,13 @@ def config3_bench(us, dev, prec, steps, warmup):
         out["roofline"] = {k: {"bound": "hbm", "achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg[k],
                                "avg_launch_ms": kern[k], "traffic": None} for k in alg if k in kern}
+        out["roofline_note"] = ("algorithmic bytes / HBM peak, SERVED FROM L2 / Infinity Cache: both ScanNet tables are 6.5 MB (13 MB together, cache-resident), so "
+                                "a frac beyond the achievable HBM rate (6.3 of 8 TB/s) is no HBM claim -- the gathers and the gradient sweep never reach HBM")
         out["algorithmic_table_bytes_per_step"] = sum(alg.values())
         step2 = build()
         win2 = us.MapWindow(step2, c2ws, pd, pc, pr, R // b, joint_opt=True, cam_lr=1e-3, has_zero_depth=None)
         win2.capture()
-        ms2, _ = timed(win2.replay)
+        ms2 = timed(win2.replay)[0]
         out["joint_opt_iteration_ms"] = ms2
         pd_full = torch.where(holes, torch.ones_like(pd), pd)
         step3 = build()
@@ -933,6 +1001,12 @@ def run_rank(args):
             # the other table kernels beside the dominant one (the encoder is the largest SINGLE kernel of the iteration)
             rec["roofline_by_kernel"] = {k: {"achieved": alg[k] / (kern[k] * 1e-3) / 1e9, "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "unit": "GB/s", "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": kern[k]} for k in alg}
+            if "hashgrid_fwd_joint" in rec["roofline_by_kernel"]:
+                try:
+                    rec["roofline_by_kernel"]["hashgrid_fwd_joint"]["l2_request"] = encoder_request_roofline((step.es.desc, step.ec.desc), step.pts[:R],
+                                                                                                             kern["hashgrid_fwd_joint"])
+                except Exception as e:                         # report, do not hide
+                    rec["roofline_by_kernel"]["hashgrid_fwd_joint"]["l2_request"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_extras:
             # also the forward-only rate (the render_img / meshing use) and the iteration without Adam
             def timed(fn, k=max(10, args.steps // 2)):
@@ -951,14 +1025,8 @@ def run_rank(args):
 
             def side_run(st):
                 n2, _ = make_runner(st)
-                for _ in range(args.warmup):
-                    n2()
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    l2 = n2()
-                torch.cuda.synchronize()
-                m2 = 1e3 * (time.perf_counter() - t1) / args.steps
-                return {"ms_per_step": m2, "rays_per_s": R / (m2 / 1e3), "final_loss": float(l2)}
+                m2, l2, ev2 = step_stats(n2, args.steps, args.warmup)
+                return {"ms_per_step": m2, "rays_per_s": R / (m2 / 1e3), "final_loss": float(l2), "step_time_hip_events": ev2}
             if args.mlp_precision != "fp32":
                 # the same iteration with f32-input MFMA decoders (exact fmaf chains, what the fixture comparisons run)
                 rec["fp32_decoders"] = side_run(build_step("fp32")[0])
@@ -984,9 +1052,9 @@ def run_rank(args):
                                                          "gradients and the poses' Adam group inside the iteration; `value` above is the iteration "
                                                          "with the poses fixed (the first five keyframes of a run)"}
         if world == 1 and not args.no_extras:
-            rec["drop_in_api"] = drop_in_bench(us, dev, args.mlp_precision, args.hidden, bound, mk, max(10, args.steps // 2), args.warmup, R, n_strat, n_imp)
+            rec["drop_in_api"] = drop_in_bench(us, dev, args.mlp_precision, args.hidden, bound, mk, args.steps, args.warmup, R, n_strat, n_imp)
         if world == 1 and not args.no_extras:
-            rec["config3"] = config3_bench(us, dev, args.mlp_precision, max(10, args.steps // 2), args.warmup)
+            rec["config3"] = config3_bench(us, dev, args.mlp_precision, args.steps, args.warmup)
         if world == 1 and not args.no_tracking:
             rec["tracking"] = tracking_bench(us, es, ec, dec, bound, dev)
         if world == 1 and not args.no_tracking and not args.no_extras:

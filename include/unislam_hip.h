@@ -155,32 +155,6 @@ int us_hashgrid_fwd_joint(const us_grid_desc* a, const us_grid_desc* b, const fl
  * produce zero records), so the counts depend on x only. */
 int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                           int64_t n, float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, void* stream);
-/* us_hashgrid_bwd_joint with torch.optim.Adam of the two tables' param groups (src/Mapper.py:118-126,443-445) applied INSIDE the accumulate
- * pass's sweep: the workgroup that owns an entry holds its final gradient sum in LDS, reads p, m, v of the entry and writes them back -- no
- * gradient table is written (write_grad = 0) and none is read back by an optimiser pass (at room0's sizes: 2 of the 7 streams of the dense
- * Adam and one kernel boundary less).  The arithmetic per element is us_adam_step_segments_dev's: the same bits as the separate pass.
- * Needs US_GRID_BWD_OVERWRITE | US_GRID_BWD_DETERMINISTIC (every entry is then written exactly once, by one workgroup; measured at no cost
- * against split bins) in this call and in the scan call; step_dev = the float[8] of us_adam_step_inc, ALREADY advanced for this optimiser
- * step.  gradA / gradB are still required (16-byte aligned): written only with write_grad != 0.  The decoders' (and the poses') group keeps its
- * own launch: us_adam_step_model with zero-length table segments. */
-typedef struct us_table_adam_desc {
-    float *pA, *mA, *vA;      /* table A: parameters, first and second moments (same indexing as gradA) */
-    float *pB, *mB, *vB;      /* table B */
-    double lrA, lrB, beta1, beta2, eps;
-    const float* step_dev;
-    int write_grad;
-} us_table_adam_desc;
-int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
-                               float* gradA, float* gradB, const us_table_adam_desc* adam, int flags, void* workspace, size_t workspace_bytes,
-                               void* stream);
-/* ONE PART of us_hashgrid_bwd_joint, cut by levels: what = 1 the record pass of levels [level_lo, level_hi), 2 the accumulate pass of those
- * levels' bins, 3 both.  The record pass is bound by vector issue, the accumulate pass by its record stream: a caller with two streams runs
- * the accumulate pass of the coarse levels BESIDE the record pass of the fine ones (MapStep.split_levels).  The parts of one pass together
- * give us_hashgrid_bwd_joint's result (every level once in each pass).  Needs the counts and scans in place (US_GRID_BWD_COUNTED |
- * US_GRID_BWD_SCANNED), unsplit bins (US_GRID_BWD_DETERMINISTIC) and US_GRID_BWD_OVERWRITE. */
-int us_hashgrid_bwd_joint_part(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB, int64_t n,
-                               float* gradA, float* gradB, int flags, void* workspace, size_t workspace_bytes, int level_lo, int level_hi, int what,
-                               void* stream);
 /* us_hashgrid_bwd_joint that ALSO leaves grid B's gradient as a bfloat16 image (gradB_bf16: uint16 [n_params of b], same indexing, rounded to
  * nearest even as a tensor copy rounds): the payload of a data-parallel all-reduce comes out of the accumulate pass's sweep instead of a
  * narrowing pass over the table (44.7 MB read + 22 MB written per step at room0's sizes).  Needs US_GRID_BWD_OVERWRITE and

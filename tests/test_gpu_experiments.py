@@ -113,3 +113,90 @@ def test_binned_backward_packed_records(us, log2T):
     ws4 = torch.empty(nb4, dtype=torch.uint8, device=DEV); g4 = torch.zeros(enc4.params.numel(), device=DEV)
     rc = lib.us_hashgrid_bwd_binned(ctypes.byref(enc4.desc), P(x4), P(dy4), 64, P(g4), L.US_GRID_BWD_PACKED, P(ws4), nb4, st)
     assert rc == L.US_ERR_CONFIG
+
+
+# ---- r6: moved here from the shipped suite together with their entry points: built, tested, measured slower
+from test_gpu_window import _window, _cfg as _wcfg, _ecfg, BOUND, W, LR  # noqa: E402
+
+
+def test_table_gradient_cut_by_levels_equals_the_whole_pass(us):
+    """us_hashgrid_bwd_joint_part: record pass and accumulate pass of level ranges, in any order that keeps a level's record pass ahead of its
+    accumulate pass, give the whole pass's gradient tables (unsplit bins: to the order of the f64 sums inside a bin)"""
+    import ctypes
+    from unislam_amd import _lib as L
+    torch.manual_seed(3)
+    n = 50000
+    ea, eb = us.HashGridEncoding(3, enc_cfg(14, 816)).to(DEV), us.HashGridEncoding(3, enc_cfg(17, 816)).to(DEV)
+    x = torch.rand(n, 3, device=DEV)
+    dya, dyb = torch.randn(16, n, 2, device=DEV), torch.randn(16, n, 2, device=DEV)
+    lib, P = L.lib(), L.ptr
+    da, db = ctypes.byref(ea.desc), ctypes.byref(eb.desc)
+    nb = int(lib.us_hashgrid_joint_workspace_bytes(da, db, n))
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    fa, fb = torch.empty(16 * n * 2, device=DEV), torch.empty(16 * n * 2, device=DEV)
+    st = L.stream()
+    L.check(lib.us_hashgrid_fwd_joint(da, db, P(ea.params.detach()), P(eb.params.detach()), P(x), n, P(fa), P(fb), 3, P(ws), nb, st), "fwd")
+    base = 3 | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_DETERMINISTIC
+    ga, gb = torch.empty(ea.desc.n_params, device=DEV), torch.empty(eb.desc.n_params, device=DEV)
+    L.check(lib.us_hashgrid_joint_scan(da, db, n, P(ga), P(gb), base, P(ws), nb, st), "scan")
+    flags = base | L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED
+    L.check(lib.us_hashgrid_bwd_joint(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, st), "whole")
+    ra, rb = ga.clone(), gb.clone()
+    for order in (((0, 7, 1), (7, 16, 1), (7, 16, 2), (0, 7, 2)), ((0, 3, 3), (3, 11, 1), (11, 16, 3), (3, 11, 2))):
+        ga.fill_(float("nan")); gb.fill_(float("nan"))
+        for lo, hi, what in order:
+            L.check(lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, lo, hi, what, st), "part")
+        for got, want in ((ga, ra), (gb, rb)):
+            assert torch.isfinite(got).all()
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), base, P(ws), nb, 0, 8, 1, st) == L.US_ERR_CONFIG   # no counts
+    assert lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, 5, 5, 1, st) == -2               # empty range
+
+
+@pytest.mark.parametrize("joint_opt", [False, True])
+def test_adam_in_the_accumulate_sweep_equals_the_separate_pass(us, joint_opt):
+    """MapStep.fuse_adam: the tables' optimiser step applied by the accumulate pass's sweep (us_hashgrid_bwd_joint_adam: the workgroup that
+    owns an entry reads p, m, v and writes them back) against the separate optimiser launch (us_adam_step_segments_dev) applied to the
+    SAME gradient -- the one the fused pass leaves with keep_table_grad -- from the same state: parameters and both moments of both tables
+    BIT FOR BIT, three iterations running (incl. entries of bins nothing lands in: the far levels of a small batch); and a whole fused
+    run lands where a run with the separate pass lands (to the rounding of the f64 sums, which differ from run to run in a few entries)."""
+    import ctypes
+    from unislam_amd import _lib as L
+    b, P, n_per = 6, 500, 100
+    c2ws, depths, colors, dirs = _window(b, P, 31)
+    g = torch.Generator().manual_seed(4)
+    draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.rand(b * n_per, 40, generator=g).to(DEV)) for _ in range(4)]
+
+    def build(fuse):
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_wcfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(16)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per)
+        step.fuse_adam, step.keep_table_grad = fuse, fuse
+        return step, us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=joint_opt, cam_lr=1e-3, has_zero_depth=False)
+
+    step, win = build(True)
+    segs = [(step.o_tab_s, step.es.desc.n_params, LR["sdf_grid"]), (step.o_tab_c, step.ec.desc.n_params, LR["color_grid"])]
+    I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
+    for idx, tr in draws[:3]:
+        p0, m0, v0, sd0 = step.flat.clone(), step.m.clone(), step.v.clone(), step.step_dev.clone()
+        win.iterate(idx, None, t_rand=tr)
+        gcopy = step.grad.clone()                                 # (the fused pass wrote the table segments: keep_table_grad)
+        L.check(L.lib().us_adam_step_segments_dev(L.ptr(p0), L.ptr(gcopy), L.ptr(m0), L.ptr(v0), 2, I64(*[s_[0] for s_ in segs]), I64(*[s_[1] for s_ in segs]),
+                                                  DBL(*[s_[2] for s_ in segs]), 0.9, 0.999, 1e-8, L.ptr(sd0), 0, L.stream()), "adam")
+        assert torch.equal(sd0, step.step_dev)                    # the same step count and bias corrections
+        for got, want, name in ((step.flat, p0, "parameters"), (step.m, m0, "first moments"), (step.v, v0, "second moments")):
+            assert torch.equal(got[step.o_tab_s:], want[step.o_tab_s:]), name
+        assert float((step.m[step.o_tab_s:] != 0).float().mean()) > 0.01
+    # a whole run either way
+    outs = []
+    for fuse in (False, True):
+        step, win = build(fuse)
+        losses = [float(win.iterate(idx, None, t_rand=tr)) for idx, tr in draws]
+        outs.append((step.flat.clone(), win.poses.clone(), losses))
+    np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=1e-5)
+    d = (outs[0][0] - outs[1][0]).abs()
+    assert float((d > 1e-6).float().mean()) < 1e-4 and float(d.max()) < 2e-3, (float((d > 1e-6).float().mean()), float(d.max()))
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-6)

@@ -182,38 +182,3 @@ def test_deterministic_table_gradient_repeats_bit_for_bit(us, joint):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for k in range(2):
         assert torch.allclose(outs[0][k], outs[2][k], rtol=1e-4, atol=2e-6 * float(outs[2][k].abs().max()))
-
-
-def test_table_gradient_cut_by_levels_equals_the_whole_pass():
-    """us_hashgrid_bwd_joint_part: record pass and accumulate pass of level ranges, in any order that keeps a level's record pass ahead of its
-    accumulate pass, give the whole pass's gradient tables (unsplit bins: to the order of the f64 sums inside a bin)"""
-    import ctypes
-    import unislam_amd as us
-    from unislam_amd import _lib as L
-    torch.manual_seed(3)
-    n = 50000
-    ea, eb = us.HashGridEncoding(3, _cfg(14)).to(DEV), us.HashGridEncoding(3, _cfg(17)).to(DEV)
-    x = torch.rand(n, 3, device=DEV)
-    dya, dyb = torch.randn(16, n, 2, device=DEV), torch.randn(16, n, 2, device=DEV)
-    lib, P = L.lib(), L.ptr
-    da, db = ctypes.byref(ea.desc), ctypes.byref(eb.desc)
-    nb = int(lib.us_hashgrid_joint_workspace_bytes(da, db, n))
-    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    fa, fb = torch.empty(16 * n * 2, device=DEV), torch.empty(16 * n * 2, device=DEV)
-    st = L.stream()
-    L.check(lib.us_hashgrid_fwd_joint(da, db, P(ea.params.detach()), P(eb.params.detach()), P(x), n, P(fa), P(fb), 3, P(ws), nb, st), "fwd")
-    base = 3 | L.US_GRID_BWD_OVERWRITE | L.US_GRID_BWD_DETERMINISTIC
-    ga, gb = torch.empty(ea.desc.n_params, device=DEV), torch.empty(eb.desc.n_params, device=DEV)
-    L.check(lib.us_hashgrid_joint_scan(da, db, n, P(ga), P(gb), base, P(ws), nb, st), "scan")
-    flags = base | L.US_GRID_BWD_COUNTED | L.US_GRID_BWD_SCANNED
-    L.check(lib.us_hashgrid_bwd_joint(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, st), "whole")
-    ra, rb = ga.clone(), gb.clone()
-    for order in (((0, 7, 1), (7, 16, 1), (7, 16, 2), (0, 7, 2)), ((0, 3, 3), (3, 11, 1), (11, 16, 3), (3, 11, 2))):
-        ga.fill_(float("nan")); gb.fill_(float("nan"))
-        for lo, hi, what in order:
-            L.check(lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, lo, hi, what, st), "part")
-        for got, want in ((ga, ra), (gb, rb)):
-            assert torch.isfinite(got).all()
-            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
-    assert lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), base, P(ws), nb, 0, 8, 1, st) == L.US_ERR_CONFIG   # no counts
-    assert lib.us_hashgrid_bwd_joint_part(da, db, P(x), P(dya), P(dyb), n, P(ga), P(gb), flags, P(ws), nb, 5, 5, 1, st) == -2               # empty range

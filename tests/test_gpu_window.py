@@ -538,6 +538,47 @@ def test_a_captured_iteration_does_not_keep_its_owner_in_a_cycle():
             gc.enable()
 
 
+def test_graph_registry_releases_oldest_first_while_newer_graphs_replay():
+    """graph.py's FIFO release on real graphs (each MapWindow graph forks side streams): the OLDEST graph is destroyed once its owner is
+    gone -- before the next capture -- and the newer ones keep replaying (the opposite order is the runtime fault of
+    profiles/r05_hipgraph_destroy_segv.txt); a graph whose owner died behind a LIVING older one waits for it.  tools/graph_fifo_check.py is
+    the long form (profiles/r06_graph_fifo.txt)."""
+    import gc
+    import unislam_amd as us
+    from unislam_amd import graph
+
+    def make(seed):
+        torch.manual_seed(seed)
+        dec = us.Decoders(_cfg(False), c_dim=32, truncation=0.06).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(15)).to(DEV)
+        c2ws, depths, colors, dirs = _window(4, 300, seed)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=4 * 48)
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, 48, joint_opt=True, cam_lr=1e-3, has_zero_depth=False)
+        win.capture()
+        return win
+
+    gc.collect(); graph.collect()
+    n0 = len(graph._KEEP)                                       # graphs of earlier tests whose owners are alive (or wait behind one that is)
+    a, b, c = make(1), make(2), make(3)
+    assert len(graph._KEEP) == n0 + 3
+    del b; gc.collect()
+    graph.collect()
+    assert len(graph._KEEP) == n0 + 3                           # b's graph waits: a's is older and alive
+    for _ in range(5):
+        a.replay(); c.replay()
+    del a; gc.collect()
+    released = graph.collect()
+    assert len(graph._KEEP) == n0 + 3 - released and (released == 2 or n0 > 0)    # nothing older alive: a's and b's go, oldest first
+    for _ in range(10):
+        la = c.replay()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(la))
+    d = make(4)                                                 # (a capture runs collect() itself)
+    for _ in range(5):
+        d.replay(); c.replay()
+    torch.cuda.synchronize()
+
+
 def test_track_step_keeps_the_minimum_loss_pose_and_mean_uncertainty():
     """us_pose_track_step: the pose step with the tracker's minimum-loss bookkeeping in its launch (src/Tracker.py:346-348) against
     us_pose_window_step + the same bookkeeping on torch ops, both chains, bit for bit; us_masked_mean against torch (:353)"""
@@ -696,53 +737,3 @@ def test_pose_group_rides_in_the_optimiser_launch(arena):
     for k in (4, 5, 6):
         assert torch.equal(a[k], c[k]), k
     assert float(a[5].abs().max()) > 0                                          # the poses' moments did move
-
-
-@pytest.mark.parametrize("joint_opt", [False, True])
-def test_adam_in_the_accumulate_sweep_equals_the_separate_pass(joint_opt):
-    """MapStep.fuse_adam: the tables' optimiser step applied by the accumulate pass's sweep (us_hashgrid_bwd_joint_adam: the workgroup that
-    owns an entry reads p, m, v and writes them back) against the separate optimiser launch (us_adam_step_segments_dev) applied to the
-    SAME gradient -- the one the fused pass leaves with keep_table_grad -- from the same state: parameters and both moments of both tables
-    BIT FOR BIT, three iterations running (incl. entries of bins nothing lands in: the far levels of a small batch); and a whole fused
-    run lands where a run with the separate pass lands (to the rounding of the f64 sums, which differ from run to run in a few entries)."""
-    import ctypes
-    import unislam_amd as us
-    from unislam_amd import _lib as L
-    b, P, n_per = 6, 500, 100
-    c2ws, depths, colors, dirs = _window(b, P, 31)
-    g = torch.Generator().manual_seed(4)
-    draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.rand(b * n_per, 40, generator=g).to(DEV)) for _ in range(4)]
-
-    def build(fuse):
-        torch.manual_seed(0)
-        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": "bf16"}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
-        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(16)).to(DEV)
-        with torch.no_grad():
-            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
-        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per)
-        step.fuse_adam, step.keep_table_grad = fuse, fuse
-        return step, us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=joint_opt, cam_lr=1e-3, has_zero_depth=False)
-
-    step, win = build(True)
-    segs = [(step.o_tab_s, step.es.desc.n_params, LR["sdf_grid"]), (step.o_tab_c, step.ec.desc.n_params, LR["color_grid"])]
-    I64, DBL = ctypes.c_int64 * 2, ctypes.c_double * 2
-    for idx, tr in draws[:3]:
-        p0, m0, v0, sd0 = step.flat.clone(), step.m.clone(), step.v.clone(), step.step_dev.clone()
-        win.iterate(idx, None, t_rand=tr)
-        gcopy = step.grad.clone()                                 # (the fused pass wrote the table segments: keep_table_grad)
-        L.check(L.lib().us_adam_step_segments_dev(L.ptr(p0), L.ptr(gcopy), L.ptr(m0), L.ptr(v0), 2, I64(*[s_[0] for s_ in segs]), I64(*[s_[1] for s_ in segs]),
-                                                  DBL(*[s_[2] for s_ in segs]), 0.9, 0.999, 1e-8, L.ptr(sd0), 0, L.stream()), "adam")
-        assert torch.equal(sd0, step.step_dev)                    # the same step count and bias corrections
-        for got, want, name in ((step.flat, p0, "parameters"), (step.m, m0, "first moments"), (step.v, v0, "second moments")):
-            assert torch.equal(got[step.o_tab_s:], want[step.o_tab_s:]), name
-        assert float((step.m[step.o_tab_s:] != 0).float().mean()) > 0.01
-    # a whole run either way
-    outs = []
-    for fuse in (False, True):
-        step, win = build(fuse)
-        losses = [float(win.iterate(idx, None, t_rand=tr)) for idx, tr in draws]
-        outs.append((step.flat.clone(), win.poses.clone(), losses))
-    np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=1e-5)
-    d = (outs[0][0] - outs[1][0]).abs()
-    assert float((d > 1e-6).float().mean()) < 1e-4 and float(d.max()) < 2e-3, (float((d > 1e-6).float().mean()), float(d.max()))
-    assert torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-6)

@@ -1,5 +1,5 @@
 """development (r5): the table gradient cut by levels -- the accumulate pass of the coarse levels beside the record pass of the fine ones on a
-second stream (us_hashgrid_bwd_joint_part) -- against the whole pass, at the bench shape: same gradients, wall time per variant.
+second stream (us_hashgrid_bwd_joint_part: EXPERIMENTS build, tools/build_experiments.sh) -- against the whole pass, at the bench shape: same gradients, wall time per variant.
    python tools/split_levels.py"""
 import ctypes, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)

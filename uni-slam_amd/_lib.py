@@ -65,7 +65,7 @@ class PoseStepDesc(ctypes.Structure):
 
 
 class TableAdamDesc(ctypes.Structure):
-    """include/unislam_hip.h: us_table_adam_desc -- the tables' Adam step applied inside the accumulate pass (us_hashgrid_bwd_joint_adam)"""
+    """include/unislam_hip_experiments.h: us_table_adam_desc -- the tables' Adam step applied inside the accumulate pass (us_hashgrid_bwd_joint_adam)"""
     _fields_ = [("pA", ctypes.c_void_p), ("mA", ctypes.c_void_p), ("vA", ctypes.c_void_p), ("pB", ctypes.c_void_p), ("mB", ctypes.c_void_p),
                 ("vB", ctypes.c_void_p), ("lrA", ctypes.c_double), ("lrB", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
                 ("eps", ctypes.c_double), ("step_dev", ctypes.c_void_p), ("write_grad", ctypes.c_int)]
@@ -90,8 +90,6 @@ SIGNATURES = {
     "us_hashgrid_joint_workspace_bytes": (ctypes.c_size_t, [_GP, _GP, c_i64]),
     "us_hashgrid_fwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
-    "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.POINTER(TableAdamDesc), c_int, c_f, ctypes.c_size_t, c_f]),
-    "us_hashgrid_bwd_joint_part": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_int, c_int, c_int, c_f]),
     "us_hashgrid_bwd_joint_img": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_joint_range": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
     "us_hashgrid_bwd_binned_range": (c_int, [_GP, c_f, c_f, c_i64, c_i64, c_f, c_int, c_f, ctypes.c_size_t, c_f]),
@@ -181,6 +179,8 @@ SIGNATURES = {
 # the experiments build (tools/build_experiments.sh, include/unislam_hip_experiments.h): bound when the loaded library exports them
 EXPERIMENT_SIGNATURES = {
     "us_encode_decode_supported": (c_int, [_GP, _GP, _MP, _MP]),
+    "us_hashgrid_bwd_joint_adam": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.POINTER(TableAdamDesc), c_int, c_f, ctypes.c_size_t, c_f]),
+    "us_hashgrid_bwd_joint_part": (c_int, [_GP, _GP, c_f, c_f, c_f, c_i64, c_f, c_f, c_int, c_f, ctypes.c_size_t, c_int, c_int, c_int, c_f]),
     "us_encode_decode_fwd": (c_int, [_GP, _GP, c_f, c_f, _MP, _MP, c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_i64, c_int, c_f]),
 }
 

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
         };
         auto copy_out = [&](uint32_t cnt, const uint32_t* gr, uint32_t sb, auto with_entries) {
             auto put = [&](const uint2 a, const uint32_t z, uint32_t k) {
-#if defined(J_WR_X_NOATOMIC) || defined(J_WR_X_LINEAR_STAGE)      // (timing experiments: the stage is in no order; keep the copy-out's stores contiguous)
+#if defined(US_EXPERIMENTS) && (defined(J_WR_X_NOATOMIC) || defined(J_WR_X_LINEAR_STAGE))      // (timing experiments: the stage is in no order; keep the copy-out's stores contiguous)
                 const uint32_t R = (uint32_t)(((uint64_t)(blockIdx.x * n_levels + level) * J_STAGE + k + sb + (gr[(a.x >> 16) & (J_LVL_BINS - 1)] & 0u)) % rec_cap);
 #else
                 const uint32_t R = gr[a.x >> 16] + k + sb;
@@ -702,9 +702,9 @@ __global__ __launch_bounds__(J_ROW_POINTS, 4) void k_jwrite(JLevels lv, uint32_t
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     k8[c] = 0xFFFFu;
-#if defined(J_WR_X_NOATOMIC)         // timing experiment (garbage results): no cursor atomics, conflict-free stage positions
+#if defined(US_EXPERIMENTS) && defined(J_WR_X_NOATOMIC)         // timing experiment (garbage results): no cursor atomics, conflict-free stage positions
                     if ((tail >> c) & 1u) k8[c] = (uint32_t)c * J_ROW_POINTS + tid;
-#elif defined(J_WR_X_LINEAR_STAGE)   // timing experiment (garbage results): the atomics run, the stage positions are conflict-free
+#elif defined(US_EXPERIMENTS) && defined(J_WR_X_LINEAR_STAGE)   // timing experiment (garbage results): the atomics run, the stage positions are conflict-free
                     if ((tail >> c) & 1u) { const uint32_t dummy = atomicAdd(&cur[par][(e[c] >> BIN_LINE_LOG2) & nbm], 1u); k8[c] = dummy < 0xFFFFFFFFu ? (uint32_t)c * J_ROW_POINTS + tid : 0u; }
 #else
                     if ((tail >> c) & 1u) k8[c] = atomicAdd(&cur[par][(e[c] >> BIN_LINE_LOG2) & nbm], 1u);
@@ -873,6 +873,13 @@ __global__ __launch_bounds__(256) void k_jitems(JLevels lv, uint32_t n_levels, u
 // bin, at the moment its final sum stands in LDS -- so that workgroup reads p, m, v of the entry and writes them back: no gradient table
 // written (write_grad 0), none read back by an optimiser pass, one kernel boundary less.  The arithmetic per element is adam_segs_body's
 // (render.hip): the same bits as the separate pass.  p == nullptr: off.
+// (the tables' optimiser step inside the sweep is an EXPERIMENTS entry point -- us_hashgrid_bwd_joint_adam, measured slower than the separate
+//  streaming pass: DESIGN.md 9 -- so the shipped build compiles its branches out of k_jaccum_p)
+#ifdef US_EXPERIMENTS
+#define J_ADAM_IN_SWEEP(ta) ((ta).pA != nullptr)
+#else
+#define J_ADAM_IN_SWEEP(ta) false
+#endif
 struct JTableAdam {
     float *pA, *mA, *vA, *pB, *mB, *vB;
     float lrA, lrB, one_minus_b1, b2, one_minus_b2, eps;
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < J_ACC_DOUBLES + 4 * 8; k += J_ACC_THREADS) acc[k] = 0.0;
     float ssA = 0.0f, ssB = 0.0f, bc2s = 1.0f;                   // Adam in the sweep: step sizes lr / (1 - b1^t), sqrt(1 - b2^t) as k_adam_segs forms them
-    if (ta.pA) {
+    if (J_ADAM_IN_SWEEP(ta)) {
         const double* aux = reinterpret_cast<const double*>(ta.step_dev + 2);
         ssA = (float)((double)ta.lrA / aux[0]); ssB = (float)((double)ta.lrB / aux[0]); bc2s = (float)aux[1];
     }
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
             if (e >= hs) continue;
             float* p = gl + (size_t)e * 2u;
             const float v0 = (float)s0, v1 = (float)s1;
-            if (ta.pA && !hot) {                                 // (deterministic mode: no bin is hot)
+            if (J_ADAM_IN_SWEEP(ta) && !hot) {                                 // (deterministic mode: no bin is hot)
                 const size_t o = ((size_t)goff + e) * 2u;
                 j_adam2(v0, v1, (side ? ta.pB : ta.pA) + o, (side ? ta.mB : ta.mA) + o, (side ? ta.vB : ta.vA) + o, side ? ssB : ssA, bc2s, ta);
                 if (ta.write_grad) *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
@@ -1077,7 +1084,7 @@ __global__ __launch_bounds__(J_ACC_THREADS, 8) void k_jaccum_p(uint32_t e_max, u
         float* gl = (((zm >> 24) & 1u) ? gradB : gradA) + (size_t)zitems[JI_GOFF][z] * 2u;
         for (uint32_t loc = tid; loc < znl; loc += J_ACC_THREADS) {
             const uint32_t e = entry_of(loc, zm & 0xFFFFu, (zm >> 16) & 0xFFu);
-            if (e < zhs && ta.pA) {                              // a zero gradient still moves the entry: m and v decay, p follows m
+            if (e < zhs && J_ADAM_IN_SWEEP(ta)) {                              // a zero gradient still moves the entry: m and v decay, p follows m
                 const uint32_t zs = (zm >> 24) & 1u;
                 const size_t o = ((size_t)zitems[JI_GOFF][z] + e) * 2u;
                 j_adam2(0.0f, 0.0f, (zs ? ta.pB : ta.pA) + o, (zs ? ta.mB : ta.mA) + o, (zs ? ta.vB : ta.vA) + o, zs ? ssB : ssA, bc2s, ta);
@@ -1380,6 +1387,7 @@ extern "C" int us_hashgrid_bwd_joint(const us_grid_desc* a, const us_grid_desc* 
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false);
 }
 
+#ifdef US_EXPERIMENTS                    // measured-slower variants, kept buildable: tools/build_experiments.sh (include/unislam_hip_experiments.h)
 extern "C" int us_hashgrid_bwd_joint_adam(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA, const float* dL_dyB,
                                           int64_t n, float* gradA, float* gradB, const us_table_adam_desc* adam, int flags, void* workspace,
                                           size_t workspace_bytes, void* stream) {
@@ -1409,6 +1417,7 @@ extern "C" int us_hashgrid_bwd_joint_part(const us_grid_desc* a, const us_grid_d
     US_REQUIRE(n > 0, US_ERR_SHAPE, "us_hashgrid_bwd_joint_part: n %lld", (long long)n);
     return bwd_joint(a, b, x, dL_dyA, dL_dyB, n, gradA, gradB, flags, workspace, workspace_bytes, stream, false, 0, nullptr, nullptr, level_lo, level_hi, what);
 }
+#endif
 
 extern "C" int us_hashgrid_bwd_joint_img(const us_grid_desc* a, const us_grid_desc* b, const float* x, const float* dL_dyA,
                                          const float* dL_dyB, int64_t n, float* gradA, float* gradB, uint16_t* gradB_bf16, int flags,

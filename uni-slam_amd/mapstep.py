@@ -38,11 +38,29 @@ class MapStep:
     # optimiser step rides in the accumulate pass (fuse_adam): scan call and gradient call must agree
     @property
     def _det(self):
-        return self._det_base | (L.US_GRID_BWD_DETERMINISTIC if getattr(self, "fuse_adam", False) else 0)
+        return self._det_base | (L.US_GRID_BWD_DETERMINISTIC if getattr(self, "_fuse_adam", False) else 0)
 
     @_det.setter
     def _det(self, v):
         self._det_base = int(v)
+
+    # fuse_adam (EXPERIMENTS build only: us_hashgrid_bwd_joint_adam, include/unislam_hip_experiments.h): see __init__
+    @property
+    def fuse_adam(self):
+        return self._fuse_adam
+
+    @fuse_adam.setter
+    def fuse_adam(self, on):
+        on = bool(on)
+        if on and not L.has_experiments():
+            raise L.UniSlamHipError("MapStep.fuse_adam: us_hashgrid_bwd_joint_adam belongs to the experiments build (tools/build_experiments.sh); "
+                                    "it was measured slower than the separate optimiser pass (DESIGN.md 9)")
+        if on != getattr(self, "_fuse_adam", False):
+            # the bin policy changes with it (no split bins): counts / scans of a pending forward pass and captured graphs are void
+            self._jcounted = False
+            self._graph = None
+            self.generation = getattr(self, "generation", 0) + 1
+        self._fuse_adam = on
 
     def __init__(self, hash_grid_sdf, hash_grid_color, decoders, bound, n_stratified, n_importance, truncation,
                  weights, lr, mask_mode="original", perturb=True, max_rays=4096, group=None, bwd_mode=-1, overlap=None, grad_comm=None, sharded_adam=False,
@@ -92,7 +110,7 @@ class MapStep:
         # deterministic: hot bins of the table gradient are not split over workgroups (US_GRID_BWD_DETERMINISTIC): no float atomics, the
         # gradients repeat bit for bit from run to run (the decoder gradients already do: per-workgroup partials, fixed-order sums)
         self._det = L.US_GRID_BWD_DETERMINISTIC if deterministic else 0
-        # fuse_adam (r5; single process, joint kernels; set it before the first iteration): iterate() applies the tables' Adam step INSIDE the
+        # fuse_adam (r5; EXPERIMENTS build, single process, joint kernels): iterate() applies the tables' Adam step INSIDE the
         # accumulate pass's sweep (us_hashgrid_bwd_joint_adam) -- no gradient table written, none read back, the optimiser launch shrinks to
         # the decoders' (and poses') group.  Every entry is then written exactly once, by one workgroup: bins are not split
         # (US_GRID_BWD_DETERMINISTIC, measured at no cost: 0.4886 against 0.4884 ms at 4096 x 64, 0.508 against 0.507 with all rays from ONE
@@ -703,6 +721,9 @@ class MapStep:
             self._timed("hashgrid_dydx_rays", lambda: lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s),
                                                                                 P(self.dydx_c), R, S, P(self.z), self.bhost, P(self.g_o), P(self.g_d),
                                                                                 None, st))
+        elif getattr(self, "_tables_stepped", False):
+            raise L.UniSlamHipError("MapStep: ray gradients after fuse_adam need the encoder's dy/dx (store_dydx, S <= 128): the gathering fallbacks would "
+                                    "read tables the accumulate pass's sweep has already stepped")
         elif lib.us_hashgrid_bwd_input_rays_supported(ds, dc, S):
             # both grids' input gradient and its reduction to the rays in ONE launch (no [N,3] round trip, no second gather launch)
             self._timed("hashgrid_bwd_input_rays", lambda: lib.us_hashgrid_bwd_input_rays(
@@ -758,7 +779,7 @@ class MapStep:
         over workgroups (US_GRID_BWD_DETERMINISTIC from here on, in the scan passes too).  Returns whether the path is taken."""
         ok = bool(on) and self.joint and self.dp_mode == "local_fast"
         if ok and not self._grad_image:
-            self._det_before_image = self._det
+            self._det_before_image = self._det_base               # (what the constructor asked for: not the fuse_adam bit of the property)
             self._det = L.US_GRID_BWD_DETERMINISTIC
         elif not ok and self._grad_image:
             self._det = getattr(self, "_det_before_image", 0)    # what the constructor's `deterministic` asked for
