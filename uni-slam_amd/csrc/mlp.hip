@@ -103,7 +103,16 @@ __device__ __forceinline__ void relu_(v4f (&h)[NQ][MT]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[q][m][r] = fmaxf(h[q][m][r], 0.0f);
+            for (int r = 0; r < 4; ++r) {
+                // ONE instruction: v_max_i32(bits, 0) -- a negative float (and -0.0) is a negative integer, a positive one a positive integer,
+                // so the signed-integer maximum with 0 IS ReLU for every non-NaN x.  fmaxf(x, 0) compiles to two (a canonicalising
+                // v_max_f32 x, x in front; so does v_med3(x, 0, inf), which LLVM folds back to maxnum), and the decoder kernels are bound by
+                // VALU issue (profiles/r06_mlp_pmc.txt: 91 % of the forward kernel's cycles issue a VALU instruction).  Not inline assembly: the
+                // hazard recogniser does not see through it, and a VALU read of an MFMA result needs wait states (an asm v_max read stale
+                // accumulators in the f32 kernel).
+                const int b = __float_as_int(h[q][m][r]);
+                h[q][m][r] = __int_as_float(b > 0 ? b : 0);
+            }
 }
 
 // dh *= (h > 0)
@@ -164,16 +173,19 @@ __device__ __forceinline__ void load_weights(float* lds, const float* __restrict
 
 // input features of 64 points as B operands: xb[q][b][c] = in[p(q)][16b + 4g + c]
 // LM: level-major planes [NIN/2][N][2]: features 16b+4g .. +3 are planes 8b+2g and 8b+2g+1 (two float2 loads)
-template <int NQ, int NIN>
+// CLAMP (forward kernels: a row beyond n is computed and never stored): rows beyond n read row n - 1 instead of taking zeros -- no zero
+// initialisation of the 16 input registers and no divergent branch around the loads of every chunk
+template <int NQ, int NIN, bool CLAMP = false>
 __device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_t base, int64_t n, int row, int g,
                                             v4f (&xb)[NQ][NIN / 16], int lm) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int64_t p = base + 16 * q + row;
+        int64_t p = base + 16 * q + row;
+        if (CLAMP) p = p < n ? p : n - 1;
 #pragma unroll
         for (int b = 0; b < NIN / 16; ++b) {
             v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (p < n) {
+            if (CLAMP || p < n) {
                 if (lm) {
                     const float2 lo = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g) * n + p) * 2);
                     const float2 hi = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g + 1) * n + p) * 2);

@@ -187,9 +187,9 @@ class Renderer(object):
         # on the device: Renderer.py:83-84 rebuilds them every call
         self._t_uni = torch.linspace(0., 1., steps=self.n_stratified).to(self.device)
         self._t_surf = torch.linspace(0., 1., steps=self.n_importance).to(self.device)
-        # the jitter of a batch whose rays all carry a depth is drawn inside the sampling launch (a counter-based generator):
-        # seeded from torch's seed at construction, advanced per call
-        self._rng_seed, self._rng_calls = int(torch.initial_seed()) & (2 ** 63 - 1), 0
+        # the jitter of a batch whose rays all carry a depth is drawn inside the sampling launch (a counter-based generator) whose seed is
+        # drawn PER CALL from torch's default CPU generator (r6): torch.manual_seed() governs it whenever it is called, and two Renderers
+        # (the tracker's and the mapper's copies of one pickled renderer) do not repeat each other's jitter
 
     def perturbation(self, z_vals):
         """Renderer.py:42-57"""
@@ -217,8 +217,7 @@ class Renderer(object):
         gt_mask = None if all_depth else (gt_depth > 0).squeeze(-1)
         if all_depth and n_rays > 0:
             # z sampling + jitter + points in ONE launch (us_sample_points)
-            self._rng_calls += 1
-            seed = (self._rng_seed + 0x9E3779B97F4A7C15 * self._rng_calls) & (2 ** 64 - 1)
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if (self.perturb and t_rand is None) else 0   # (a CPU draw: no device sync)
             z_vals, pts = _SamplePointsFn.apply(rays_o, rays_d, gt_depth, self._bhost, self._t_uni, self._t_surf, float(truncation),
                                                 t_rand, seed, bool(self.perturb))
             return self._decode_composite(scene_rep, decoders, pts, z_vals, device)
