@@ -79,3 +79,43 @@ def test_graph_registry_keeps_and_releases(monkeypatch):
     monkeypatch.setenv("US_KEEP_GRAPHS", "0")                      # the old behaviour, for reproducing the runtime fault
     graph._keep(sentinel)
     assert graph._KEEP == []
+
+
+def test_torch_draws_is_torch_s_global_stream():
+    """slam.TorchDraws(state) hands out what torch's global CPU generator hands the reference from that state: same numbers for the same
+    calls in the same order (randint / rand / randperm interleaved as the loop interleaves them)"""
+    from unislam_amd.slam import TorchDraws
+    torch.manual_seed(77)
+    state = torch.get_rng_state().clone()
+    want = [torch.randint(2240, (200,)), torch.rand(197, 40), torch.randint(3072, (50,)), torch.randperm(3072)[:307], torch.rand(0, 40),
+            torch.randint(307, (400,)), torch.randperm(0), torch.rand(400, 40)]
+    d = TorchDraws(state=state.numpy())
+    got = [d.randint(2240, 200), d.rand(197, 40), d.randint(3072, 50), d.randperm(3072)[:307], d.rand(0, 40), d.randint(307, 400), d.randperm(0),
+           d.rand(400, 40)]
+    for a, b in zip(want, got):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert not torch.equal(TorchDraws(seed=1).rand(3, 3), TorchDraws(seed=2).rand(3, 3))
+
+
+def test_jitter_rows_follow_the_reference_s_compaction():
+    """slam._jitter_rows: the reference draws rand(R', S) for the rays that passed the pre-filter AND carry a depth (src/Mapper.py:403-406,
+    src/utils/Renderer.py:87-101), then -- if any ray has no depth -- rand(n0, n_strat) and rand(n0, n_imp) for those (Renderer.py:117,
+    common.py:64); the kernels take t_rand by ROW and the zero-depth draws by COMPACTED ROW of !(depth > 0), pre-filtered or not"""
+    from unislam_amd.slam import TorchDraws, _jitter_rows
+    valid = torch.tensor([1, 0, 1, 1, 0, 1, 1, 0], dtype=torch.uint8)
+    gd = torch.tensor([1.0, 2.0, 0.0, 3.0, 0.0, 0.5, 0.0, 0.0])
+    S, ns, ni = 5, 3, 2
+    g = torch.Generator().manual_seed(3)
+    ref_t, ref_u0, ref_u1 = torch.rand(3, S, generator=g), torch.rand(2, ns, generator=g), torch.rand(2, ni, generator=g)   # rows 0, 3, 5 | rows 2, 6
+    t_rand, zd = _jitter_rows(TorchDraws(seed=3), valid, gd, S, ns, ni, True, True)
+    assert torch.equal(t_rand[[0, 3, 5]], ref_t) and float(t_rand[[1, 2, 4, 6, 7]].abs().sum()) == 0.0
+    # rows without a depth: 2, 4, 6, 7 -> compacted 0, 1, 2, 3; of those 2 and 6 passed the pre-filter: compacted rows 0 and 2
+    assert torch.equal(zd[0][[0, 2]], ref_u0) and torch.equal(zd[1][[0, 2]], ref_u1) and float(zd[0][[1, 3]].abs().sum()) == 0.0
+    # no jitter (perturb off): nothing is drawn for t_rand, the inverse-transform draws still are
+    t2, zd2 = _jitter_rows(TorchDraws(seed=3), valid, gd, S, ns, ni, False, True)
+    g2 = torch.Generator().manual_seed(3)
+    assert float(t2.abs().sum()) == 0.0 and torch.equal(zd2[1][[0, 2]], torch.rand(2, ni, generator=g2)) and float(zd2[0].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="without a depth"):
+        _jitter_rows(TorchDraws(seed=3), valid, gd, S, ns, ni, True, False)
+    t3, zd3 = _jitter_rows(TorchDraws(seed=3), torch.ones(4, dtype=torch.uint8), torch.ones(4), S, ns, ni, True, False)
+    assert zd3 is None and torch.equal(t3, torch.rand(4, S, generator=torch.Generator().manual_seed(3)))
