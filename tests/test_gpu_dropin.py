@@ -4,8 +4,11 @@ reference's three param groups: src/networks/decoders.py:91-105,182-205, src/uti
 443-445) on the kernels of the straight-line mapping step: Decoders.forward as ONE autograd node (joint encoder, decoder pair, joint
 binned table gradient), one-launch sampling, and unislam_amd.optim.Adam (one launch per optimizer.step()).
 
-Held against the two-module path (encoder and decoder as separate autograd nodes: the round-1 kernels, themselves pinned by fixtures
-g4 / g7 / g9): features' effect on raw within 1e-6, table gradients within 1e-4 of the largest gradient, decoder gradients 1e-4.
+Held against the two-module path (encoder and decoder as separate autograd nodes; r6: on the counted / scanned kernels with a cached
+scratch): features' effect on raw within 1e-6, table gradients within 1e-4 of the largest gradient, decoder gradients 1e-4 -- HIP against
+HIP.  What anchors the node itself: fixtures g4 / g7 / g9 (tests/test_gpu_parity.py, test_gpu_step.py) run THROUGH it since r5, and (r6)
+test_one_node_forward_at_full_size_against_the_oracle / test_module_seam_alone_against_the_oracle below compare node and seam with the CPU
+oracle directly at BASELINE configs[1]'s 262 144 points.
 """
 import copy
 

@@ -305,7 +305,7 @@ def test_soak_on_the_closed_loop_bounds_every_frame():
           f"{100 * float(err[-40:].max()):.2f} cm, keyframes {len(slam.mapper.keyframe_list)}, LC {slam.mapper.LC_cnt}, kinds {kc}")
     assert len(slam.mapper.keyframe_list) > 60
     assert sum(v for k, v in kc.items() if k[1]) >= 30                       # windows with the extra rays
-    assert float(err.max()) < 0.07, float(err.max())                         # every frame within 7 cm (measured: 3.5 - 4.1 cm, at the bare wall of frames 35 - 51)
+    assert float(err.max()) < 0.07, float(err.max())                         # every frame within 7 cm (measured over rounds 5-6: 3.5 - 4.7 cm, at the bare wall of frames 35 - 51)
     assert slam.ate_rmse() < 0.03
     assert float(err[-40:].max()) < 0.04                                     # the second pass over the start is no worse than the first
     rot = torch.linalg.matrix_norm(slam.estimate_c2w_list[:n, :3, :3] - slam.gt_c2w_list[:n, :3, :3])
