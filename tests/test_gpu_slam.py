@@ -284,6 +284,40 @@ def test_g16_policy_one_frame_at_a_time_from_the_reference_state(golden):
         np.testing.assert_allclose(est[:3, :3], ref[:3, :3], atol=4e-4 if not mapped else 1e-3)
 
 
+@pytest.mark.parametrize("k,nf", [(12, 3), (16, 2)])
+def test_g16_consecutive_frames_from_a_snapshot_carry_the_loop_state(golden, k, nf):
+    """the hand-over BETWEEN frames, from the reference's state at frame k (fixture g16) over nf consecutive frames: the new keyframe and its
+    pool, the poses joint_opt wrote back, the iteration counts and the tracking-back flag the tracker leaves for the mapper and for its own
+    next frame, the constant-speed prediction from the refined pose.  k = 12: a mapped frame (joint_opt, new keyframe) followed by two
+    tracked-only ones whose counts double and fall back; k = 16: two tracking-back frames in a row (both mapped out of turn with 16
+    iterations, both kept as keyframes).  The later frames start from a map that is 8 - 32 Adam steps away from the reference's, so their
+    bars are those of a short amplification: draws and decisions exact, poses 2e-3 m (measured: 4e-5, 2e-4, 1e-4 | 5e-5, 2.4e-4).  The
+    frames are chosen where every uncertainty evaluation is > 20 % from the threshold; measured further out (tools/try_g16_run.py): from
+    frame 12 the decisions of nine frames and poses within 1e-3 for six (then 2 - 3e-3); from frame 16 the run leaves the reference's
+    decisions at frame 20 (an evaluation 30 % above the threshold there): the amplification, at the trained map's slower rate."""
+    import unislam_amd as us
+    from g15_settings import G16
+    g = golden("g16_policy")
+    slam, draws = _resume(us, g, G16, k)
+    slam.run(n_frames=k + nf, start=k, total=G16["n_frames"])
+    frames = list(range(k, k + nf))
+    n_draws = int(np.sum(np.isin(g["draw_frame"], frames)))
+    assert draws.k == int(g[f"snap{k}__draw_pos"]) + n_draws, (draws.k, int(g[f"snap{k}__draw_pos"]), n_draws)
+    for f in frames:
+        assert slam.history["track_iters"][f] == int(g["track_iters"][f]) and int(slam.history["tracking_back"][f]) == int(g["tracking_back"][f]), f
+    mapped_ref = [int(x) for x in g["mapped_frames"] if int(x) in frames]
+    assert [m["idx"] for m in slam.history["mapped"]] == mapped_ref
+    j0 = int(g[f"snap{k}__n_mapped"])
+    assert [m["iters"] for m in slam.history["mapped"]] == [int(x) for x in g["map_iters"][j0:j0 + len(mapped_ref)]]
+    n_kf = int(g[f"snap{k}__n_keyframes"]) + sum(1 for f in mapped_ref if f in [int(x) for x in g["keyframe_list"]])
+    assert slam.mapper.keyframe_list == [int(x) for x in g["keyframe_list"][:n_kf]]
+    for f in frames:
+        est, ref = slam.estimate_c2w_list[f].cpu().numpy(), g["est_c2w"][f]
+        print(f"g16 from {k}: frame {f}: |t - t_ref| {np.abs(est[:3, 3] - ref[:3, 3]).max():.1e} m, |R - R_ref| {np.abs(est[:3, :3] - ref[:3, :3]).max():.1e}")
+        np.testing.assert_allclose(est[:3, 3], ref[:3, 3], atol=2e-3)
+        np.testing.assert_allclose(est[:3, :3], ref[:3, :3], atol=2e-3)
+
+
 def test_soak_on_the_closed_loop_bounds_every_frame():
     """
     264 frames (1.2 rounds of SyntheticRoom(path="loop"): the camera comes back to where it started) at the default policy -- a mapped frame
