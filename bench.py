@@ -198,12 +198,29 @@ def keyframe_pools(n_frames, bound, seed, device):
 def step_stats(fn, steps, warmup):
     """side-run timing, the headline's way: `warmup` untimed calls, `steps` calls between two synchronisations (wall time per step), then
     `steps` more with one HIP event pair per call on the launch stream -> (ms per step, last return value, {median, p10, p90} of the events)"""
+    import gc
     out = None
     for _ in range(warmup):
         out = fn()
+    # Python's cyclic collector is held off inside the timed loops: a full collection in a process that holds torch and a few models costs
+    # 50 - 94 ms (measured: tools/time_dropin.py, `slowest_host_call_ms` / `max_ms` of single runs) and lands in one of every ~150 eager
+    # autograd iterations -- inside a 100-step loop or not, which made the eager side runs jump by a factor two from run to run
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _step_stats_loops(fn, steps, out)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _step_stats_loops(fn, steps, out):
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    t_prev, host_max = t0, 0.0
     for _ in range(steps):
         out = fn()
+        t_now = time.perf_counter(); host_max = max(host_max, t_now - t_prev); t_prev = t_now
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -212,7 +229,8 @@ def step_stats(fn, steps, warmup):
     torch.cuda.synchronize()
     ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
     q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
-    return ms, out, {"n": steps, "median_ms": q(0.5), "p10_ms": q(0.1), "p90_ms": q(0.9)}
+    return ms, out, {"n": steps, "median_ms": q(0.5), "p10_ms": q(0.1), "p90_ms": q(0.9), "max_ms": ts[-1], "slowest_host_call_ms": 1e3 * host_max,
+                     "python_gc": "held off inside the timed loops"}
 
 
 def gather_rate_curve(path=None):
