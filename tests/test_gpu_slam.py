@@ -169,7 +169,9 @@ def test_g15_replayed_draw_for_draw(golden):
     floating-point arithmetic only (CPU fp32 autograd + torch.optim.Adam there; HIP kernels here, fp32 decoders).  Measured: the first
     iteration's loss agrees to 1e-7, then the difference doubles per Adam step of the first mapped frame (lr 0.25 against tables
     initialised at 1e-4: Adam's first steps are +-lr * sign(g), discontinuous where a gradient nearly cancels) and saturates at 1e-2 by
-    iteration 20: from there on the two runs are two samples of one process, 3 - 20 mm apart per frame (both 30 - 40 mm from the truth).
+    iteration 20: from there on the two runs are two samples of one process, 3 - 20 mm apart per frame (both 30 - 40 mm from the truth) -- and
+    so are two runs of the SAME HIP code on these draws (tools/replay_twice.py, profiles/r06_replay_twice.txt: bit-identical for 34
+    iterations, then 1.5 mm apart at frame 4 and 5 - 11 mm at frames 5 - 13): amplification, not a parity defect.
     Held: every draw, the loop's decisions, the first iterations' losses; per-frame positions within 4 cm of the reference's estimate and the
     ATE within 25 % (the deterministic per-frame comparison from the reference's own state is test_g16_policy_one_frame_at_a_time_...).
     """
