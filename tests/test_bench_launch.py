@@ -47,3 +47,29 @@ def test_plain_command_rehearsal_on_one_gpu(n, extra):
     assert rec["config"]["rays_per_gpu"] == 512 and "roofline" in rec and rec["roofline"]["frac"] > 0
     assert abs(rec["value"] - n * 512 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
     assert rec["final_loss"] == rec["final_loss"]                     # not NaN
+
+
+def test_request_roofline_of_the_encoder_from_the_committed_curve():
+    """bench.py's `roofline_by_kernel.hashgrid_fwd_joint.l2_request` (r6): the random-gather curve is read from profiles/r06_ta_bench.txt as
+    tools/ta_bench.hip printed it; lane loads are counted per point, level and grid as gather_corners issues them (4, + 4 on a hashed level
+    when the cell's x is odd); the ceiling is the sum of loads / rate(level slab).  Checked on the CPU with a hand-made descriptor."""
+    import types
+    import bench
+    curve = bench.gather_rate_curve()
+    assert len(curve) >= 10 and curve == sorted(curve)
+    sizes, rates = [c[0] for c in curve], [c[1] for c in curve]
+    assert rates[0] > 900 and 250 < bench._rate_at(curve, 4 * 2 ** 20) < 280 and rates[-1] < 60          # 16 KiB, 4 MiB (the L2), 128 MiB
+    assert all(a >= b for a, b in zip(rates, rates[1:]))              # bigger tables never gather faster
+    assert bench._rate_at(curve, 1) == rates[0] and bench._rate_at(curve, 1e12) == rates[-1]
+    mid = bench._rate_at(curve, (sizes[3] * sizes[4]) ** 0.5)
+    assert min(rates[3], rates[4]) <= mid <= max(rates[3], rates[4])
+    bench.torch = torch
+    try:
+        # two levels of one grid: a dense 4^3 level (64 entries) and a hashed level of 32 entries at resolution 8
+        d = types.SimpleNamespace(n_levels=2, offset=[0, 64, 96], resolution=[4, 8], scale=[3.0, 7.0])
+        x = torch.tensor([[0.10, 0.5, 0.5], [0.30, 0.5, 0.5], [0.90, 0.2, 0.1]])     # hashed level: cells x = floor(7 x + 0.5) = 1, 2, 6 -> one odd
+        r = bench.encoder_request_roofline((d,), x, kernel_ms=1e-3)
+    finally:
+        bench.torch = None
+    assert r["lane_loads_per_launch"] == 4 * 3 + (4 * 3 + 4 * 1)
+    assert abs(r["achieved"] - r["lane_loads_per_launch"] / 1e-6 / 1e9) < 1e-6 and r["frac"] == pytest.approx(r["ceiling_ms"] / 1e-3)
