@@ -92,6 +92,11 @@ int us_grid_desc_init(us_grid_desc* desc_host, uint32_t n_levels, uint32_t n_fea
 #define US_GRID_BWD_ONLY_A 256
 #define US_GRID_BWD_ONLY_B 512
 #define US_GRID_BWD_RECORDS_READY 1024
+/* US_GRID_FEAT_SPLIT_BF16 (us_hashgrid_fwd_joint / _dydx, with US_GRID_LEVEL_MAJOR): the feature planes hold, per point and level, the pair
+ * {bf16 hi(f0) | bf16 hi(f1) << 16, bf16 lo(f0) | bf16 lo(f1) << 16} (hi = bf16(f), lo = bf16(f - hi)) instead of two floats -- the same 8
+ * bytes, the operand images of the split-operand decoders (US_PREC_BF16), which then take them with US_MLP_IN_SPLIT_BF16 and skip the
+ * split of their inputs: results bit-identical to float planes.  Only the decoders read such planes. */
+#define US_GRID_FEAT_SPLIT_BF16 2048
 /* US_GRID_ACCUMULATE (us_hashgrid_bwd_input_gather only): dL_dx += instead of = (the second grid adds to the first) */
 #define US_GRID_ACCUMULATE 8
 
@@ -248,6 +253,9 @@ size_t us_mlp_n_params(const us_mlp_desc* d);
 /* US_MLP_DEFER_REDUCE (us_mlp_bwd with a workspace): leave the per-workgroup partial weight gradients in the workspace; the caller adds
  * them with us_mlp_reduce later -- e.g. on another stream, beside the table gradient, instead of ahead of it */
 #define US_MLP_DEFER_REDUCE 2
+/* US_MLP_IN_SPLIT_BF16 (US_PREC_BF16 decoders, with US_MLP_LEVEL_MAJOR): `in` holds the planes us_hashgrid_fwd_joint wrote with
+ * US_GRID_FEAT_SPLIT_BF16 (the inputs already as hi / lo bf16 pairs).  Outputs and gradients as with float planes, bit for bit. */
+#define US_MLP_IN_SPLIT_BF16 4
 int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t workspace_bytes, int64_t n, float* grad_params, void* stream);
 
 /* out[i*out_stride + o] = act(MLP(in[i][:]))[o], o < n_out   (out_stride lets two decoders write one raw[N][4]) */

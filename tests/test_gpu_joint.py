@@ -182,3 +182,63 @@ def test_deterministic_table_gradient_repeats_bit_for_bit(us, joint):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for k in range(2):
         assert torch.allclose(outs[0][k], outs[2][k], rtol=1e-4, atol=2e-6 * float(outs[2][k].abs().max()))
+
+
+@pytest.mark.parametrize("n", [70001, 4096 * 64, 31])
+def test_pre_split_feature_planes_give_the_same_bits(n):
+    """US_GRID_FEAT_SPLIT_BF16 + US_MLP_IN_SPLIT_BF16 (r6): the joint encoder writes the features as the split-bf16 decoders' hi / lo operand
+    pairs, the decoders load them instead of splitting float planes -- outputs, input gradients and parameter gradients of the decoder pair
+    BIT FOR BIT those of float planes (forward, backward with and without parameter gradients), and the planes themselves are the split of
+    the float planes value for value."""
+    import ctypes
+    import unislam_amd as us
+    from unislam_amd import _lib as L
+    torch.manual_seed(11)
+    lib, P, st = L.lib(), L.ptr, L.stream()
+    ea, eb = us.HashGridEncoding(3, _cfg(16)).to(DEV), us.HashGridEncoding(3, _cfg(19)).to(DEV)
+    with torch.no_grad():
+        ea.params.copy_(torch.randn_like(ea.params) * 0.1); eb.params.copy_(torch.randn_like(eb.params) * 0.1)
+    x = torch.rand(n, 3, device=DEV)
+    da, db = ctypes.byref(ea.desc), ctypes.byref(eb.desc)
+    ds = us.make_mlp_desc(32, 32, 2, 1, "tanh", True, "bf16"); dc = us.make_mlp_desc(32, 32, 2, 3, "sigmoid", True, "bf16")
+    ps = torch.randn(us.network.mlp_n_params(ds), device=DEV) * 0.3; pc = torch.randn(us.network.mlp_n_params(dc), device=DEV) * 0.3
+    A, B = ctypes.byref(ds), ctypes.byref(dc)
+    d_raw = torch.randn(n, 4, device=DEV)
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+    wsb = int(lib.us_mlp_bwd_workspace_bytes(A))
+    outs = []
+    for split in (0, 1):
+        fa, fb = torch.empty(16, n, 2, device=DEV), torch.empty(16, n, 2, device=DEV)
+        L.check(lib.us_hashgrid_fwd_joint(da, db, P(ea.params.detach()), P(eb.params.detach()), P(x), n, P(fa), P(fb),
+                                          3 | (L.US_GRID_FEAT_SPLIT_BF16 if split else 0), None, 0, st), "fwd")
+        mf = 1 | (L.US_MLP_IN_SPLIT_BF16 if split else 0)
+        raw = torch.empty(n, 4, device=DEV)
+        L.check(lib.us_mlp_fwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), n, off(raw, 3), 4, P(raw), 4, mf, st), "mlp fwd")
+        dfa, dfb = torch.empty(16, n, 2, device=DEV), torch.empty(16, n, 2, device=DEV)
+        gs, gc = torch.zeros_like(ps), torch.zeros_like(pc)
+        wa, wb = torch.empty(wsb, dtype=torch.uint8, device=DEV), torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        L.check(lib.us_mlp_bwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, n, P(dfa), P(dfb),
+                                    P(gs), P(gc), mf, P(wa), P(wb), wsb, st), "mlp bwd")
+        dfa2, dfb2 = torch.empty(16, n, 2, device=DEV), torch.empty(16, n, 2, device=DEV)
+        L.check(lib.us_mlp_bwd_pair(A, B, P(ps), P(pc), P(fa), P(fb), off(raw, 3), 4, P(raw), 4, off(d_raw, 3), 4, P(d_raw), 4, n, P(dfa2), P(dfb2),
+                                    None, None, mf, None, None, 0, st), "mlp bwd (inputs only)")
+        outs.append((fa, fb, raw, dfa, dfb, gs, gc, dfa2, dfb2))
+    f0, f1 = outs
+    for k, name in ((2, "raw"), (3, "dL/dfeatures (sdf)"), (4, "dL/dfeatures (colour)"), (5, "sdf decoder gradient"), (6, "colour decoder gradient"),
+                    (7, "dL/dfeatures, lean kernel (sdf)"), (8, "dL/dfeatures, lean kernel (colour)")):
+        assert torch.equal(f0[k], f1[k]), name
+    # the planes: hi = bf16(f), lo = bf16(f - hi), two features per dword pair
+    for k in (0, 1):
+        f = f0[k].reshape(-1, 2)
+        hi = f.bfloat16()
+        lo = (f - hi.float()).bfloat16()
+        w = f1[k].reshape(-1, 2).view(torch.int32)
+        bits = lambda t: t.view(torch.int16).to(torch.int32) & 0xFFFF
+        assert torch.equal(w[:, 0], bits(hi[:, 0]) | (bits(hi[:, 1]) << 16)) and torch.equal(w[:, 1], bits(lo[:, 0]) | (bits(lo[:, 1]) << 16))
+    # the flag is refused where it does not apply
+    dp = us.make_mlp_desc(32, 32, 2, 1, "tanh", True, "bf16_plain")
+    raw = torch.empty(n, 4, device=DEV)
+    assert lib.us_mlp_fwd(ctypes.byref(dp), P(ps), P(f1[0]), n, off(raw, 3), 4, 1 | L.US_MLP_IN_SPLIT_BF16, st) == L.US_ERR_CONFIG
+    assert lib.us_mlp_fwd(A, P(ps), P(f1[0]), n, off(raw, 3), 4, L.US_MLP_IN_SPLIT_BF16, st) == L.US_ERR_CONFIG            # row-major planes
+    assert lib.us_hashgrid_fwd_joint(da, db, P(ea.params.detach()), P(eb.params.detach()), P(x), n, P(f1[0]), P(f1[1]), 1 | L.US_GRID_FEAT_SPLIT_BF16,
+                                     None, 0, st) == L.US_ERR_CONFIG

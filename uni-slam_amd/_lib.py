@@ -14,6 +14,7 @@ US_MAX_LEVELS = 32
 US_ERR_CONFIG = -3          # unislam_hip.h: unsupported descriptor / configuration
 US_GRID_CLAMP01 = 1
 US_GRID_LEVEL_MAJOR = 2
+US_GRID_FEAT_SPLIT_BF16 = 2048  # us_hashgrid_fwd_joint(_dydx): feature planes as hi / lo bf16 pairs (the split-bf16 decoders' operands)
 US_GRID_BWD_OVERWRITE = 4
 US_GRID_ACCUMULATE = 8
 US_GRID_BWD_COUNTED = 16
@@ -25,6 +26,8 @@ US_GRID_BWD_ONLY_B = 512
 US_GRID_BWD_RECORDS_READY = 1024
 US_MLP_LEVEL_MAJOR = 1
 US_MLP_DEFER_REDUCE = 2
+FEAT_SPLIT_DEFAULT = os.environ.get("US_FEAT_SPLIT", "1") != "0"   # the pre-split feature hand-over of the split-bf16 decoders (A/B switch)
+US_MLP_IN_SPLIT_BF16 = 4        # `in` holds the hi / lo bf16 pairs the joint encoder wrote with US_GRID_FEAT_SPLIT_BF16
 US_LOSS_DEFER_BETA = 256
 US_ADAM_STEP_ADVANCED = 0x80000000
 US_POSE_GRAD_ONLY = 1

@@ -300,8 +300,21 @@ __global__ __launch_bounds__(J_FWD_THREADS, DYDX ? 4 : J_FWD_WAVES_PER_EU) void 
                 const float w = corner_weight(c, pos);
                 r0 = fmaf(w, v[c].x, r0); r1 = fmaf(w, v[c].y, r1);
             }
-            float* o = (s ? outB : outA) + feat_index(lm, i, n, level, C, 2);
-            o[0] = r0; o[1] = r1;
+            float* o = (s ? outB : outA) + feat_index(lm & 1, i, n, level, C, 2);
+            if (lm & 2) {
+                // US_GRID_FEAT_SPLIT_BF16: the pair as the split-bf16 decoders' operands -- {hi(f0) | hi(f1) << 16, lo(f0) | lo(f1) << 16} with
+                // hi = bf16(f), lo = bf16(f - hi), value for value what mlp_bf16.inc's bf_pack_split forms from the float pair: the same 8
+                // bytes, and the decoders (forward and backward) load their B operands instead of spending ~45 VALU instructions per 32
+                // points on the split.  This kernel waits on its gathers (14 % of its wave cycles issue anything): the conversions are free here.
+                const __bf16 h0 = (__bf16)r0, h1 = (__bf16)r1;
+                const __bf16 l0 = (__bf16)(r0 - (float)h0), l1 = (__bf16)(r1 - (float)h1);
+                uint2 wv;
+                wv.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                wv.y = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+                *reinterpret_cast<uint2*>(o) = wv;
+            } else {
+                o[0] = r0; o[1] = r1;
+            }
             if (DYDX) {                                          // k_fwd<F, DYDX>'s arithmetic, value for value
                 // planes [L][3][N][2] of IEEE half values: a store instruction covers whole lines.  (dy/dx = scale * feature differences: |.| < 65504
                 // for any table this path trains, relative error 2^-11 -- against 5e-4 relative per element the pose gradient sums ~10^6 of them)
@@ -1171,7 +1184,8 @@ static int fwd_joint(const char* fn, const us_grid_desc* a, const us_grid_desc* 
     US_REQUIRE(((uintptr_t)paramsA & 15u) == 0 && ((uintptr_t)paramsB & 15u) == 0, US_ERR_SHAPE, "%s: params must be 16-byte aligned", fn);
     US_REQUIRE((dydxA != nullptr) == (dydxB != nullptr), US_ERR_NULL, "%s: dy_dx of both grids or of neither", fn);
     US_REQUIRE(!dydxA || ((((uintptr_t)dydxA | (uintptr_t)dydxB) & 3u) == 0), US_ERR_SHAPE, "%s: dy_dx must be 4-byte aligned", fn);
-    const int clamp = flags & US_GRID_CLAMP01, lm = (flags & US_GRID_LEVEL_MAJOR) ? 1 : 0;
+    US_REQUIRE(!(flags & US_GRID_FEAT_SPLIT_BF16) || (flags & US_GRID_LEVEL_MAJOR), US_ERR_CONFIG, "%s: US_GRID_FEAT_SPLIT_BF16 needs level-major planes", fn);
+    const int clamp = flags & US_GRID_CLAMP01, lm = ((flags & US_GRID_LEVEL_MAJOR) ? 1 : 0) | ((flags & US_GRID_FEAT_SPLIT_BF16) ? 2 : 0);
     dim3 grid((unsigned)us_cdiv(n, J_FWD_THREADS), a->n_levels), block(J_FWD_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (workspace) {

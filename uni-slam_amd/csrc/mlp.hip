@@ -186,7 +186,7 @@ __device__ __forceinline__ void load_inputs(const float* __restrict__ in, int64_
         for (int b = 0; b < NIN / 16; ++b) {
             v4f v = {0.f, 0.f, 0.f, 0.f};
             if (CLAMP || p < n) {
-                if (lm) {
+                if (lm & 1) {
                     const float2 lo = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g) * n + p) * 2);
                     const float2 hi = *reinterpret_cast<const float2*>(in + ((int64_t)(8 * b + 2 * g + 1) * n + p) * 2);
                     v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(MLP_BWD_WAVES(WIDTH) * 64) void k_mlp_bwd(const flo
                 if (p < n) {
 #pragma unroll
                     for (int b = 0; b < C::KB_IN; ++b) {
-                        if (lm) {
+                        if (lm & 1) {
                             *reinterpret_cast<float2*>(dL_din + ((int64_t)(8 * b + 2 * g) * n + p) * 2) = make_float2(dx[q][b][0], dx[q][b][1]);
                             *reinterpret_cast<float2*>(dL_din + ((int64_t)(8 * b + 2 * g + 1) * n + p) * 2) = make_float2(dx[q][b][2], dx[q][b][3]);
                         } else {
@@ -591,11 +591,20 @@ extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
         }                                                                                                          \
     } while (0)
 
+// the kernels' `lm` word: bit 0 level-major planes, bit 1 inputs already split into hi / lo bf16 pairs (US_MLP_IN_SPLIT_BF16)
+static int mlp_lm_word(const char* fn, int flags, const us_mlp_desc* d, int* lm_out) {
+    const int split = (flags & US_MLP_IN_SPLIT_BF16) ? 1 : 0;
+    US_REQUIRE(!split || ((flags & US_MLP_LEVEL_MAJOR) && d && d->precision == US_PREC_BF16 && d->n_in == 32), US_ERR_CONFIG,
+               "%s: US_MLP_IN_SPLIT_BF16 needs US_MLP_LEVEL_MAJOR and US_PREC_BF16 decoders of 32 inputs", fn);
+    *lm_out = ((flags & US_MLP_LEVEL_MAJOR) ? 1 : 0) | (split ? 2 : 0);
+    return US_OK;
+}
+
 // us_mlp_fwd with the point count optionally read on the device (n_dev[0] * n_mul <= n; NULL: n): shared with render.hip
 int us_mlp_fwd_counted_rows(const us_mlp_desc* d, const float* params, const float* in, int64_t n, float* out,
                             int64_t out_stride, int flags, const int32_t* n_dev, int n_mul, void* stream) {
-    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_fwd", d); if (rc) return rc;
+    int lm; rc = mlp_lm_word("us_mlp_fwd", flags, d, &lm); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_fwd: out_stride %lld < n_out", (long long)out_stride);
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(params && in && out, US_ERR_NULL, "us_mlp_fwd: NULL pointer");
@@ -641,8 +650,8 @@ extern "C" size_t us_mlp_bwd_workspace_bytes(const us_mlp_desc* d) {
 extern "C" int us_mlp_bwd(const us_mlp_desc* d, const float* params, const float* in, const float* out,
                           int64_t out_stride, const float* dL_dout, int64_t dout_stride, int64_t n, float* dL_din,
                           float* grad_params, int flags, void* workspace, size_t workspace_bytes, void* stream) {
-    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
     int rc = check_mlp("us_mlp_bwd", d); if (rc) return rc;
+    int lm; rc = mlp_lm_word("us_mlp_bwd", flags, d, &lm); if (rc) return rc;
     US_REQUIRE(out_stride >= (int64_t)d->n_out && dout_stride >= (int64_t)d->n_out, US_ERR_SHAPE, "us_mlp_bwd: stride < n_out");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(params && in && out && dL_dout, US_ERR_NULL, "us_mlp_bwd: NULL pointer");
@@ -738,7 +747,7 @@ extern "C" int us_mlp_fwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, con
     US_REQUIRE(out_stride_a >= (int64_t)da->n_out && out_stride_b >= (int64_t)db->n_out, US_ERR_SHAPE, "us_mlp_fwd_pair: out_stride < n_out");
     if (n <= 0) return n == 0 ? US_OK : US_ERR_SHAPE;
     US_REQUIRE(params_a && params_b && in_a && in_b && out_a && out_b, US_ERR_NULL, "us_mlp_fwd_pair: NULL pointer");
-    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
+    int lm; { const int rc = mlp_lm_word("us_mlp_fwd_pair", flags, da, &lm); if (rc) return rc; }
     hipStream_t s = (hipStream_t)stream;
     int64_t nb = us_cdiv(n, 16 * MLP_BF_FWD_NQ * MLP_WAVES); if (nb > MLP_BF_FWD_CAP) nb = MLP_BF_FWD_CAP;           // as us_mlp_fwd (bf16)
     dim3 grid((unsigned)nb, 2), block(MLP_THREADS);
@@ -771,7 +780,7 @@ static int mlp_bwd_pair(const us_mlp_desc* da, const us_mlp_desc* db, const floa
         workspace_a = workspace_b = nullptr;
     }
     US_REQUIRE((dL_din_a != nullptr) == (dL_din_b != nullptr), US_ERR_NULL, "us_mlp_bwd_pair: input gradients of both decoders or of neither");
-    const int lm = (flags & US_MLP_LEVEL_MAJOR) ? 1 : 0;
+    int lm; { const int rc = mlp_lm_word("us_mlp_bwd_pair", flags, da, &lm); if (rc) return rc; }
     if (dy_dx_a || dy_dx_b || dpts_a || dpts_b) {
         US_REQUIRE(dy_dx_a && dy_dx_b && dpts_a && dpts_b && dpts_a != dpts_b, US_ERR_NULL, "us_mlp_bwd_pair_dydx: dy_dx and dL_dpts of both decoders");
         US_REQUIRE(lm && da->n_in == 32, US_ERR_CONFIG, "us_mlp_bwd_pair_dydx: level-major inputs of 16 levels x 2 features");

@@ -62,15 +62,20 @@ class _DecodersFusedFn(torch.autograd.Function):
         raw = torch.empty((n, 4), dtype=torch.float32, device=dev)
         ws, nbytes = (dec._fused_workspace(es, ec, n) if want_tab else (None, 0))
         flags = L.US_GRID_CLAMP01 | L.US_GRID_LEVEL_MAJOR
-        L.check(lib.us_hashgrid_fwd_joint(ds, dc, P(ts), P(tc), P(x), n, P(feat_s), P(feat_c), flags, P(ws), nbytes, st),
-                "us_hashgrid_fwd_joint")
+        # (r6) split-bf16 decoders: the encoder writes the features as their hi / lo operand pairs (same bytes, same values), which only the
+        # decoders' launches of this node read
+        d_s, d_c = dec.mlp_descs()
+        split = bool(getattr(dec, "feat_split", L.FEAT_SPLIT_DEFAULT) and d_s.precision == 1 and d_c.precision == 1 and d_s.n_in == 32 and d_c.n_in == 32)
+        ctx.mflags = mfl = L.US_MLP_LEVEL_MAJOR | (L.US_MLP_IN_SPLIT_BF16 if split else 0)
+        L.check(lib.us_hashgrid_fwd_joint(ds, dc, P(ts), P(tc), P(x), n, P(feat_s), P(feat_c), flags | (L.US_GRID_FEAT_SPLIT_BF16 if split else 0),
+                                          P(ws), nbytes, st), "us_hashgrid_fwd_joint")
         ctx.pair = dec._pair_ok()
         if ctx.pair:
-            L.check(lib.us_mlp_fwd_pair(ms, mc, ps, pc, P(feat_s), P(feat_c), n, _off(raw, 3), 4, P(raw), 4, L.US_MLP_LEVEL_MAJOR, st),
+            L.check(lib.us_mlp_fwd_pair(ms, mc, ps, pc, P(feat_s), P(feat_c), n, _off(raw, 3), 4, P(raw), 4, mfl, st),
                     "us_mlp_fwd_pair")
         else:
-            L.check(lib.us_mlp_fwd(ms, ps, P(feat_s), n, _off(raw, 3), 4, L.US_MLP_LEVEL_MAJOR, st), "us_mlp_fwd")
-            L.check(lib.us_mlp_fwd(mc, pc, P(feat_c), n, P(raw), 4, L.US_MLP_LEVEL_MAJOR, st), "us_mlp_fwd")
+            L.check(lib.us_mlp_fwd(ms, ps, P(feat_s), n, _off(raw, 3), 4, mfl, st), "us_mlp_fwd")
+            L.check(lib.us_mlp_fwd(mc, pc, P(feat_c), n, P(raw), 4, mfl, st), "us_mlp_fwd")
         ctx.dec, ctx.es, ctx.ec, ctx.counted = dec, es, ec, None
         # the backward pass reads the decoders' weights from the packed vector as it is THEN (they are not copied per call): note their
         # versions, so that an in-place update between forward and backward raises as it would for a tensor autograd saved
@@ -111,12 +116,12 @@ class _DecodersFusedFn(torch.autograd.Function):
         gs_p, gc_p = (P(gflat), _off(gflat, n_s)) if want_dec else (None, None)
         if ctx.pair:
             L.check(lib.us_mlp_bwd_pair(ms, mc, ps, pc, P(feat_s), P(feat_c), _off(raw, 3), 4, P(raw), 4, _off(d_raw, 3), 4, P(d_raw), 4, n,
-                                        P(d_feat_s), P(d_feat_c), gs_p, gc_p, L.US_MLP_LEVEL_MAJOR, P(mws_s), P(mws_c), mws_bytes, st),
+                                        P(d_feat_s), P(d_feat_c), gs_p, gc_p, ctx.mflags, P(mws_s), P(mws_c), mws_bytes, st),
                     "us_mlp_bwd_pair")
         else:
-            L.check(lib.us_mlp_bwd(ms, ps, P(feat_s), _off(raw, 3), 4, _off(d_raw, 3), 4, n, P(d_feat_s), gs_p, L.US_MLP_LEVEL_MAJOR,
+            L.check(lib.us_mlp_bwd(ms, ps, P(feat_s), _off(raw, 3), 4, _off(d_raw, 3), 4, n, P(d_feat_s), gs_p, ctx.mflags,
                                    P(mws_s), mws_bytes, st), "us_mlp_bwd")
-            L.check(lib.us_mlp_bwd(mc, pc, P(feat_c), P(raw), 4, P(d_raw), 4, n, P(d_feat_c), gc_p, L.US_MLP_LEVEL_MAJOR,
+            L.check(lib.us_mlp_bwd(mc, pc, P(feat_c), P(raw), 4, P(d_raw), 4, n, P(d_feat_c), gc_p, ctx.mflags,
                                    P(mws_c), mws_bytes, st), "us_mlp_bwd")
         g_s = g_c = None
         flags = L.US_GRID_CLAMP01 | L.US_GRID_LEVEL_MAJOR

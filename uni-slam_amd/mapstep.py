@@ -292,6 +292,15 @@ class MapStep:
         self.mlp_ws = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)
         self.mlp_ws_s = torch.empty(self.mlp_ws_bytes, dtype=torch.uint8, device=dev)      # (one per decoder: they may run in one launch)
 
+    def _split_flags(self, joint_branch):
+        """(encoder flag, decoder flag) of the pre-split feature hand-over (r6): in the joint branches, with two split-bf16 decoders of 32
+        inputs, the encoder writes the features as the decoders' hi / lo bf16 operand pairs (same bytes, same values: the decoders skip
+        the split of their inputs, forward and backward).  Nothing else reads the feature planes.  feat_split = False turns it off."""
+        on = bool(joint_branch and getattr(self, "feat_split", L.FEAT_SPLIT_DEFAULT) and self.desc_s.precision == 1 and self.desc_c.precision == 1
+                  and self.desc_s.n_in == 32 and self.desc_c.n_in == 32)
+        self._gs, self._ms = (L.US_GRID_FEAT_SPLIT_BF16, L.US_MLP_IN_SPLIT_BF16) if on else (0, 0)
+        return self._gs, self._ms
+
     def _decoder_pair(self):
         """joint path: run the two decoders as ONE launch each way (us_mlp_fwd_pair / us_mlp_bwd_pair)?  Yes when they have one shape and a
         bf16 precision."""
@@ -431,6 +440,7 @@ class MapStep:
             self._wait_scans()                                   # a scan of the previous call may still read the workspace
             self._jcounted = True
             self._dydx_valid = False
+            gs_, ms_ = self._split_flags(True)
             if self.store_dydx:
                 L_ = self.es.desc.n_levels
                 if self.dydx_s is None or self.dydx_s.numel() < L_ * self.max_rays * S * 6:
@@ -438,11 +448,11 @@ class MapStep:
                     self.dydx_c = torch.empty_like(self.dydx_s)
                 self._dydx_valid = True
                 self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint_dydx(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                         P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3,
+                                                                                         P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3 | gs_,
                                                                                          P(self.ws), self.ws_bytes, st))
             else:
                 self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                    P(self.feat_s), P(self.feat_c), 3, P(self.ws), self.ws_bytes, st))
+                                                                                    P(self.feat_s), P(self.feat_c), 3 | gs_, P(self.ws), self.ws_bytes, st))
             # the binning's scan passes depend on the counts only: they run beside the decoders (own stream; the backward pass waits for
             # it), off the critical path.  A probed step keeps them on the one stream, timed by themselves.
             scan_call = lambda q: lib.us_hashgrid_joint_scan(ds, dc, N, off(self.grad, self.o_tab_s), off(self.grad, self.o_tab_c),
@@ -476,21 +486,23 @@ class MapStep:
                 fork_scans()
             if self._decoder_pair():                             # both decoders in one launch
                 self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st))
                 if main_first:
                     fork_scans()
                 return self._finish_forward(o, d, gd, gc, R)
             # decoders of different shapes: one after the other on the main stream
-            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st))
-            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
+            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1 | ms_, st))
+            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1 | ms_, st))
             return self._finish_forward(o, d, gd, gc, R)
         if not backward_follows and self.joint and self._decoder_pair():
             # a render-only call on ONE stream: both encoders in one launch (no binning counts), both decoders in one launch
+            gs_, ms_ = self._split_flags(True)
             self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
-                                                                                P(self.feat_s), P(self.feat_c), 3, None, 0, st))
+                                                                                P(self.feat_s), P(self.feat_c), 3 | gs_, None, 0, st))
             self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st))
             return self._finish_forward(o, d, gd, gc, R)
+        self._split_flags(False)                                 # (the one-grid encoders write float planes)
         with self._branch() as st2:
             if counted:
                 self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd_counted(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), 3,
@@ -588,7 +600,7 @@ class MapStep:
             self._backward_in_ranges(R, on_ready)
         elif self.joint:
             # the two decoder backward passes side by side, then ONE binned pass for both tables
-            mflags = 1 | (L.US_MLP_DEFER_REDUCE if defer else 0)
+            mflags = 1 | getattr(self, "_ms", 0) | (L.US_MLP_DEFER_REDUCE if defer else 0)   # (_ms: the forward pass left pre-split feature planes)
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
@@ -744,10 +756,11 @@ class MapStep:
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
+        mf = 1 | getattr(self, "_ms", 0)
         L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c),
-                               off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, st), "us_mlp_bwd")
+                               off(self.grad, self.o_dec_c), mf, P(self.mlp_ws), self.mlp_ws_bytes, st), "us_mlp_bwd")
         L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s),
-                               off(self.grad, self.o_dec_s), 1, P(self.mlp_ws_s), self.mlp_ws_bytes, st), "us_mlp_bwd")
+                               off(self.grad, self.o_dec_s), mf, P(self.mlp_ws_s), self.mlp_ws_bytes, st), "us_mlp_bwd")
         for k, r0 in enumerate(range(0, R, self.chunk_rays)):
             n_k, i0 = (min(R, r0 + self.chunk_rays) - r0) * S, r0 * S
             flags = 3 | self._det | (L.US_GRID_BWD_OVERWRITE if k == 0 else 0)

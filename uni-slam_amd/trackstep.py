@@ -59,6 +59,13 @@ class TrackStep:
         self.stats, self.loss, self.median, self.err = f(10), f(1), f(1), f(R)
         self.valid = torch.empty(R, dtype=torch.uint8, device=dev)
 
+    def _split_flags(self, joint):
+        """(encoder flag, decoder flag): with two split-bf16 decoders the joint encoder writes the features as the decoders' hi / lo bf16
+        operand pairs (same bytes and values; the decoders skip the split of their inputs).  feat_split = False turns it off."""
+        on = bool(joint and getattr(self, "feat_split", L.FEAT_SPLIT_DEFAULT) and self.desc_s.precision == 1 and self.desc_c.precision == 1
+                  and self.desc_s.n_in == 32 and self.desc_c.n_in == 32)
+        return (L.US_GRID_FEAT_SPLIT_BF16, L.US_MLP_IN_SPLIT_BF16) if on else (0, 0)
+
     def _decoder_params(self):
         dec = self.dec
         if dec.tcnn_network:
@@ -110,23 +117,24 @@ class TrackStep:
         # one launch where the pair of grids qualifies (positions and cells computed once, one launch less in a latency-bound chain)
         if self._joint is None:
             self._joint = bool(lib.us_hashgrid_joint_supported(ds, dc, 1))    # the count-free encoder needs the shared geometry only
+        gs_, ms_ = self._split_flags(self._joint)
         if self._joint:
             # ... and d(features)/d(position) of both, which the pose gradient contracts at the end (no second gather pass over the tables)
             if self.dydx_s is None:
                 self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float16, device=self.device)
                 self.dydx_c = torch.empty_like(self.dydx_s)
             L.check(lib.us_hashgrid_fwd_joint_dydx(ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c),
-                                                   3, None, 0, st), "us_hashgrid_fwd_joint_dydx")
+                                                   3 | gs_, None, 0, st), "us_hashgrid_fwd_joint_dydx")
         else:
             L.check(lib.us_hashgrid_fwd(ds, P(ts), P(self.pts), N, P(self.feat_s), None, 3, st), "us_hashgrid_fwd")
             L.check(lib.us_hashgrid_fwd(dc, P(tc), P(self.pts), N, P(self.feat_c), None, 3, st), "us_hashgrid_fwd")
         pair = bool(lib.us_mlp_pair_supported(ms, mc))             # both decoders in one launch each way
         if pair:
-            L.check(lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st),
+            L.check(lib.us_mlp_fwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st),
                     "us_mlp_fwd_pair")
         else:
-            L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1, st), "us_mlp_fwd")
-            L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1, st), "us_mlp_fwd")
+            L.check(lib.us_mlp_fwd(ms, P(self._ps), P(self.feat_s), N, off(self.raw, 3), 4, 1 | ms_, st), "us_mlp_fwd")
+            L.check(lib.us_mlp_fwd(mc, P(self._pc), P(self.feat_c), N, P(self.raw), 4, 1 | ms_, st), "us_mlp_fwd")
         L.check(lib.us_composite_fwd(P(self.raw), P(self.z), P(self._beta), R, S, P(self.term), P(self.unc), P(self.depth),
                                      P(self.rgb), P(self.dunc), None, st), "us_composite_fwd")
         med = None
@@ -150,12 +158,12 @@ class TrackStep:
                                      P(self.g_sdf), P(self.d_raw), None, None, st), "us_composite_bwd")
         if pair:
             L.check(lib.us_mlp_bwd_pair(ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4,
-                                        off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1, None, None, 0, st),
+                                        off(self.d_raw, 3), 4, P(self.d_raw), 4, N, P(self.d_feat_s), P(self.d_feat_c), None, None, 1 | ms_, None, None, 0, st),
                     "us_mlp_bwd_pair")
         else:
-            L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1,
+            L.check(lib.us_mlp_bwd(ms, P(self._ps), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s), None, 1 | ms_,
                                    None, 0, st), "us_mlp_bwd")
-            L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1,
+            L.check(lib.us_mlp_bwd(mc, P(self._pc), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c), None, 1 | ms_,
                                    None, 0, st), "us_mlp_bwd")
         if self._joint and S <= 128:
             L.check(lib.us_hashgrid_dydx_rays(self.es.desc.n_levels, P(self.d_feat_s), P(self.d_feat_c), P(self.dydx_s), P(self.dydx_c), R, S, P(self.z),
@@ -286,10 +294,11 @@ class TrackStep:
         if self.dydx_s is None:
             self.dydx_s = torch.empty(self.es.desc.n_levels * self.max_rays * S * 6, dtype=torch.float16, device=self.device)
             self.dydx_c = torch.empty_like(self.dydx_s)
+        gs_, ms_ = self._split_flags(True)
         T("us_hashgrid_fwd_joint_dydx", lambda: lib.us_hashgrid_fwd_joint_dydx(
-            ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3, None, 0, st))
+            ds, dc, P(ts), P(tc), P(self.pts), N, P(self.feat_s), P(self.feat_c), P(self.dydx_s), P(self.dydx_c), 3 | gs_, None, 0, st))
         T("us_mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(
-            ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1, st))
+            ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), N, off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st))
         T("us_track_loss_fwd", lambda: lib.us_track_loss_fwd(
             P(self.raw), P(self.z), P(self._beta), n, S, P(self.valid), P(self.t_gd), P(self.t_gc), self.truncation, P(self.term), P(self.unc),
             P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.err), P(self.median), P(self.stats), st))
@@ -303,7 +312,7 @@ class TrackStep:
             self.dpts_c = torch.empty_like(self.dpts_s)
         T("us_mlp_bwd_pair_dydx", lambda: lib.us_mlp_bwd_pair_dydx(
             ms, mc, P(self._ps), P(self._pc), P(self.feat_s), P(self.feat_c), off(self.raw, 3), 4, P(self.raw), 4, off(self.d_raw, 3), 4,
-            P(self.d_raw), 4, N, None, None, None, None, 1, None, None, 0, P(self.dydx_s), P(self.dydx_c), P(self.dpts_s), P(self.dpts_c), st))
+            P(self.d_raw), 4, N, None, None, None, None, 1 | ms_, None, None, 0, P(self.dydx_s), P(self.dydx_c), P(self.dpts_s), P(self.dpts_c), st))
         T("us_ray_points_bwd2", lambda: lib.us_ray_points_bwd2(P(self.dpts_s), P(self.dpts_c), P(self.z), self.bhost, n, S, P(self.g_o), P(self.g_d), st))
         T("us_pose_track_step", lambda: lib.us_pose_track_step(
             P(self.pose), P(self.g_o), P(self.g_d), P(self.t_dirs), n, P(self.pm), P(self.pv), P(self.g_pose), self.lr_R, self.lr_T,
