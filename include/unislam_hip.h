@@ -29,7 +29,8 @@ extern "C" {
 #endif
 
 #define US_MAX_LEVELS 32
-#define US_ABI_VERSION 1
+#define US_ABI_VERSION 2          /* 2 (r6): us_hashgrid_bwd_joint_adam / _part left the shipped ABI (unislam_hip_experiments.h); new flags
+                                   * US_GRID_FEAT_SPLIT_BF16, US_MLP_IN_SPLIT_BF16 */
 
 enum {
     US_OK = 0,

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(built):
         assert hasattr(lib, n), f"{n} declared in include/unislam_hip.h but not exported"
     from unislam_amd import _lib
     assert sorted(_lib.SIGNATURES.keys()) == names            # the ctypes table covers exactly the header
-    assert _lib.lib().us_abi_version() == 1
+    assert _lib.lib().us_abi_version() == 2
     # the measured-slower variants live in their own header and are NOT part of the shipped library
     exp = header_functions("unislam_hip_experiments.h")
     assert sorted(_lib.EXPERIMENT_SIGNATURES.keys()) == exp and not set(exp) & set(names)
