@@ -55,11 +55,13 @@ def test_synthetic_room_refuses_paths_through_walls():
 
 
 def test_graph_registry_keeps_and_releases(monkeypatch):
-    """the registry of captured graphs on a PRIVATE list (the process-global one holds the graphs of earlier GPU tests): FIFO release --
-    an entry is dropped only when its owner is gone AND nothing older is left in front of it (destroying a graph breaks the OLDER ones)"""
+    """the registry of captured graphs on a PRIVATE list (the process-global one holds the graphs of earlier GPU tests): nothing is
+    destroyed while ANY owner is alive (destroying one multi-branch hipGraph leaves the living ones with dangling streams); when the last
+    owner is gone the registry empties at the next capture"""
     import gc
     from unislam_amd import graph
     monkeypatch.setattr(graph, "_KEEP", [])
+    monkeypatch.delenv("US_GRAPH_RELEASE", raising=False)
 
     class Owner:
         pass
@@ -68,15 +70,27 @@ def test_graph_registry_keeps_and_releases(monkeypatch):
     graph._keep(ga, a); graph._keep(gb, b); graph._keep(gc_, c)
     assert [e[0] for e in graph._KEEP] == [ga, gb, gc_] and graph.collect() == 0
     del b; gc.collect()
-    assert graph.collect() == 0 and len(graph._KEEP) == 3          # b's graph is not the oldest: destroying it would break a's
+    assert graph.collect() == 0 and len(graph._KEEP) == 3
     del a; gc.collect()
-    assert graph.collect() == 2 and [e[0] for e in graph._KEEP] == [gc_]   # now a's goes, then b's, oldest first; c's owner lives
-    sentinel = object()
-    graph._keep(sentinel)                                          # no owner: kept until release_all()
+    assert graph.collect() == 0 and len(graph._KEEP) == 3          # c's owner lives: a's and b's graphs wait for it
+    monkeypatch.setenv("US_GRAPH_RELEASE", "fifo")                 # the refuted rule, kept for reproducing the fault: the front goes
+    assert graph.collect() == 2 and [e[0] for e in graph._KEEP] == [gc_]
+    monkeypatch.delenv("US_GRAPH_RELEASE")
+    d = Owner(); gd = object()
+    graph._keep(gd, d)
     del c; gc.collect()
-    assert graph.collect() == 1 and [e[0] for e in graph._KEEP] == [sentinel] and graph.collect() == 0
-    assert graph.release_all() == 1 and graph._KEEP == []
-    monkeypatch.setenv("US_KEEP_GRAPHS", "0")                      # the old behaviour, for reproducing the runtime fault
+    assert graph.collect() == 0 and len(graph._KEEP) == 2          # d's owner lives
+    del d; gc.collect()
+    monkeypatch.setenv("US_GRAPH_RELEASE", "never")
+    assert graph.collect() == 0 and len(graph._KEEP) == 2
+    monkeypatch.delenv("US_GRAPH_RELEASE")
+    assert graph.collect() == 2 and graph._KEEP == []              # every owner gone: all of them, oldest first
+    sentinel = object()
+    graph._keep(sentinel)                                          # no owner: kept until release_all(), and keeps everything behind it
+    e = Owner(); graph._keep(object(), e); del e; gc.collect()
+    assert graph.collect() == 0 and len(graph._KEEP) == 2
+    assert graph.release_all() == 2 and graph._KEEP == []
+    monkeypatch.setenv("US_KEEP_GRAPHS", "0")                      # the r4 behaviour, for reproducing the runtime fault
     graph._keep(sentinel)
     assert graph._KEEP == []
 

@@ -1,9 +1,11 @@
-"""Is destroying the OLDEST captured multi-branch hipGraph safe while newer ones keep replaying?  (graph.py's FIFO release rests on it;
-profiles/r05_hipgraph_destroy_segv.txt is the opposite order: destroying a NEWER graph breaks the older ones.)  Three MapWindows, each
+"""Is destroying the OLDEST captured multi-branch hipGraph safe while newer ones keep replaying?  (graph.py's first r6 release rule, "fifo",
+rested on it.  This script runs clean -- profiles/r06_graph_fifo.txt -- and the rule was still wrong: profiles/r06_graph_release_rules.txt;
+the default rule is now "idle", this script forces the old one.)  profiles/r05_hipgraph_destroy_segv.txt is the opposite order: destroying a NEWER graph breaks the older ones.  Three MapWindows, each
 with its captured graph (side streams: scans beside the decoders), released oldest first with replays of the survivors in between; then
 twenty capture / drop cycles with one long-lived window replaying throughout.
    python tools/graph_fifo_check.py"""
 import gc, os, sys
+os.environ["US_GRAPH_RELEASE"] = "fifo"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

@@ -18,38 +18,52 @@ import weakref
 
 import torch
 
-# Every captured graph is kept alive here for as long as a NEWER one may still be replayed.  Reason (r5, reproduced twice each way on the
-# MI355X box with `pytest tests/test_gpu_dropin.py tests/test_gpu_slam.py`; native backtrace in profiles/r05_hipgraph_destroy_segv.txt): with
-# the HIP runtime torch 2.10+rocm7.0 bundles, destroying ONE graph that has parallel branches (hipGraphExecDestroy, reached from the garbage
-# collector when a MapStep / window / SLAM object dies) leaves every OLDER multi-branch graph exec with dangling branch streams: its next
-# hipGraphLaunch dies in hip::Graph::UpdateStreams (SIGSEGV on the host).  All graphs of this package fork side streams, so a graph may only
-# be destroyed when no older one is alive.  r6: the registry is a FIFO -- each entry holds the graph and a weak reference to the object that
-# replays it (CapturedIteration / SegmentedGraph); before every new capture the entries at the FRONT whose owners are dead are dropped,
-# oldest first (the oldest graph has no older one to break).  So a long run that re-captures (a window per mapped frame, a re-capture after
-# KeyframeArena.grow() or a MapStep reallocation) holds the graphs that are still in use plus those younger than the oldest one in use, not
-# every graph ever captured.  release_all() drops everything; only safe when no captured graph will be replayed again.
+# Every captured graph is kept alive here for as long as ANY captured graph may still be replayed.  Reason (r5, reproduced twice each way on
+# the MI355X box with `pytest tests/test_gpu_dropin.py tests/test_gpu_slam.py`; native backtrace in profiles/r05_hipgraph_destroy_segv.txt):
+# with the HIP runtime torch 2.10+rocm7.0 bundles, destroying ONE graph that has parallel branches (hipGraphExecDestroy, reached from the
+# garbage collector when a MapStep / window / SLAM object dies) leaves other multi-branch graph execs with dangling branch streams: a later
+# hipGraphLaunch dies in hip::Graph::UpdateStreams (SIGSEGV on the host).  All graphs of this package fork side streams.
+# r6, first form: a FIFO (destroy the OLDEST graph once its owner is dead, on the reading that only OLDER graphs break).  That reading was
+# wrong: tools/graph_fifo_check.py ran clean, but `pytest tests/test_gpu_window.py` on its own crashed the same way after two older graphs
+# were destroyed behind a living newer one and a further graph was captured (profiles/r06_graph_release_rules.txt) -- a use-after-free that
+# only shows when the freed memory is reused.  r6, final form ("idle"): each entry holds the graph and a weak reference to the object that
+# replays it (CapturedIteration / SegmentedGraph); before a capture the registry is emptied ONLY IF every owner in it is dead -- no living
+# graph exec is left to hold a dangling stream.  A process that keeps one long-lived graph (the tracker's) and re-captures others (a window
+# per mapped frame, a re-capture after KeyframeArena.grow()) therefore holds every graph it captured: capture one graph per KIND of
+# iteration and rebind its inputs (ArenaWindow.bind does); the registry warns beyond 256.  release_all() drops everything; only safe when no
+# captured graph will be replayed again.  US_GRAPH_RELEASE=never|idle|fifo picks the rule ("fifo" only to reproduce the fault).
 _KEEP = []                  # [(graph, weakref to its owner | None)], oldest first
-_WARN_AT = 256              # a registry this long means per-frame captures whose owners stay alive: say so once
+_RELEASE_DEFAULT = "idle"
+_WARN_AT = 256              # a registry this long means per-frame captures behind a long-lived graph: say so once
 _warned = [False]
 
 
 def _keep(g, owner=None):
-    if os.environ.get("US_KEEP_GRAPHS", "1") != "0":     # "0": the old behaviour (for reproducing the runtime fault)
+    if os.environ.get("US_KEEP_GRAPHS", "1") != "0":     # "0": the r4 behaviour (for reproducing the runtime fault)
         _KEEP.append((g, weakref.ref(owner) if owner is not None else None))
         if len(_KEEP) > _WARN_AT and not _warned[0]:
             _warned[0] = True
             warnings.warn(f"unislam_amd.graph: {len(_KEEP)} captured hipGraphs are alive (each holds its launch records and a private memory pool). "
-                          "Capture one graph per KIND of iteration and rebind its inputs (ArenaWindow.bind), or drop the objects that own old "
-                          "graphs: they are destroyed oldest-first at the next capture.")
+                          "Capture one graph per KIND of iteration and rebind its inputs (ArenaWindow.bind): graphs are only destroyed once "
+                          "every object that owns one is gone.")
 
 
 def collect():
-    """destroy the graphs at the FRONT of the registry whose owners are gone (oldest first: safe, see _KEEP); returns how many.  Called
-    before every capture -- never during one (hipGraphDestroy is not permitted while a stream captures)."""
+    """empty the registry if EVERY owner in it is gone (see _KEEP); returns how many graphs were destroyed.  Called before every capture --
+    never during one (hipGraphDestroy is not permitted while a stream captures)."""
+    rule = os.environ.get("US_GRAPH_RELEASE", _RELEASE_DEFAULT)
+    if rule == "never":
+        return 0
     n = 0
-    while _KEEP and _KEEP[0][1] is not None and _KEEP[0][1]() is None:
-        _KEEP.pop(0)
-        n += 1
+    if rule == "fifo":                                   # the refuted first form: dead owners at the front go, oldest first
+        while _KEEP and _KEEP[0][1] is not None and _KEEP[0][1]() is None:
+            _KEEP.pop(0)
+            n += 1
+        return n
+    if all(r is not None and r() is None for _, r in _KEEP):
+        while _KEEP:
+            _KEEP.pop(0)                                 # oldest first
+            n += 1
     return n
 
 
