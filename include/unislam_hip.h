@@ -257,6 +257,11 @@ size_t us_mlp_n_params(const us_mlp_desc* d);
 /* US_MLP_IN_SPLIT_BF16 (US_PREC_BF16 decoders, with US_MLP_LEVEL_MAJOR): `in` holds the planes us_hashgrid_fwd_joint wrote with
  * US_GRID_FEAT_SPLIT_BF16 (the inputs already as hi / lo bf16 pairs).  Outputs and gradients as with float planes, bit for bit. */
 #define US_MLP_IN_SPLIT_BF16 4
+/* US_MLP_OUT_PREACT (us_mlp_fwd / us_mlp_fwd_pair, bf16-family precisions): `out` receives the outputs BEFORE out_act; the consumer applies it
+ * (us_render_loss_fwd + US_RENDER_ACT).  US_MLP_DOUT_PREACT (us_mlp_bwd / _pair / _pair_dydx, bf16-family): dL_dout is the gradient w.r.t.
+ * those pre-activation outputs (us_render_loss_bwd + US_RENDER_ACT); `out` is not read (may be NULL). */
+#define US_MLP_OUT_PREACT 8
+#define US_MLP_DOUT_PREACT 16
 int us_mlp_reduce(const us_mlp_desc* d, const void* workspace, size_t workspace_bytes, int64_t n, float* grad_params, void* stream);
 
 /* out[i*out_stride + o] = act(MLP(in[i][:]))[o], o < n_out   (out_stride lets two decoders write one raw[N][4]) */
@@ -437,6 +442,14 @@ enum { US_LOSS_MAP_ORIGINAL = 0, US_LOSS_MAP_NOMASK = 1, US_LOSS_TRK_ORIGINAL = 
 /* or-ed into `mode` of us_render_loss_bwd: the per-ray d(beta) partials are left in beta_partials and summed by the caller's
  * us_beta_reduce(beta_partials, n_rays, d_beta, stream) (d_beta += fixed-order sum), off the backward pass's critical path */
 #define US_LOSS_DEFER_BETA 256
+/* US_RENDER_ACT(act_rgb, act_sdf), or-ed into `mode` of us_render_loss_fwd AND us_render_loss_bwd (act_* = the decoders' us_mlp_desc.out_act):
+ * `raw` arrives as the decoders' PRE-activation outputs (us_mlp_fwd / _pair with US_MLP_OUT_PREACT).  us_render_loss_fwd applies the
+ * activations itself and REWRITES raw in place with the activated samples (what the decoders would have written, value for value: the
+ * backward calls and any later reader see the usual raw); us_render_loss_bwd leaves d_raw as the gradient w.r.t. the pre-activation
+ * outputs (the decoders' backward launch then takes US_MLP_DOUT_PREACT and does not read `out`).  The decoder launches are bound by VALU
+ * issue, these two wait on their loads: the ~80 VALU instructions per 32 points move where they are free. */
+#define US_RENDER_ACT_ON 0x100000
+#define US_RENDER_ACT(act_rgb, act_sdf) (US_RENDER_ACT_ON | ((act_rgb) << 12) | ((act_sdf) << 16))
 int us_beta_reduce(const float* beta_partials, int64_t n_rays, float* d_beta, void* stream);
 /* us_adam_step_segments(_dev): bit 31 of zero_grad_mask = the device-side step count was already advanced for this step by
  * us_adam_step_inc(step_dev, beta1, beta2, stream) (one thread: count + 1 and the two bias corrections) */

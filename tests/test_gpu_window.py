@@ -4,6 +4,7 @@ src/Mapper.py:359-376,443-459) -- its three kernels against torch / the oracle, 
 the reference's Mapper.optimize_mapping (g14), hipGraph replay against eager.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -571,11 +572,12 @@ def test_a_captured_iteration_does_not_keep_its_owner_in_a_cycle():
             gc.enable()
 
 
-def test_graph_registry_releases_oldest_first_while_newer_graphs_replay():
-    """graph.py's FIFO release on real graphs (each MapWindow graph forks side streams): the OLDEST graph is destroyed once its owner is
-    gone -- before the next capture -- and the newer ones keep replaying (the opposite order is the runtime fault of
-    profiles/r05_hipgraph_destroy_segv.txt); a graph whose owner died behind a LIVING older one waits for it.  tools/graph_fifo_check.py is
-    the long form (profiles/r06_graph_fifo.txt)."""
+def test_graph_registry_destroys_nothing_while_a_graph_is_alive():
+    """graph.py's release rule on real graphs (each MapWindow graph forks side streams): while one captured graph is alive nothing is
+    destroyed, whatever the order the owners die in -- destroying a graph NEWER than a living one is the fault of
+    profiles/r05_hipgraph_destroy_segv.txt, destroying OLDER ones and then capturing again is the one this test used to end in
+    (profiles/r06_graph_release_rules.txt); once every owner is gone the registry empties before the next capture, and that capture
+    replays.  tools/graph_fifo_check.py / graph_fifo_check2.py are the sequences that looked safe under the first rule."""
     import gc
     import unislam_amd as us
     from unislam_amd import graph
@@ -590,26 +592,34 @@ def test_graph_registry_releases_oldest_first_while_newer_graphs_replay():
         win.capture()
         return win
 
+    assert os.environ.get("US_GRAPH_RELEASE", "idle") == "idle"
     gc.collect(); graph.collect()
-    n0 = len(graph._KEEP)                                       # graphs of earlier tests whose owners are alive (or wait behind one that is)
+    n0 = len(graph._KEEP)                                       # graphs of earlier tests that wait for an owner that is still alive
     a, b, c = make(1), make(2), make(3)
     assert len(graph._KEEP) == n0 + 3
     del b; gc.collect()
-    graph.collect()
-    assert len(graph._KEEP) == n0 + 3                           # b's graph waits: a's is older and alive
+    assert graph.collect() == 0 and len(graph._KEEP) == n0 + 3
     for _ in range(5):
         a.replay(); c.replay()
     del a; gc.collect()
-    released = graph.collect()
-    assert len(graph._KEEP) == n0 + 3 - released and (released == 2 or n0 > 0)    # nothing older alive: a's and b's go, oldest first
+    assert graph.collect() == 0 and len(graph._KEEP) == n0 + 3  # c lives: a's and b's graphs wait
     for _ in range(10):
         la = c.replay()
     torch.cuda.synchronize()
     assert np.isfinite(float(la))
     d = make(4)                                                 # (a capture runs collect() itself)
+    assert len(graph._KEEP) == n0 + 4
     for _ in range(5):
         d.replay(); c.replay()
     torch.cuda.synchronize()
+    del c, d, la; gc.collect()
+    if n0 == 0:
+        assert graph.collect() == 4 and graph._KEEP == []       # no owner left: all four go, then a fresh capture replays
+        e = make(5)
+        for _ in range(5):
+            le = e.replay()
+        torch.cuda.synchronize()
+        assert np.isfinite(float(le)) and len(graph._KEEP) == 1
 
 
 def test_track_step_keeps_the_minimum_loss_pose_and_mean_uncertainty():
@@ -770,3 +780,60 @@ def test_pose_group_rides_in_the_optimiser_launch(arena):
     for k in (4, 5, 6):
         assert torch.equal(a[k], c[k]), k
     assert float(a[5].abs().max()) > 0                                          # the poses' moments did move
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_handovers_between_launches_change_no_bit(prec):
+    """The two r6 hand-overs between the launches of a mapping iteration -- features written by the encoder as the split-bf16 decoders' hi / lo
+    operand pairs (US_GRID_FEAT_SPLIT_BF16 / US_MLP_IN_SPLIT_BF16), output activations and their derivatives evaluated by the compositing
+    launches instead of the decoder launches (US_MLP_OUT_PREACT / US_MLP_DOUT_PREACT / US_RENDER_ACT) -- against the same iteration without
+    them.  First iteration (same tables on both sides): raw, rendered values, loss and the decoder gradients BIT FOR BIT, the table gradients
+    to the order of the f64 sums inside a bin; dL/d(raw) is the other side's times act'(raw), bit for bit.  Later iterations start from
+    tables that differ in a last bit in a handful of entries -- as between any two runs of one build -- so they are compared to 1e-6."""
+    import unislam_amd as us
+    b, P, n_per = 6, 500, 128
+    c2ws, depths, colors, dirs = _window(b, P, 41)
+    g = torch.Generator().manual_seed(6)
+    draws = [(torch.randint(P, (b, n_per), generator=g).to(DEV), torch.rand(b * n_per, 40, generator=g).to(DEV)) for _ in range(3)]
+    outs = []
+    for on in (False, True):
+        torch.manual_seed(0)
+        dec = us.Decoders(dict(_cfg(False), model={"mlp_precision": prec}), c_dim=32, hidden_size=32, truncation=0.06, n_blocks=2).to(DEV)
+        es, ec = us.HashGridEncoding(3, _ecfg(14)).to(DEV), us.HashGridEncoding(3, _ecfg(16)).to(DEV)
+        with torch.no_grad():
+            es.params.copy_(torch.randn(es.params.shape) * 0.3); ec.params.copy_(torch.randn(ec.params.shape) * 0.3)
+        step = us.MapStep(es, ec, dec, BOUND, 32, 8, 0.06, W, LR, max_rays=b * n_per, deterministic=True)
+        step.feat_split, step.act_handover = on, on
+        win = us.MapWindow(step, c2ws, depths, colors, dirs, n_per, joint_opt=True, cam_lr=1e-3, has_zero_depth=False)
+        rec = []
+        for idx, tr in draws:
+            loss = win.iterate(idx, None, t_rand=tr)
+            rec.append((float(loss), step.raw[:win.R].clone(), step.depth[:win.R].clone(), step.rgb[:win.R].clone(), step.d_raw[:win.R].clone(),
+                        step.grad.clone()))
+        assert (step._ms != 0) == (on and prec == "bf16") and (step._mo != 0) == on            # the paths were taken / left as asked
+        outs.append((rec, step.flat.clone(), win.poses.clone(), step.o_tab_s))
+    (ra, fa, pa, o_tab), (rb, fb, pb, _) = outs
+
+    def where(x, y):
+        bad = (x != y).nonzero()
+        return (len(bad), bad[:4].tolist(), x[x != y][:4].tolist(), y[x != y][:4].tolist())
+    (la, raw_a, d_a, c_a, dr_a, g_a), (lb, raw_b, d_b, c_b, dr_b, g_b) = ra[0], rb[0]
+    assert la == lb, (la, lb)
+    assert torch.equal(raw_a, raw_b), where(raw_a, raw_b)
+    assert torch.equal(d_a, d_b) and torch.equal(c_a, c_b), (where(d_a, d_b), where(c_a, c_b))
+    # dL/d(raw): with the hand-over it is the gradient w.r.t. the PRE-activation outputs -- the other's times act'(raw)
+    want = dr_a.clone()
+    want[..., :3] = dr_a[..., :3] * (raw_a[..., :3] * (1.0 - raw_a[..., :3]))
+    want[..., 3] = dr_a[..., 3] * (1.0 - raw_a[..., 3] * raw_a[..., 3])
+    assert torch.equal(dr_b, want), where(dr_b, want)
+    assert torch.equal(g_a[:o_tab], g_b[:o_tab]), where(g_a[:o_tab], g_b[:o_tab])            # decoders + beta
+    assert float(g_a[o_tab:].abs().max()) > 0 and torch.allclose(g_a[o_tab:], g_b[o_tab:], rtol=1e-6, atol=1e-12)
+    for it in (1, 2):
+        (la, raw_a, d_a, c_a, _, g_a), (lb, raw_b, d_b, c_b, _, g_b) = ra[it], rb[it]
+        assert abs(la - lb) <= 1e-6 * abs(la), (it, la, lb)
+        for x, y in ((raw_a, raw_b), (d_a, d_b), (c_a, c_b)):
+            assert torch.allclose(x, y, rtol=1e-6, atol=1e-7), (it, float((x - y).abs().max()))
+        assert float((raw_a != raw_b).float().mean()) < 1e-3                                    # (a last bit here and there, not a different path)
+    d = (fa - fb).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) < 1e-5, (float((d > 0).float().mean()), float(d.max()))
+    assert torch.allclose(pa, pb, rtol=0, atol=1e-7)

@@ -27,6 +27,9 @@ US_GRID_BWD_RECORDS_READY = 1024
 US_MLP_LEVEL_MAJOR = 1
 US_MLP_DEFER_REDUCE = 2
 FEAT_SPLIT_DEFAULT = os.environ.get("US_FEAT_SPLIT", "1") != "0"   # the pre-split feature hand-over of the split-bf16 decoders (A/B switch)
+US_MLP_OUT_PREACT, US_MLP_DOUT_PREACT = 8, 16   # decoder outputs before out_act / dL_dout w.r.t. them (the compositing launches take the activation)
+US_RENDER_ACT_ON = 0x100000
+ACT_HANDOVER_DEFAULT = os.environ.get("US_ACT_HANDOVER", "1") != "0"    # A/B switch of that hand-over
 US_MLP_IN_SPLIT_BF16 = 4        # `in` holds the hi / lo bf16 pairs the joint encoder wrote with US_GRID_FEAT_SPLIT_BF16
 US_LOSS_DEFER_BETA = 256
 US_ADAM_STEP_ADVANCED = 0x80000000

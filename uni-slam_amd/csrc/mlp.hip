@@ -126,16 +126,7 @@ __device__ __forceinline__ void relu_bwd_(v4f (&dh)[NQ][MT], const v4f (&h)[NQ][
             for (int r = 0; r < 4; ++r) dh[q][m][r] = h[q][m][r] > 0.0f ? dh[q][m][r] : 0.0f;
 }
 
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == US_ACT_TANH) return tanhf(v);
-    if (act == US_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
-    return v;
-}
-__device__ __forceinline__ float act_bwd(float y, int act) {
-    if (act == US_ACT_TANH) return 1.0f - y * y;
-    if (act == US_ACT_SIGMOID) return y * (1.0f - y);
-    return 1.0f;
-}
+#include "act_dev.h"
 
 // cooperative load of the flat parameter vector [W0 | WH | WL | biases] into the LDS images.  All of a thread's global loads
 // are issued before the first LDS store (a load -> store -> load ... loop cost ~11 dependent round trips = most of the
@@ -591,12 +582,15 @@ extern "C" size_t us_mlp_n_params(const us_mlp_desc* d) {
         }                                                                                                          \
     } while (0)
 
-// the kernels' `lm` word: bit 0 level-major planes, bit 1 inputs already split into hi / lo bf16 pairs (US_MLP_IN_SPLIT_BF16)
+// the kernels' `lm` word: bit 0 level-major planes, bit 1 inputs already split into hi / lo bf16 pairs (US_MLP_IN_SPLIT_BF16), bit 2 outputs
+// before the activation (US_MLP_OUT_PREACT), bit 3 dL_dout w.r.t. those (US_MLP_DOUT_PREACT)
 static int mlp_lm_word(const char* fn, int flags, const us_mlp_desc* d, int* lm_out) {
     const int split = (flags & US_MLP_IN_SPLIT_BF16) ? 1 : 0;
     US_REQUIRE(!split || ((flags & US_MLP_LEVEL_MAJOR) && d && d->precision == US_PREC_BF16 && d->n_in == 32), US_ERR_CONFIG,
                "%s: US_MLP_IN_SPLIT_BF16 needs US_MLP_LEVEL_MAJOR and US_PREC_BF16 decoders of 32 inputs", fn);
-    *lm_out = ((flags & US_MLP_LEVEL_MAJOR) ? 1 : 0) | (split ? 2 : 0);
+    const int pre = flags & (US_MLP_OUT_PREACT | US_MLP_DOUT_PREACT);
+    US_REQUIRE(!pre || (d && d->precision != US_PREC_F32), US_ERR_CONFIG, "%s: US_MLP_OUT_PREACT / US_MLP_DOUT_PREACT are served by the bf16-family kernels", fn);
+    *lm_out = ((flags & US_MLP_LEVEL_MAJOR) ? 1 : 0) | (split ? 2 : 0) | ((flags & US_MLP_OUT_PREACT) ? 4 : 0) | ((flags & US_MLP_DOUT_PREACT) ? 8 : 0);
     return US_OK;
 }
 

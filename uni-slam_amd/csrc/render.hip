@@ -9,6 +9,7 @@
 #include "us_common.h"
 #include "dec_adam_dev.h"
 #include "pose_step_dev.h"
+#include "act_dev.h"
 #include <math.h>
 #include <string.h>
 
@@ -279,9 +280,11 @@ __device__ __forceinline__ RayGate ray_gate(int mode, float gt, float d, float u
 
 // loss terms riding on the compositing kernels (us_render_loss_fwd / us_render_loss_bwd): enabled == 0 -> plain compositing
 struct LossFwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; float tr, tr04; float* partials;
-                 float* err; };                 // err (US_LOSS_TRK_ORIGINAL): |gt - depth| per ray for the median gate, applied by k_track_gate_reduce
+                 float* err; int act; };        // act (US_RENDER_ACT): 0, or US_RENDER_ACT_ON | rgb activation << 12 | sdf activation << 16 -- `raw` arrives as the decoders'
+                                                // pre-activation outputs (US_MLP_OUT_PREACT): activated here and written back in place                 // err (US_LOSS_TRK_ORIGINAL): |gt - depth| per ray for the median gate, applied by k_track_gate_reduce
 struct LossBwd { int enabled, mode; const uint8_t* valid; const float* gt_depth; const float* gt_color; const float* depth; const float* rgb;
-                 const float* unc; float tr, tr04; LossW lw; const float* stats; float* loss_out; const float* median; };
+                 const float* unc; float tr, tr04; LossW lw; const float* stats; float* loss_out; const float* median;
+                 int act; };                    // act (US_RENDER_ACT): d_raw leaves as the gradient w.r.t. the decoders' PRE-activation outputs (US_MLP_DOUT_PREACT)
 
 template <int EPL>
 __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
@@ -300,7 +303,14 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__
         const int s = lane * EPL + e;
         a[e] = 0.0f; z[e] = 0.0f; c[e][0] = c[e][1] = c[e][2] = 0.0f; tl[e] = 1.0f; sdfv[e] = 0.0f;
         if (s < S) {
-            const float4 r = *reinterpret_cast<const float4*>(raw + (ray * S + s) * 4);
+            float4 r = *reinterpret_cast<const float4*>(raw + (ray * S + s) * 4);
+            if (lf.act) {
+                // the decoders left their pre-activation outputs (their launches are bound by VALU issue; this one waits on its loads):
+                // the same act_fwd, value for value, and `raw` holds the activated sample from here on (the backward passes read it)
+                const int ac = (lf.act >> 12) & 15, as = (lf.act >> 16) & 15;
+                r.x = act_fwd(r.x, ac); r.y = act_fwd(r.y, ac); r.z = act_fwd(r.z, ac); r.w = act_fwd(r.w, as);
+                *reinterpret_cast<float4*>(const_cast<float*>(raw) + (ray * S + s) * 4) = r;
+            }
             float sig, ex;
             sdfv[e] = r.w;
             a[e] = sdf_to_alpha(r.w, beta, sig, ex);
@@ -477,6 +487,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
                 else if (!back) gs = k_ta * ((z[e] + sdf[e] * lb.tr) - gt_l) * lb.tr;
             }
             o.w = da * da_dsdf + gs;
+            if (lb.act) {                            // ... times the output activations' derivatives: what the decoders' backward pass would form first
+                const int ac = (lb.act >> 12) & 15, as = (lb.act >> 16) & 15;
+                o.x = o.x * act_bwd(c[e][0], ac); o.y = o.y * act_bwd(c[e][1], ac); o.z = o.z * act_bwd(c[e][2], ac); o.w = o.w * act_bwd(sdf[e], as);
+            }
             *reinterpret_cast<float4*>(d_raw + (ray * S + s) * 4) = o;
             dbeta_local += da * da_dbeta;
         }
@@ -1643,13 +1657,15 @@ extern "C" int us_loss_grad(int mode, const float* sdf, int64_t sdf_stride, cons
 extern "C" int us_render_loss_fwd(const float* raw, const float* z_vals, const float* beta, int64_t n_rays, int n_samples, int mode,
                                   const uint8_t* valid, const float* gt_depth, const float* gt_color, double truncation, float* term,
                                   float* pixel_unc, float* depth, float* rgb, float* depth_unc, float* partials, float* stats, void* stream) {
+    const int act = (mode & US_RENDER_ACT_ON) ? (mode & 0x1FF000) : 0;     // US_RENDER_ACT(rgb, sdf): raw holds pre-activation outputs
+    mode &= 0xFF;
     US_REQUIRE(mode == US_LOSS_MAP_ORIGINAL || mode == US_LOSS_MAP_NOMASK || mode == US_LOSS_TRK_NOMASK, US_ERR_CONFIG,
                "us_render_loss_fwd: mode %d needs the median of the rendered depth error (use us_composite_fwd + us_loss_stats)", mode);
     US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_render_loss_fwd: empty batch");
     US_REQUIRE(raw && z_vals && beta && gt_depth && gt_color && term && pixel_unc && depth && rgb && depth_unc && partials && stats, US_ERR_NULL,
                "us_render_loss_fwd: NULL pointer");
     US_REQUIRE(n_samples >= 1 && n_samples <= 128, US_ERR_SHAPE, "us_render_loss_fwd: n_samples %d not in 1..128", n_samples);
-    LossFwd lf{1, mode, valid, gt_depth, gt_color, (float)truncation, (float)(0.4 * truncation), partials};
+    LossFwd lf{1, mode, valid, gt_depth, gt_color, (float)truncation, (float)(0.4 * truncation), partials, nullptr, act};
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (n_samples <= 64)
@@ -1667,7 +1683,8 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
                                   const float* pixel_unc, double truncation, const float* w5_host, const float* stats, float* d_raw,
                                   float* d_beta, float* beta_partials, float* loss_out, void* stream) {
     const bool defer_beta = (mode & US_LOSS_DEFER_BETA) != 0;    // the caller sums the per-ray d(beta) partials itself (us_beta_reduce)
-    mode &= ~US_LOSS_DEFER_BETA;
+    const int act = (mode & US_RENDER_ACT_ON) ? (mode & 0x1FF000) : 0;     // US_RENDER_ACT(rgb, sdf): d_raw w.r.t. pre-activation outputs
+    mode &= 0xFF;
     US_REQUIRE(mode == US_LOSS_MAP_ORIGINAL || mode == US_LOSS_MAP_NOMASK || mode == US_LOSS_TRK_NOMASK, US_ERR_CONFIG,
                "us_render_loss_bwd: mode %d needs the median of the rendered depth error (use us_loss_grad + us_composite_bwd)", mode);
     US_REQUIRE(n_rays >= 1, US_ERR_SHAPE, "us_render_loss_bwd: empty batch");
@@ -1677,6 +1694,7 @@ extern "C" int us_render_loss_bwd(const float* raw, const float* z_vals, const f
     LossBwd lb{};
     lb.enabled = 1; lb.mode = mode; lb.valid = valid; lb.gt_depth = gt_depth; lb.gt_color = gt_color; lb.depth = depth; lb.rgb = rgb;
     lb.unc = pixel_unc; lb.tr = (float)truncation; lb.tr04 = (float)(0.4 * truncation); lb.stats = stats; lb.loss_out = loss_out;
+    lb.act = act;
     for (int k = 0; k < 5; ++k) lb.lw.w[k] = w5_host[k];
     dim3 grid((unsigned)us_cdiv(n_rays, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;

@@ -301,6 +301,20 @@ class MapStep:
         self._gs, self._ms = (L.US_GRID_FEAT_SPLIT_BF16, L.US_MLP_IN_SPLIT_BF16) if on else (0, 0)
         return self._gs, self._ms
 
+    def _act_flags(self):
+        """the output activations' hand-over (r6): with bf16-family decoders the decoder launches write / take PRE-activation values
+        (US_MLP_OUT_PREACT / US_MLP_DOUT_PREACT) and the compositing launches apply tanh / sigmoid and their derivatives
+        (US_RENDER_ACT in `mode`): ~80 VALU instructions per 32 points leave kernels that are bound by VALU issue for kernels that wait on
+        their loads.  raw is rewritten in place with the activated samples by us_render_loss_fwd: same values as before.
+        act_handover = False turns it off."""
+        on = bool(getattr(self, "act_handover", L.ACT_HANDOVER_DEFAULT) and self.desc_s.precision != 0 and self.desc_c.precision != 0)
+        if on:
+            self._mo, self._md = L.US_MLP_OUT_PREACT, L.US_MLP_DOUT_PREACT
+            self._ra = L.US_RENDER_ACT_ON | (int(self.desc_c.out_act) << 12) | (int(self.desc_s.out_act) << 16)
+        else:
+            self._mo = self._md = self._ra = 0
+        return self._mo
+
     def _decoder_pair(self):
         """joint path: run the two decoders as ONE launch each way (us_mlp_fwd_pair / us_mlp_bwd_pair)?  Yes when they have one shape and a
         bf16 precision."""
@@ -392,6 +406,7 @@ class MapStep:
         N = R * S
         P = L.ptr
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
+        mo_ = self._act_flags()
         # pre-filter against the scene box (Mapper.py:396-406) as a validity flag instead of a compaction
         c_free, s_off, s_span = ctypes.c_float(1.2), ctypes.c_float(1.5 * self.truncation), ctypes.c_float(3 * self.truncation)
         # filter + z + points in one launch; jitter from t_rand or, if none is given, from the in-kernel generator
@@ -486,13 +501,13 @@ class MapStep:
                 fork_scans()
             if self._decoder_pair():                             # both decoders in one launch
                 self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st))
+                                                                        off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_ | mo_, st))
                 if main_first:
                     fork_scans()
                 return self._finish_forward(o, d, gd, gc, R)
             # decoders of different shapes: one after the other on the main stream
-            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1 | ms_, st))
-            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1 | ms_, st))
+            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1 | ms_ | mo_, st))
+            self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1 | ms_ | mo_, st))
             return self._finish_forward(o, d, gd, gc, R)
         if not backward_follows and self.joint and self._decoder_pair():
             # a render-only call on ONE stream: both encoders in one launch (no binning counts), both decoders in one launch
@@ -500,7 +515,7 @@ class MapStep:
             self._timed("hashgrid_fwd_joint", lambda: lib.us_hashgrid_fwd_joint(ds, dc, off(fl, self.o_tab_s), off(fl, self.o_tab_c), P(self.pts), N,
                                                                                 P(self.feat_s), P(self.feat_c), 3 | gs_, None, 0, st))
             self._timed("mlp_fwd_pair", lambda: lib.us_mlp_fwd_pair(ms, mc, off(fl, self.o_dec_s), off(fl, self.o_dec_c), P(self.feat_s), P(self.feat_c), N,
-                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_, st))
+                                                                    off(self.raw, 3), 4, P(self.raw), 4, 1 | ms_ | mo_, st))
             return self._finish_forward(o, d, gd, gc, R)
         self._split_flags(False)                                 # (the one-grid encoders write float planes)
         with self._branch() as st2:
@@ -509,13 +524,13 @@ class MapStep:
                                                                                     P(self.ws_s), self.ws_bytes, st2))
             else:
                 self._timed("hashgrid_fwd_sdf", lambda: lib.us_hashgrid_fwd(ds, off(fl, self.o_tab_s), P(self.pts), N, P(self.feat_s), None, 3, st2))
-            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1, st2))
+            self._timed("mlp_fwd_sdf", lambda: lib.us_mlp_fwd(ms, off(fl, self.o_dec_s), P(self.feat_s), N, off(self.raw, 3), 4, 1 | mo_, st2))
         if counted:
             self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd_counted(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), 3,
                                                                                   P(self.ws), self.ws_bytes, st))
         else:
             self._timed("hashgrid_fwd_color", lambda: lib.us_hashgrid_fwd(dc, off(fl, self.o_tab_c), P(self.pts), N, P(self.feat_c), None, 3, st))
-        self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1, st))
+        self._timed("mlp_fwd_color", lambda: lib.us_mlp_fwd(mc, off(fl, self.o_dec_c), P(self.feat_c), N, P(self.raw), 4, 1 | mo_, st))
         self._join()
         return self._finish_forward(o, d, gd, gc, R)
 
@@ -523,7 +538,7 @@ class MapStep:
         lib, st, P, S, fl = L.lib(), L.stream(), L.ptr, self.S, self.flat
         beta = ctypes.c_void_p(fl.data_ptr() + 4 * self.o_beta)
         # compositing + the loss's sums and counts in one launch (+ the fixed-order reduction)
-        L.check(lib.us_render_loss_fwd(P(self.raw), P(self.z), beta, R, S, self.mode, P(self.valid), P(gd), P(gc), self.truncation,
+        L.check(lib.us_render_loss_fwd(P(self.raw), P(self.z), beta, R, S, self.mode | getattr(self, "_ra", 0), P(self.valid), P(gd), P(gc), self.truncation,
                                        P(self.term), P(self.unc), P(self.depth), P(self.rgb), P(self.dunc), P(self.partials), P(self.stats), st),
                 "us_render_loss_fwd")
         self._batch = (o, d, gd, gc, R)
@@ -570,14 +585,15 @@ class MapStep:
         self._dec_grad_clean = False
         gbeta = off(self.grad, self.o_beta) if self.has_beta else None
         # the loss gradients (from the possibly all-reduced statistics) + the compositing backward in one launch
-        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode | (L.US_LOSS_DEFER_BETA if (defer and gbeta is not None) else 0),
+        md_ = getattr(self, "_md", 0)                            # (the forward pass's choice: dL/d(raw) leaves w.r.t. the pre-activation outputs)
+        L.check(lib.us_render_loss_bwd(P(self.raw), P(self.z), beta, R, S, self.mode | getattr(self, "_ra", 0) | (L.US_LOSS_DEFER_BETA if (defer and gbeta is not None) else 0),
                                        P(self.valid), P(gd), P(gc), P(self.depth), P(self.rgb),
                                        P(self.unc), self.truncation, self.w5, P(self.stats), P(self.d_raw), gbeta, P(self.beta_part),
                                        P(self.loss), st), "us_render_loss_bwd")
 
         def sdf_branch(q):
             self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
-                                                              off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1,
+                                                              off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), 1 | md_,
                                                               P(self.mlp_ws_s), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_sdf", lambda: lib.us_hashgrid_bwd_binned(ds, P(self.pts), P(self.d_feat_s), N, off(self.grad, self.o_tab_s),
@@ -588,7 +604,7 @@ class MapStep:
 
         def color_branch(q):
             self._timed("mlp_bwd_color", lambda: lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4,
-                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1, P(self.mlp_ws), self.mlp_ws_bytes, q))
+                                                                N, P(self.d_feat_c), off(self.grad, self.o_dec_c), 1 | md_, P(self.mlp_ws), self.mlp_ws_bytes, q))
             if binned:
                 self._timed("hashgrid_bwd_color", lambda: lib.us_hashgrid_bwd_binned(dc, P(self.pts), P(self.d_feat_c), N, off(self.grad, self.o_tab_c),
                                                                                     3 | L.US_GRID_BWD_OVERWRITE | self._det | (L.US_GRID_BWD_COUNTED if self._counted else 0), P(self.ws), self.ws_bytes, q))
@@ -600,7 +616,7 @@ class MapStep:
             self._backward_in_ranges(R, on_ready)
         elif self.joint:
             # the two decoder backward passes side by side, then ONE binned pass for both tables
-            mflags = 1 | getattr(self, "_ms", 0) | (L.US_MLP_DEFER_REDUCE if defer else 0)   # (_ms: the forward pass left pre-split feature planes)
+            mflags = 1 | md_ | getattr(self, "_ms", 0) | (L.US_MLP_DEFER_REDUCE if defer else 0)   # (_ms: the forward pass left pre-split feature planes)
             mlp_s = lambda q: self._timed("mlp_bwd_sdf", lambda: lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4,
                                                                                 off(self.d_raw, 3), 4, N, P(self.d_feat_s), off(self.grad, self.o_dec_s), mflags,
                                                                                 P(self.mlp_ws_s), self.mlp_ws_bytes, q))
@@ -756,7 +772,7 @@ class MapStep:
         off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)
         ds, dc = ctypes.byref(self.es.desc), ctypes.byref(self.ec.desc)
         ms, mc = ctypes.byref(self.desc_s), ctypes.byref(self.desc_c)
-        mf = 1 | getattr(self, "_ms", 0)
+        mf = 1 | getattr(self, "_ms", 0) | getattr(self, "_md", 0)
         L.check(lib.us_mlp_bwd(mc, off(fl, self.o_dec_c), P(self.feat_c), P(self.raw), 4, P(self.d_raw), 4, N, P(self.d_feat_c),
                                off(self.grad, self.o_dec_c), mf, P(self.mlp_ws), self.mlp_ws_bytes, st), "us_mlp_bwd")
         L.check(lib.us_mlp_bwd(ms, off(fl, self.o_dec_s), P(self.feat_s), off(self.raw, 3), 4, off(self.d_raw, 3), 4, N, P(self.d_feat_s),
