@@ -31,4 +31,5 @@ def log(idx, s):
     d = (s.estimate_c2w_list[idx][:3, 3] - s.gt_c2w_list[idx][:3, 3]) * 100
     print(f"{idx:4d} err {e:7.3f} cm ({float(d[0]):6.2f} {float(d[1]):6.2f} {float(d[2]):6.2f})  tb {int(s.tracking_back)}  kf {len(s.mapper.keyframe_list):3d}  unc {float(w) if w is not None else -1:.5f} joint {int(s.mapper.joint_opt)}", flush=True)
 slam.run(log=log)
-print("ATE", 100 * slam.ate_rmse(), "max mem GB", torch.cuda.max_memory_allocated() / 2**30)
+from unislam_amd import graph
+print("ATE", 100 * slam.ate_rmse(), "max mem GB", torch.cuda.max_memory_allocated() / 2**30, "captured graphs alive", len(graph._KEEP))
