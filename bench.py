@@ -81,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward only, bf16 decoders, trained-like tables)")
+    ap.add_argument("--side", default="", choices=["", "dp_rank_local"],
+                    help="(internal) run ONE side measurement and print its JSON: what side_process() starts as a child of the N = 1 run")
     return ap.parse_args(argv)
 
 
@@ -446,8 +448,38 @@ def slam_bench(us, dev, hidden, prec, n_frames=30):
                     "steady_state_ms_per_frame": tr + mp / every, "steady_state_frames_per_s": 1e3 / (tr + mp / every),
                     "ate_rmse_cm": 100 * slam.ate_rmse(), "keyframes": len(slam.mapper.keyframe_list), "joint_opt": bool(slam.mapper.joint_opt),
                     "tracking_ms_all": [round(x, 2) for x in t_track], "mapping_ms_all": [round(x, 1) for x in t_map]})
+        out["render_img"] = render_img_bench(us, slam, frames, cfg, bound, dev)
     except Exception as e:                                # report, do not hide
         out["error"] = repr(e)[:300]
+    return out
+
+
+def render_img_bench(us, slam, frames, cfg, bound, dev, reps=5):
+    """
+    the forward-only consumer of the path: Renderer.render_img (src/utils/Renderer.py:160-223) of one 680 x 1200 frame at
+    its estimated pose on the map the run above built -- 816 000 rays x 40 samples, sampling + encoders + decoders + compositing per chunk,
+    no gradient -- with the reference's chunk (ray_batch_size = 10000: 82 chunks) and with 204 000 rays per chunk (4 chunks).  Wall time
+    around the call with a device synchronisation on both sides, median of `reps`; the PSNR of the render is a sanity number.
+    """
+    import types
+    out = {}
+    k = len(frames) - 1
+    _, color, depth, _, _ = frames[k]
+    c2w = slam.estimate_c2w_list[k].to(dev)
+    holder = types.SimpleNamespace(bound=bound, device=dev, H=frames.H, W=frames.W, fx=frames.fx, fy=frames.fy, cx=frames.cx, cy=frames.cy)
+    rcfg = dict(cfg, rendering=dict(cfg["rendering"], perturb=False))
+    for name, chunk in (("ray_batch_size_10000", 10000), ("ray_batch_size_204000", 204000)):
+        r = us.Renderer(rcfg, holder, ray_batch_size=chunk)
+        ts = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            d, c, *_ = r.render_img(([slam.es], [slam.ec]), slam.decoders, c2w, 0.06, dev, gt_depth=depth)
+            torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+        ms = _median(ts[1:])
+        mse = float(((c.float() - color) ** 2).mean())
+        out[name] = {"ms_per_image": ms, "rays_per_s": frames.H * frames.W / (ms / 1e3), "chunks": -(-frames.H * frames.W // chunk),
+                     "psnr_db": -10.0 * math.log10(max(mse, 1e-12))}
+    out["workload"] = "Renderer.render_img of one 680 x 1200 frame (816 000 rays x 40 samples, forward only) at its estimated pose, bf16 decoders"
     return out
 
 
@@ -496,7 +528,7 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
     """
     What ONE rank of the data-parallel step costs by itself: a 1-rank RCCL process group, so every collective of the step is
     issued and waited for but moves nothing.  MapStep(group=True) in its two dp_modes: eager, replayed as hipGraph segments between the
-    collectives (graph.SegmentedGraph), and replayed as ONE graph that holds the RCCL calls (the default); with the poses fixed and with
+    collectives (graph.SegmentedGraph; the default), and replayed as ONE graph that holds the RCCL calls (opt-in); with the poses fixed and with
     joint_opt (rank-owned poses, src/Mapper.py:359-376).
     """
     import torch.distributed as dist
@@ -531,12 +563,12 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
                 o[tag + "_graph_segments_ms"] = timed(win.replay)
                 o[tag + "_graph_segments"] = len(win._graph.segments)
                 o[tag + "_graph_segments_launched"] = win._graph.n_launched    # (r6: a segment that recorded nothing is skipped on replay)
-                win.capture()                                # RCCL: the collectives captured into the ONE graph (the default)
+                win.capture(collectives="inside")            # RCCL: the collectives captured into the ONE graph (opt-in; this is why the run has a process of its own)
                 o[tag + "_replayed_ms"] = timed(win.replay)
             out[mode] = o
         step = build_step(group=True, dp_mode="local_fast", sharded_adam=True)[0]
         win = us.MapWindow(step, c2ws, pd, pc, pr, 4096 // N_KEYFRAMES, joint_opt=False, has_zero_depth=False)
-        win.capture()
+        win.capture(collectives="inside")
         out["local_fast_sharded_adam"] = {"poses_fixed_replayed_ms": timed(win.replay), "note": "reduce-scatter + Adam on this rank's shard "
                                           "(1 rank: the whole buffer) + all-gather"}
     except Exception as e:                                # report, do not hide
@@ -545,6 +577,35 @@ def dp_rank_local_bench(us, build_step, bound, dev, steps, warmup):
         if own_pg and dist.is_initialized():
             dist.destroy_process_group()
     return out
+
+
+def side_process(name, args, timeout_s=300):
+    """
+    A side run in a process of its own, its JSON merged into the parent's record.  Used for `dp_rank_local_ms`: that run opens an RCCL
+    process group and captures collectives into hipGraphs, and once (r6, 1 of ~40 runs) torch's process-group watchdog thread queried an event
+    that had been recorded in a capturing stream (hipErrorCapturedEvent) and terminated the process -- which took the whole bench line with
+    it.  A child that dies costs its own entry only: the error text is recorded and the run is tried once more.
+    """
+    cmd = [sys.executable, os.path.abspath(__file__), "--side", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rays", str(args.rays), "--hidden", str(args.hidden), "--mlp-precision", args.mlp_precision, "--bwd-mode", str(args.bwd_mode),
+           "--joint", args.joint, "--grad-comm", args.grad_comm] + (["--no-overlap"] if args.no_overlap else []) + \
+          (["--no-decoder-pair"] if args.no_decoder_pair else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    last = None
+    for attempt in range(2):
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=os.path.dirname(os.path.abspath(__file__)))
+        except subprocess.TimeoutExpired:
+            return {"error": f"side process {name}: no result within {timeout_s} s"}
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            out = json.loads(lines[-1])
+            if attempt:
+                out["first_attempt"] = last
+            return out
+        err = [ln for ln in p.stderr.splitlines() if "rror" in ln]
+        last = f"side process {name} ended with code {p.returncode}: " + (err[0] if err else p.stderr[-300:])[:400]
+    return {"error": last}
 
 
 def _tcnn_only_model_class():
@@ -859,6 +920,12 @@ def run_rank(args):
         st.decoder_pair = not args.no_decoder_pair
         return st, es, ec, dec
 
+    if args.side == "dp_rank_local":                        # (a child of the N = 1 run: side_process)
+        out = dp_rank_local_bench(us, lambda **kw: build_step(args.mlp_precision, **kw), bound, dev, args.steps, args.warmup)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        return
+
     step, es, ec, dec = build_step(args.mlp_precision)
     if world > 1:
         broadcast_parameters(step.flat)
@@ -1078,7 +1145,7 @@ def run_rank(args):
         if world == 1 and not args.no_tracking and not args.no_extras:
             rec["slam_frame"] = slam_bench(us, dev, args.hidden, args.mlp_precision)
         if world == 1 and not args.no_extras:
-            rec["dp_rank_local_ms"] = dp_rank_local_bench(us, lambda **kw: build_step(args.mlp_precision, **kw), bound, dev, args.steps, args.warmup)
+            rec["dp_rank_local_ms"] = side_process("dp_rank_local", args)     # (RCCL group + captured collectives: in a process of its own)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(bound, n_strat, n_imp, args.hidden, R)
         sys.stdout.flush()

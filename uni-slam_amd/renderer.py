@@ -203,17 +203,19 @@ class Renderer(object):
         return zero_depth_z(scene_rep, decoders, rays_o_uni, rays_d_uni, self._bhost, self._t_uni, self.n_importance,
                             self.perturb, device)
 
-    def render_batch_ray(self, scene_rep, decoders, rays_d, rays_o, device, truncation, gt_depth=None, t_rand=None):
+    def render_batch_ray(self, scene_rep, decoders, rays_d, rays_o, device, truncation, gt_depth=None, t_rand=None, all_depth=None):
         """
         Renderer.py:59-152.  Returns (termination_prob, pixel_unc, rendered_depth, rendered_rgb, sdf[R,S],
         z_vals[R,S], rendered_depth_uncertainty).  `t_rand` ([R_with_depth, S], optional) replaces the
-        torch.rand draw of the jitter (parity tests); otherwise it is drawn on the device.
+        torch.rand draw of the jitter (parity tests); otherwise it is drawn on the device.  `all_depth` (optional): the caller already
+        knows whether every ray carries a depth (render_img asks once per image instead of once per chunk).
         """
         n_rays = rays_o.shape[0]
         S = self.n_stratified + self.n_importance
         gt_depth = gt_depth.reshape(-1, 1)
         # the reference synchronises here too (Renderer.py:104: `if not gt_mask.all()`); one reduction instead of compare + all
-        all_depth = n_rays == 0 or float(gt_depth.detach().min()) > 0
+        if all_depth is None:
+            all_depth = n_rays == 0 or float(gt_depth.detach().min()) > 0
         gt_mask = None if all_depth else (gt_depth > 0).squeeze(-1)
         if all_depth and n_rays > 0:
             # z sampling + jitter + points in ONE launch (us_sample_points)
@@ -249,10 +251,13 @@ class Renderer(object):
             rays_o = rays_o.reshape(-1, 3); rays_d = rays_d.reshape(-1, 3)
             outs = [[], [], [], [], []]
             gt_depth = gt_depth.reshape(-1)
+            # one question per image instead of one host synchronisation per chunk (Renderer.py:104 asks in every render_batch_ray call):
+            # if every pixel has a depth, every chunk does; otherwise each chunk finds out for itself
+            whole = True if (gt_depth.numel() > 0 and float(gt_depth.min()) > 0) else None
             for i in range(0, rays_d.shape[0], self.ray_batch_size):
                 ret = self.render_batch_ray(scene_rep, decoders, rays_d[i:i + self.ray_batch_size].contiguous(),
                                             rays_o[i:i + self.ray_batch_size].contiguous(), device, truncation,
-                                            gt_depth=gt_depth[i:i + self.ray_batch_size])
+                                            gt_depth=gt_depth[i:i + self.ray_batch_size], all_depth=whole)
                 term, unc, depth, color, _, _, dunc = ret
                 outs[0].append(term.double()); outs[1].append(unc.double()); outs[2].append(dunc.double())
                 outs[3].append(depth.double()); outs[4].append(color)

@@ -263,18 +263,15 @@ class MapWindow:
                 graph = CapturedIteration(body, warmup=0)
             else:
                 # data-parallel: the rank-local launches as hipGraph segments, the collectives between them (dist.dp_iterate's `cut`)
-                # collectives "inside" (default over RCCL): the process group's calls are captured INTO the one graph -- RCCL kernels as graph
-                # nodes, one launch per step: measured 0.536 ms of rank-local time against 0.585 eager and 0.642 with "between" (each
-                # segment boundary leaves the GPU idle for a graph launch); "between" (default over gloo, which cannot be captured): the
-                # collectives stay eager between hipGraph segments
-                import torch.distributed as dist
-                from .dist import _pg
+                # collectives "between" (default): the collectives stay eager between hipGraph segments (graph.SegmentedGraph; the form the
+                # gloo world-2 / 8 tests cover).  "inside" (opt-in, RCCL only): the process group's calls are captured INTO the one graph --
+                # RCCL kernels as graph nodes, one launch per step: 0.51 ms of rank-local time against 0.54 eager and 0.60 with "between" --
+                # but it has only ever run on a 1-rank group (no node with more GPUs was available to the builder): work handles,
+                # finish_first and the optimiser in parts inside a captured graph are untested at world > 1, a hang during replay only ends
+                # at the process group's timeout, and once in ~40 runs of bench.py's 1-rank rehearsal torch's process-group watchdog thread
+                # queried an event that had been recorded in the capturing stream (hipErrorCapturedEvent) and terminated the process.
                 if collectives is None:
-                    # "inside" has only ever run on a 1-rank RCCL group (no node with more GPUs was available to the builder): work handles,
-                    # finish_first and the optimiser in parts inside a captured graph are untested at world > 1, and a hang during replay only
-                    # ends at the process group's timeout.  Default: "inside" for one rank, "between" (tested with gloo at world 2 / 8) beyond.
-                    nccl = dist.get_backend(_pg(s.group)) == "nccl"
-                    collectives = "inside" if (nccl and dist.get_world_size(_pg(s.group)) == 1) else "between"
+                    collectives = "between"
                 if collectives not in ("inside", "between"):
                     raise L.UniSlamHipError(f"MapWindow.capture: collectives {collectives!r} not in ('inside', 'between')")
                 inside = collectives == "inside"
