@@ -31,6 +31,25 @@ def test_plain_multi_gpu_command_spawns_ranks_and_propagates_failure():
     assert out.stdout.strip() == ""
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the failure path of a box without a GPU")
+def test_a_side_process_that_dies_costs_its_own_entry_only():
+    """bench.side_process: the dp_rank_local side run (an RCCL group + collectives captured into graphs) has a process of its own since
+    torch's process-group watchdog once terminated bench.py in it; a child that ends badly is tried once more and then leaves an error
+    text in its entry -- here both attempts end with 'needs the MI355X'"""
+    import bench
+    args = bench.parse_args(["--steps", "2", "--warmup", "1"])
+    out = bench.side_process("dp_rank_local", args, timeout_s=120)
+    assert set(out) == {"error"} and "dp_rank_local" in out["error"] and "code 1" in out["error"], out
+
+
+@pytest.mark.gpu
+def test_the_side_process_returns_the_rank_local_table():
+    import bench
+    args = bench.parse_args(["--steps", "3", "--warmup", "1"])
+    out = bench.side_process("dp_rank_local", args, timeout_s=280)
+    assert "error" not in out and out["local_fast"]["poses_fixed_graph_segments"] >= 2 and out["local_fast"]["poses_fixed_eager_ms"] > 0, out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,extra", [(2, []), (2, ["--sharded-adam"]), (4, []), (2, ["--grad-comm", "bf16"])])
 def test_plain_command_rehearsal_on_one_gpu(n, extra):
